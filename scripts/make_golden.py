@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (hjxwhy/mipnerf_pl,
+mounted read-only at /root/reference) on CPU with seeded inputs.
+
+Run (only possible in the build container; the GPU box has no /root/reference):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 -B /root/repo/scripts/make_golden.py
+
+The reference's own tests hold no golden vectors (it has no tests), so these files
+are the pin for oracle/mipnerf_oracle.py and, through it, for the HIP path.
+Import recipe: SURVEY.md section 8(c) -- stub `cv2` (only used at datasets.py:196),
+put /root/reference first on sys.path so its `datasets/` wins over HuggingFace's.
+"""
+import os
+import sys
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("MIPNERF_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.path.insert(0, REF)
+sys.path.insert(1, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from datasets.datasets import Rays as RefRays  # noqa: E402  (reference)
+from models import mip as refmip  # noqa: E402  (reference)
+from models.mip_nerf import MipNerf as RefMipNerf  # noqa: E402  (reference)
+
+from oracle import mipnerf_oracle as orc  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(os.cpu_count())
+
+
+def to_ref_rays(rays):
+    return RefRays(*[torch.from_numpy(np.asarray(a)) for a in rays])
+
+
+def load_params(model, params):
+    sd = {"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+
+
+def rays_dict(rays):
+    return {"rays_" + k: np.asarray(v) for k, v in rays._asdict().items()}
+
+
+def ret_dict(ret, prefix=""):
+    d = {}
+    for lvl, (rgb, dist, acc, w, t) in enumerate(ret):
+        for name, v in zip(("rgb", "distance", "acc", "weights", "t_samples"), (rgb, dist, acc, w, t)):
+            d[f"{prefix}l{lvl}_{name}"] = v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)
+    return d
+
+
+def maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+def check_oracle(tag, ref_ret, orc_ret, tol):
+    worst = 0.0
+    for lvl in range(len(ref_ret)):
+        for name, r, o in zip(("rgb", "distance", "acc", "weights", "t_samples"), ref_ret[lvl], orc_ret[lvl]):
+            d = maxdiff(r.detach().numpy(), o)
+            worst = max(worst, d)
+            assert d <= tol, f"{tag}: oracle vs reference level {lvl} {name}: {d} > {tol}"
+    print(f"  [{tag}] oracle vs reference max|diff| = {worst:.3e} (tol {tol:g})")
+
+
+def forward_case(name, batch, num_samples, param_seed, gain, ray_seed, multiscale=False,
+                 unbounded=False, disparity=False):
+    rays = orc.synthetic_rays(batch, seed=ray_seed, multiscale=multiscale, unbounded=unbounded)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples, disparity=disparity)
+    load_params(model, params)
+    model.eval()
+    out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain,
+               ray_seed=ray_seed, disparity=int(disparity))
+    with torch.no_grad():
+        for wb in (True, False):
+            ret = model(to_ref_rays(rays), False, wb)
+            out.update(ret_dict(ret, prefix=f"wb{int(wb)}_"))
+            oret = orc.mipnerf_forward(params, rays, False, wb, num_samples=num_samples,
+                                       disparity=disparity)
+            check_oracle(f"{name}/wb{int(wb)}", ret, oret, 2e-4)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz  max sigma-ish acc={float(out['wb1_l1_acc'].max()):.3f}")
+
+
+def randomized_case(name, batch, num_samples, param_seed, gain, ray_seed, torch_seed):
+    rays = orc.synthetic_rays(batch, seed=ray_seed)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples)
+    load_params(model, params)
+    with torch.no_grad():
+        torch.manual_seed(torch_seed)
+        ret = model(to_ref_rays(rays), True, True)
+        # replay the two draws of the reference (mip.py:159 torch.rand, mip.py:201 uniform_)
+        torch.manual_seed(torch_seed)
+        t_rand = torch.rand(batch, num_samples + 1).numpy()
+        u_rand = torch.empty(batch, num_samples + 1).uniform_(0, 1).numpy()
+    oret = orc.mipnerf_forward(params, rays, True, True, num_samples=num_samples,
+                               t_rand=t_rand, u_rand=u_rand)
+    check_oracle(name, ret, oret, 2e-4)
+    out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain,
+               ray_seed=ray_seed, t_rand=t_rand, u_rand=u_rand)
+    out.update(ret_dict(ret, prefix="wb1_"))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz")
+
+
+def stage_case(name, batch, num_samples, param_seed, gain, ray_seed):
+    """Per-function goldens: every free function of models/mip.py on the hot path,
+    called directly on the reference."""
+    rays = orc.synthetic_rays(batch, seed=ray_seed, multiscale=True)
+    R = to_ref_rays(rays)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples)
+    load_params(model, params)
+    out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain)
+    with torch.no_grad():
+        t0, (m0, c0) = refmip.sample_along_rays(R.origins, R.directions, R.radii, num_samples,
+                                                R.near, R.far, False, False, "cone")
+        enc0 = refmip.integrated_pos_enc((m0, c0), 0, 16)
+        venc = refmip.pos_enc(R.viewdirs, 0, 4, True)
+        raw_rgb, raw_density = model.mlp(enc0, venc)
+        rgb = torch.sigmoid(raw_rgb) * (1 + 2 * 0.001) - 0.001
+        density = torch.nn.functional.softplus(raw_density - 1.0)
+        comp = refmip.volumetric_rendering(rgb, density, t0, R.directions, True)
+        t1, (m1, c1) = refmip.resample_along_rays(R.origins, R.directions, R.radii, t0, comp[3],
+                                                  False, "cone", True, 0.01)
+        enc1 = refmip.integrated_pos_enc((m1, c1), 0, 16)
+        dl = refmip.distloss(comp[3], t0)
+        # the PDF sampler alone, on adversarial weights (zeros, one-hot, tiny)
+        wz = torch.zeros(4, num_samples)
+        wz[1, 5] = 1.0
+        wz[2] = 1e-9
+        wz[3] = torch.linspace(0, 1, num_samples)
+        bins = t0[:4].clone()
+        pdf_t = refmip.sorted_piecewise_constant_pdf(bins, wz.clone(), num_samples + 1, False)
+    out.update(t0=t0.numpy(), means0=m0.numpy(), covs0=c0.numpy(), enc0=enc0.numpy(),
+               viewdirs_enc=venc.numpy(), raw_rgb0=raw_rgb.numpy(), raw_density0=raw_density.numpy(),
+               rgb0=rgb.numpy(), density0=density.numpy(), comp_rgb0=comp[0].numpy(),
+               distance0=comp[1].numpy(), acc0=comp[2].numpy(), weights0=comp[3].numpy(),
+               t1=t1.numpy(), means1=m1.numpy(), covs1=c1.numpy(), enc1=enc1.numpy(),
+               distloss0=np.float32(dl.item()), pdf_w=wz.numpy(), pdf_bins=bins.numpy(),
+               pdf_t=pdf_t.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz  density range [{float(density.min()):.3g}, {float(density.max()):.3g}]")
+
+
+def grad_case(name, batch, num_samples, param_seed, gain, ray_seed):
+    """Training-step golden: loss of nerf_system.py:99-111 (restated there is no way to
+    import it without pytorch_lightning) + grads of every parameter from the reference
+    autograd graph.  Grads are stored as (l2, sum, 64 strided samples) per tensor."""
+    rays = orc.synthetic_rays(batch, seed=ray_seed, multiscale=True)
+    R = to_ref_rays(rays)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples)
+    load_params(model, params)
+    gt = np.random.default_rng(1).uniform(0, 1, size=(batch, 3)).astype(np.float32)
+    rgbs = torch.from_numpy(gt)
+    ret = model(R, False, True)
+    mask = R.lossmult
+    losses, dls = [], []
+    for (rgb, _, _, w, t) in ret:
+        losses.append((mask * (rgb - rgbs[..., :3]) ** 2).sum() / mask.sum())
+        dls.append(refmip.distloss(w, t))
+    loss = 0.1 * (losses[0] + 0.01 * dls[0]) + losses[1] + 0.01 * dls[-1]
+    loss.backward()
+    out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain,
+               gt=gt, loss=np.float32(loss.item()),
+               mse=np.array([l.item() for l in losses], np.float32),
+               distloss=np.array([d.item() for d in dls], np.float32))
+    out.update(ret_dict(ret, prefix="wb1_"))
+    for k, p in model.named_parameters():
+        g = p.grad.detach().numpy().ravel()
+        stride = max(1, g.size // 64)
+        key = k.replace("mlp.", "")
+        out["g_l2_" + key] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["g_sum_" + key] = np.float64(g.astype(np.float64).sum())
+        out["g_smp_" + key] = g[::stride][:64].copy()
+    oloss = orc.training_loss([tuple(x.detach().numpy() for x in lv) for lv in ret], rays, gt)
+    assert abs(float(oloss) - float(loss.item())) < 1e-5, (oloss, loss.item())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz loss={loss.item():.6f}")
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "reference not mounted"
+    # BASELINE.json configs[0]: 256 rays x 64 samples (the reference's CPU-runnable case)
+    forward_case("fwd_c1_256x64_xavier", 256, 64, param_seed=0, gain=1.0, ray_seed=0)
+    forward_case("fwd_c1_256x64_trained", 256, 64, param_seed=1, gain=40.0, ray_seed=1)
+    # ragged batch (render tail), N=128 as configs[1], multiscale radii
+    forward_case("fwd_ragged_100x128_trained", 100, 128, param_seed=2, gain=40.0, ray_seed=2,
+                 multiscale=True)
+    # configs[3]-like: per-ray near/far, N=256
+    forward_case("fwd_unbounded_24x256_trained", 24, 256, param_seed=3, gain=40.0, ray_seed=3,
+                 unbounded=True)
+    forward_case("fwd_disparity_32x64_trained", 32, 64, param_seed=4, gain=40.0, ray_seed=4,
+                 disparity=True)
+    randomized_case("fwd_randomized_64x128_trained", 64, 128, param_seed=5, gain=40.0, ray_seed=5,
+                    torch_seed=1234)
+    stage_case("stages_16x64_trained", 16, 64, param_seed=6, gain=40.0, ray_seed=6)
+    grad_case("train_64x64_trained", 64, 64, param_seed=7, gain=40.0, ray_seed=7)
+    print("done")

@@ -1,0 +1,124 @@
+"""CPU: the numpy oracle against the golden vectors generated from the unmodified
+reference (scripts/make_golden.py).  This is the pin that makes the oracle trustworthy."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import mipnerf_oracle as orc
+
+FWD_CASES = [
+    "fwd_c1_256x64_xavier", "fwd_c1_256x64_trained", "fwd_ragged_100x128_trained",
+    "fwd_unbounded_24x256_trained", "fwd_disparity_32x64_trained",
+]
+NAMES = ("rgb", "distance", "acc", "weights", "t_samples")
+# fp32 tolerance of the oracle vs the reference: both are fp32 on CPU, differences come from
+# BLAS summation order and libm (sleef vs numpy) ulps, amplified by exp() in compositing.
+TOL = 5e-5
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def rays_of(g):
+    return orc.Rays(*[g["rays_" + k] for k in orc.Rays._fields])
+
+
+@pytest.mark.parametrize("name", FWD_CASES)
+@pytest.mark.parametrize("wb", [True, False])
+def test_forward_matches_reference(golden_dir, name, wb):
+    g = load(golden_dir, name)
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    ret = orc.mipnerf_forward(params, rays_of(g), False, wb, num_samples=int(g["num_samples"]),
+                              disparity=bool(g["disparity"]))
+    for lvl in range(2):
+        for nm, val in zip(NAMES, ret[lvl]):
+            ref = g[f"wb{int(wb)}_l{lvl}_{nm}"]
+            assert val.shape == ref.shape and val.dtype == np.float32
+            np.testing.assert_allclose(val, ref, rtol=0, atol=TOL, err_msg=f"{name} l{lvl} {nm}")
+
+
+def test_randomized_matches_reference(golden_dir):
+    g = load(golden_dir, "fwd_randomized_64x128_trained")
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    ret = orc.mipnerf_forward(params, rays_of(g), True, True, num_samples=int(g["num_samples"]),
+                              t_rand=g["t_rand"], u_rand=g["u_rand"])
+    for lvl in range(2):
+        for nm, val in zip(NAMES, ret[lvl]):
+            np.testing.assert_allclose(val, g[f"wb1_l{lvl}_{nm}"], rtol=0, atol=TOL)
+
+
+def test_stage_functions_match_reference(golden_dir):
+    g = load(golden_dir, "stages_16x64_trained")
+    rays = rays_of(g)
+    N = int(g["num_samples"])
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    t0, (m0, c0) = orc.sample_along_rays(rays.origins, rays.directions, rays.radii, N, rays.near,
+                                         rays.far, False, False)
+    np.testing.assert_array_equal(t0, g["t0"])
+    np.testing.assert_allclose(m0, g["means0"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(c0, g["covs0"], rtol=2e-5, atol=1e-12)
+    enc0 = orc.integrated_pos_enc((g["means0"], g["covs0"]), 0, 16)
+    np.testing.assert_allclose(enc0, g["enc0"], rtol=0, atol=2e-6)
+    venc = orc.pos_enc(rays.viewdirs, 0, 4, True)
+    np.testing.assert_allclose(venc, g["viewdirs_enc"], rtol=0, atol=1e-6)
+    raw_rgb, raw_density = orc.mlp_forward(params, g["enc0"], g["viewdirs_enc"])
+    np.testing.assert_allclose(raw_rgb, g["raw_rgb0"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(raw_density, g["raw_density0"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(orc.softplus(g["raw_density0"] - np.float32(1)), g["density0"],
+                               rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(orc.sigmoid(g["raw_rgb0"]) * np.float32(1.002) - np.float32(0.001),
+                               g["rgb0"], rtol=0, atol=1e-6)
+    comp = orc.volumetric_rendering(g["rgb0"], g["density0"], g["t0"], rays.directions, True)
+    for val, key in zip(comp, ("comp_rgb0", "distance0", "acc0", "weights0")):
+        np.testing.assert_allclose(val, g[key], rtol=0, atol=5e-6)
+    t1, (m1, c1) = orc.resample_along_rays(rays.origins, rays.directions, rays.radii, g["t0"],
+                                           g["weights0"], False)
+    np.testing.assert_allclose(t1, g["t1"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(orc.distloss(g["weights0"], g["t0"]), g["distloss0"], rtol=1e-5)
+    pdf_t = orc.sorted_piecewise_constant_pdf(g["pdf_bins"], g["pdf_w"], N + 1, False)
+    np.testing.assert_allclose(pdf_t, g["pdf_t"], rtol=0, atol=5e-6)
+
+
+def test_training_loss_matches_reference(golden_dir):
+    g = load(golden_dir, "train_64x64_trained")
+    ret = [tuple(g[f"wb1_l{l}_{nm}"] for nm in NAMES) for l in range(2)]
+    loss = orc.training_loss(ret, rays_of(g), g["gt"])
+    np.testing.assert_allclose(loss, g["loss"], rtol=1e-5)
+
+
+# ---- known-answer checks derived from the reference code ----------
+def test_known_answers():
+    B, N = 3, 64
+    rays = orc.synthetic_rays(B, seed=9)
+    t = np.broadcast_to(orc.torch_linspace(2, 6, N + 1), (B, N + 1)).astype(np.float32)
+    rgb = np.full((B, N, 3), 0.25, np.float32)
+    zero = np.zeros((B, N, 1), np.float32)
+    c, d, a, w = orc.volumetric_rendering(rgb, zero, t, rays.directions, True)
+    assert np.all(a == 0) and np.all(c == 1) and np.all(d == t[:, 0])     # zero density, white
+    c, d, a, w = orc.volumetric_rendering(rgb, zero, t, rays.directions, False)
+    assert np.all(c == 0)
+    dens = zero.copy()
+    dens[:, 10, 0] = 1e6                                                   # opaque bin 10
+    c, d, a, w = orc.volumetric_rendering(rgb, dens, t, rays.directions, False)
+    assert np.allclose(w[:, 10], 1) and np.allclose(np.delete(w, 10, axis=1), 0)
+    np.testing.assert_allclose(d, 0.5 * (t[:, 10] + t[:, 11]), rtol=1e-6)
+    # uniform weights => resampled t is the linear map of u
+    tt = orc.sorted_piecewise_constant_pdf(t, np.ones((B, N), np.float32), N + 1, False)
+    np.testing.assert_allclose(tt, t, atol=2e-6)
+    # IPE with zero covariance == plain PE ordering [sin l0(xyz) .. l15 | cos ..]
+    m = np.array([[[0.1, -0.2, 0.3]]], np.float32)
+    e = orc.integrated_pos_enc((m, np.zeros_like(m)), 0, 16)
+    assert e.shape == (1, 1, 96)
+    np.testing.assert_allclose(e[0, 0, :3], np.sin(m[0, 0]), atol=1e-7)
+    np.testing.assert_allclose(e[0, 0, 3:6], np.sin(2 * m[0, 0]), atol=1e-7)
+    np.testing.assert_allclose(e[0, 0, 48:51], np.cos(m[0, 0]), atol=1e-6)
+    # MLP with zero weights => rgb = sigmoid(b)*1.002-0.001
+    p = orc.make_params(seed=0)
+    for k in p:
+        if k.endswith("weight"):
+            p[k][...] = 0
+    rr, dd = orc.mlp_forward(p, np.zeros((1, 2, 96), np.float32), np.zeros((1, 27), np.float32))
+    np.testing.assert_allclose(rr[0, 0], p["color_layer.bias"], atol=1e-7)
+    np.testing.assert_allclose(dd[0, 0], p["density_layer.bias"], atol=1e-7)
