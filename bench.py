@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Benchmark of the Mip-NeRF hot path on MI355X (contract: see the task statement).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one MipNerf.forward (coarse + fine level) over one batch of synthetic lego-like rays
+resident in HBM: BASELINE.json configs[1] = 4096 rays x (128 + 128) samples, bf16 MLP.
+metric = ray-samples/sec (whole job, all ranks), ray-samples per step = B x N x num_levels.
+Ranks shard rays (independent, no data-path collective): weak scaling.
+Also reported: the roofline of the dominant kernel (the bf16 MFMA MLP), timed live with HIP events
+through mipnerf_time_mlp, and the CPU baseline = the numpy oracle on a bounded sample (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FLOP_PER_SAMPLE = 1_220_608          # 2 x 610,304 MAC of the MLP per ray-sample
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from mipnerf_pl_amd import MipNerf, Rays, _lib as L
+    from oracle import mipnerf_oracle as orc       # cpu_baseline leg + synthetic inputs only
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    B, N = args.rays, args.samples
+    rays_np = orc.synthetic_rays(B, seed=100 + rank)
+    params = orc.make_params(seed=0, density_gain=40.0)
+    model = MipNerf(num_samples=N, precision=args.precision)
+    model.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model = model.to(dev)
+    R = Rays(*[torch.from_numpy(a).to(dev) for a in rays_np])
+
+    def step():
+        with torch.no_grad():
+            return model(R, False, True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert bool(torch.isfinite(out[-1][0]).all())
+
+    samples_per_step = B * N * model.num_levels
+    value = samples_per_step * world * args.steps / dt
+
+    # ---- roofline of the dominant kernel (bf16 / fp32 MFMA MLP), HIP events on the launch stream ----
+    roofline = None
+    cpu_baseline = None
+    if rank == 0:
+        prec = model.precision
+        dt_t = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
+        M = B * N
+        enc = (torch.rand(M, 96, device=dev) * 2 - 1).to(dt_t)
+        venc = torch.zeros(B, 32, device=dev, dtype=dt_t)
+        venc[:, :27] = (torch.rand(B, 27, device=dev) * 2 - 1).to(dt_t)
+        rgbs = torch.empty(M, 4, device=dev)
+        ctx = model.mlp.native(dev)
+        import ctypes as C
+        ms = C.c_float()
+        L.check(L.lib().mipnerf_time_mlp(ctx.handle, M, N, enc.data_ptr(), venc.data_ptr(), prec, rgbs.data_ptr(),
+                                         20, C.byref(ms), torch.cuda.current_stream().cuda_stream), "time_mlp")
+        tflops = FLOP_PER_SAMPLE * M / (ms.value * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        roofline = {"bound": "mfma", "kernel": "k_mlp_bf16" if prec == L.PREC_BF16 else "k_mlp_f32",
+                    "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+                    "traffic": None, "launch_ms": round(ms.value, 4), "samples_per_launch": M}
+        if world == 1 and not args.no_cpu_baseline:
+            # bounded sample of the same workload: 256 rays x N x 2 levels through the numpy oracle
+            nb = 256
+            sub = orc.Rays(*[a[:nb] for a in rays_np])
+            orc.mipnerf_forward(params, orc.Rays(*[a[:32] for a in rays_np]), False, True, num_samples=N)  # warm BLAS
+            reps, tcpu = 0, 0.0
+            while tcpu < 10.0 and reps < 20:
+                c0 = time.perf_counter()
+                orc.mipnerf_forward(params, sub, False, True, num_samples=N)
+                tcpu += time.perf_counter() - c0
+                reps += 1
+            cpu_baseline = {"value": round(nb * N * 2 * reps / tcpu, 1), "unit": "ray-samples/s",
+                            "cores": os.cpu_count(), "kind": "port",
+                            "sample": f"{reps} x oracle.mipnerf_forward on {nb} rays x {N} samples x 2 levels (numpy fp32, "
+                                      f"BLAS threads = all cores)"}
+
+    if rank == 0:
+        line = {
+            "metric": "ray-samples/sec", "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) "
+                                   f"samples per GPU, 8x256 MLP, random-init trained-like weights",
+                       "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
+                       "parallelism": f"ray-split x{world} (no data-path collective)"},
+            "per_gpu": round(value / world, 1),
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,204 @@
+/* mipnerf_hip.h -- C ABI of the MI355X-native Mip-NeRF volume-rendering hot path.
+ *
+ * Shared library: mipnerf_pl_amd/csrc/libmipnerf_hip.so (hipcc --offload-arch=gfx950).
+ * The reference (hjxwhy/mipnerf_pl) has no FFI of its own -- its boundary is the Python
+ * class contract `MipNerf.forward(rays, randomized, white_bkgd)` (models/mip_nerf.py:172-248)
+ * built from the free functions of models/mip.py.  Each entry point below replaces one of
+ * those functions (cited per prototype); `mipnerf_forward` replaces the whole level loop.
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch.cuda tensor .data_ptr()) unless
+ *     the parameter name ends in `_host`; float32, row-major, contiguous;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is
+ *     enqueued asynchronously on it, no entry point synchronises or allocates, except
+ *     mipnerf_create / mipnerf_destroy (hipMalloc / hipFree of the packed-weight buffers);
+ *   - return value: 0 = MIPNERF_OK, otherwise an error code; mipnerf_last_error() returns
+ *     a thread-local message.  The Python host turns codes into RuntimeError /
+ *     NotImplementedError (the reference raises NotImplementedError for unsupported
+ *     enum values: mip_nerf.py:50,70,165,170, mip.py:98);
+ *   - inputs are never written; outputs never alias inputs (mip.py:184 mutates its
+ *     argument in place -- this library does not).
+ */
+#ifndef MIPNERF_HIP_H
+#define MIPNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIPNERF_ABI_VERSION 1
+
+enum {
+    MIPNERF_OK = 0,
+    MIPNERF_E_INVALID = 1,      /* bad argument (null pointer, size <= 0, N too large ...) */
+    MIPNERF_E_UNSUPPORTED = 2,  /* NotImplementedError in the reference, or an MLP shape the
+                                   compiled kernels do not cover */
+    MIPNERF_E_HIP = 3,          /* a HIP runtime call failed (message has hipGetErrorString) */
+    MIPNERF_E_WORKSPACE = 4     /* workspace too small */
+};
+
+/* compute precision of the MLP (the rest of the path is always fp32) */
+enum {
+    MIPNERF_PREC_FP32 = 0, /* v_mfma_f32_32x32x2_f32, exact fp32 products (parity mode)   */
+    MIPNERF_PREC_BF16 = 1  /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate    */
+};
+
+/* flags */
+enum {
+    MIPNERF_FLAG_WHITE_BKGD = 1, /* volumetric_rendering(white_bkgd=True), mip.py:399-400  */
+    MIPNERF_FLAG_DISPARITY = 2   /* sample linearly in disparity, mip.py:149-150           */
+};
+
+/* Mirrors the keyword arguments of MipNerf.__init__ (models/mip_nerf.py:117-141) that
+ * change the arithmetic.  ray_shape is always 'cone' ('cylinder' raises in the reference). */
+typedef struct mipnerf_config {
+    int32_t num_samples;         /* nerf.num_samples, N (<= MIPNERF_MAX_SAMPLES)           */
+    int32_t num_levels;          /* nerf.num_levels (1 or 2)                                */
+    int32_t min_deg_point;       /* 0                                                       */
+    int32_t max_deg_point;       /* 16                                                      */
+    int32_t deg_view;            /* 4                                                       */
+    int32_t use_viewdirs;        /* 1                                                       */
+    int32_t disparity;           /* 0                                                       */
+    int32_t disable_integration; /* 0 ; 1 => covariances zeroed before the IPE (PE)         */
+    int32_t net_depth;           /* 8                                                       */
+    int32_t net_width;           /* 256                                                     */
+    int32_t net_depth_condition; /* 1                                                       */
+    int32_t net_width_condition; /* 128                                                     */
+    int32_t skip_index;          /* 4                                                       */
+    int32_t num_rgb_channels;    /* 3                                                       */
+    int32_t num_density_channels;/* 1                                                       */
+    float resample_padding;      /* 0.01                                                    */
+    float density_bias;          /* -1                                                      */
+    float rgb_padding;           /* 0.001                                                   */
+} mipnerf_config;
+
+#define MIPNERF_MAX_SAMPLES 512
+#define MIPNERF_NUM_PARAM_TENSORS 24 /* 2 x (8 trunk + density + extra + 1 view + color)   */
+
+/* The 7 fields of the reference `Rays` namedtuple (datasets/datasets.py:13-16), SoA. */
+typedef struct mipnerf_rays {
+    const float* origins;    /* [B,3] */
+    const float* directions; /* [B,3] un-normalised */
+    const float* viewdirs;   /* [B,3] unit          */
+    const float* radii;      /* [B,1] */
+    const float* lossmult;   /* [B,1] (unused by forward) */
+    const float* near;       /* [B,1] */
+    const float* far;        /* [B,1] */
+} mipnerf_rays;
+
+/* One level of the list returned by MipNerf.forward (mip_nerf.py:246). */
+typedef struct mipnerf_level_out {
+    float* comp_rgb;  /* [B,3]   */
+    float* distance;  /* [B]     */
+    float* acc;       /* [B]     */
+    float* weights;   /* [B,N]   */
+    float* t_samples; /* [B,N+1] */
+} mipnerf_level_out;
+
+typedef struct mipnerf_ctx mipnerf_ctx;
+
+const char* mipnerf_last_error(void);
+int mipnerf_abi_version(void);
+
+/* ---- context: configuration + packed weights ------------------------------------------ */
+/* MipNerf.__init__ (mip_nerf.py:117-170).  Fails with MIPNERF_E_UNSUPPORTED when the MLP
+ * shape is not the one the MFMA kernels were generated for (see mipnerf_compiled_arch). */
+int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out);
+int mipnerf_destroy(mipnerf_ctx* ctx);
+/* Writes the MLP shape the library was compiled for into *cfg (other fields defaulted). */
+int mipnerf_compiled_arch(mipnerf_config* cfg);
+
+/* (Re)pack the fp32 master parameters into the MFMA operand streams (bf16 fragment stream,
+ * fp32 fragment stream, bias tables).  `params` is a HOST array of
+ * MIPNERF_NUM_PARAM_TENSORS device pointers in state_dict order of the reference MLP
+ * (mip_nerf.py:19-73): layers.{0..7}.0.{weight,bias}, density_layer.{weight,bias},
+ * extra_layer.{weight,bias}, view_layers.0.0.{weight,bias}, color_layer.{weight,bias}.
+ * Call after every optimizer step / load_state_dict. */
+int mipnerf_set_params(mipnerf_ctx* ctx, const float* const* params_host, void* stream);
+
+/* ---- the whole hot path: MipNerf.forward (mip_nerf.py:172-248) ------------------------ */
+size_t mipnerf_workspace_bytes(const mipnerf_ctx* ctx, int64_t num_rays);
+/* t_rand [B,N+1] / u_rand [B,N+1]: uniform [0,1) noise replacing torch.rand (mip.py:159)
+ * and uniform_ (mip.py:201); both NULL <=> randomized=False.  out[level], level <
+ * num_levels. */
+int mipnerf_forward(mipnerf_ctx* ctx, int64_t num_rays, const mipnerf_rays* rays,
+                    const float* t_rand, const float* u_rand, uint32_t flags, int precision,
+                    void* workspace, size_t workspace_bytes, const mipnerf_level_out* out,
+                    void* stream);
+
+/* ---- per-stage entry points (each parity-tested alone) --------------------------------- */
+/* sample_along_rays (mip.py:127-165), t part: t_samples [B,N+1]. */
+int mipnerf_sample_along_rays(int64_t num_rays, int32_t num_samples, const float* near,
+                              const float* far, const float* t_rand, int32_t disparity,
+                              float* t_samples, void* stream);
+/* cast_rays (mip.py:81-103) + conical_frustum_to_gaussian (50-78) + lift_gaussian (22-36):
+ * means, covs [B,N,3] (either may be NULL). */
+int mipnerf_cast_rays(int64_t num_rays, int32_t num_samples, const float* t_samples,
+                      const float* origins, const float* directions, const float* radii,
+                      float* means, float* covs, void* stream);
+/* cast_rays + integrated_pos_enc (mip.py:322-350) fused: enc [B*N, 6*(max_deg-min_deg)];
+ * out_dtype MIPNERF_PREC_FP32 (float) or MIPNERF_PREC_BF16 (bfloat16 RNE). */
+int mipnerf_cast_ipe(int64_t num_rays, int32_t num_samples, int32_t min_deg, int32_t max_deg,
+                     int32_t disable_integration, const float* t_samples, const float* origins,
+                     const float* directions, const float* radii, void* enc, int out_dtype,
+                     void* stream);
+/* integrated_pos_enc (mip.py:322-350, diagonal) on given means / covs [M,3]. */
+int mipnerf_integrated_pos_enc(int64_t num_points, int32_t min_deg, int32_t max_deg,
+                               const float* means, const float* covs, void* enc, int out_dtype,
+                               void* stream);
+/* pos_enc(viewdirs, 0, deg_view, append_identity=True) (mip.py:353-363): [B, 3+6*deg_view]
+ * written with row stride `ld` elements (ld >= 3+6*deg; pad columns zeroed). */
+int mipnerf_pos_enc(int64_t num_rays, int32_t deg_view, const float* viewdirs, void* out,
+                    int32_t ld, int out_dtype, void* stream);
+/* MLP.forward (mip_nerf.py:75-111) + activations (mip_nerf.py:236-238):
+ * enc [M,96] (dtype = precision), viewenc [B,32] (dtype = precision, ld 32),
+ * sample m belongs to ray m / num_samples.  rgb_sigma [M,4] = (r,g,b,sigma) after
+ * sigmoid/padding and softplus(raw+bias); raw [M,4] = (raw_rgb, raw_density) or NULL. */
+int mipnerf_mlp_forward(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples,
+                        const void* enc, const void* viewenc, int precision, float* rgb_sigma,
+                        float* raw, void* stream);
+/* volumetric_rendering (mip.py:366-401). */
+int mipnerf_volumetric_rendering(int64_t num_rays, int32_t num_samples, const float* rgb_sigma,
+                                 const float* t_samples, const float* directions,
+                                 int32_t white_bkgd, float* comp_rgb, float* distance, float* acc,
+                                 float* weights, void* stream);
+/* resample_along_rays (mip.py:232-280) t part: blur-pool + padding +
+ * sorted_piecewise_constant_pdf (mip.py:168-229) with num_samples+1 draws. */
+int mipnerf_resample_along_rays(int64_t num_rays, int32_t num_samples, const float* t_samples,
+                                const float* weights, const float* u_rand, float resample_padding,
+                                float* t_new, void* stream);
+/* sorted_piecewise_constant_pdf alone (mip.py:168-229): bins [B,N+1], weights [B,N]
+ * (not mutated), num_draws samples out [B,num_draws]. */
+int mipnerf_sorted_piecewise_constant_pdf(int64_t num_rays, int32_t num_bins, const float* bins,
+                                          const float* weights, int32_t num_draws,
+                                          const float* u_rand, float* samples, void* stream);
+
+/* ---- instrumentation ------------------------------------------------------------------ */
+/* Times `iters` launches of the bf16 MLP kernel with hipEvents on `stream`; returns the
+ * average milliseconds per launch in *ms (used by bench.py for roofline.achieved). */
+int mipnerf_time_mlp(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples, const void* enc,
+                     const void* viewenc, int precision, float* rgb_sigma, int iters, float* ms,
+                     void* stream);
+/* Hardware self-test of the MFMA fragment layouts and the LDS-DMA path the kernels rely
+ * on; returns 0 when the device behaves as the kernels assume (message in
+ * mipnerf_last_error() either way). */
+int mipnerf_selftest(void* stream);
+/* Tuning / debug knobs.  option 0: bf16 MLP weight staging (1 = global_load_lds ring
+ * [default], 0 = register-staged ring, same schedule); option 1: persistent grid size of the
+ * bf16 MLP kernel (default = number of CUs). */
+int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
+/* Host-only exports of the static plan tables (no GPU needed), used by the CPU tests to
+ * prove the C++ plan expansion equals mipnerf_pl_amd/mlp_plan.py.  which: 0 = bf16 stream
+ * pack table, 1 = bias table, 2 = fp32 stream pack table (flat parameter indices, -1 = 0).
+ * Return the element count; copy only when cap is large enough. */
+int64_t mipnerf_debug_table(int which, int32_t* out_host, int64_t cap);
+int64_t mipnerf_debug_f32net(int32_t* out_host, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIPNERF_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libmipnerf_hip.so (the C ABI declared in include/mipnerf_hip.h).
+
+The library is built in-tree by `python -m mipnerf_pl_amd.build` (hipcc --offload-arch=gfx950).
+There is no CPU fallback: if the shared object is missing, loading fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libmipnerf_hip.so")
+
+OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_WORKSPACE = 0, 1, 2, 3, 4
+PREC_FP32, PREC_BF16 = 0, 1
+FLAG_WHITE_BKGD, FLAG_DISPARITY = 1, 2
+NUM_PARAM_TENSORS = 24
+MAX_SAMPLES = 512
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "num_samples", "num_levels", "min_deg_point", "max_deg_point", "deg_view", "use_viewdirs",
+        "disparity", "disable_integration", "net_depth", "net_width", "net_depth_condition",
+        "net_width_condition", "skip_index", "num_rgb_channels", "num_density_channels")] + [
+        ("resample_padding", C.c_float), ("density_bias", C.c_float), ("rgb_padding", C.c_float)]
+
+
+class RaysPtrs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("origins", "directions", "viewdirs", "radii", "lossmult", "near", "far")]
+
+
+class LevelOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("comp_rgb", "distance", "acc", "weights", "t_samples")]
+
+
+_P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/mipnerf_hip.h declares
+SIGNATURES = {
+    "mipnerf_last_error": (C.c_char_p, []),
+    "mipnerf_abi_version": (C.c_int, []),
+    "mipnerf_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
+    "mipnerf_destroy": (C.c_int, [_P]),
+    "mipnerf_compiled_arch": (C.c_int, [C.POINTER(Config)]),
+    "mipnerf_set_params": (C.c_int, [_P, C.POINTER(_P), _P]),
+    "mipnerf_workspace_bytes": (_SZ, [_P, _I64]),
+    "mipnerf_forward": (C.c_int, [_P, _I64, C.POINTER(RaysPtrs), _P, _P, C.c_uint32, C.c_int, _P, _SZ,
+                                  C.POINTER(LevelOut), _P]),
+    "mipnerf_sample_along_rays": (C.c_int, [_I64, _I32, _P, _P, _P, _I32, _P, _P]),
+    "mipnerf_cast_rays": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "mipnerf_cast_ipe": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "mipnerf_integrated_pos_enc": (C.c_int, [_I64, _I32, _I32, _P, _P, _P, C.c_int, _P]),
+    "mipnerf_pos_enc": (C.c_int, [_I64, _I32, _P, _P, _I32, C.c_int, _P]),
+    "mipnerf_mlp_forward": (C.c_int, [_P, _I64, _I32, _P, _P, C.c_int, _P, _P, _P]),
+    "mipnerf_volumetric_rendering": (C.c_int, [_I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
+    "mipnerf_resample_along_rays": (C.c_int, [_I64, _I32, _P, _P, _P, _F, _P, _P]),
+    "mipnerf_sorted_piecewise_constant_pdf": (C.c_int, [_I64, _I32, _P, _P, _I32, _P, _P, _P]),
+    "mipnerf_time_mlp": (C.c_int, [_P, _I64, _I32, _P, _P, C.c_int, _P, C.c_int, C.POINTER(_F), _P]),
+    "mipnerf_selftest": (C.c_int, [_P]),
+    "mipnerf_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
+    "mipnerf_debug_table": (_I64, [C.c_int, _P, _I64]),
+    "mipnerf_debug_f32net": (_I64, [_P, _I64]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle with argtypes set."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MI355X-native Mip-NeRF path has no CPU fallback. "
+                "Build it with `python -m mipnerf_pl_amd.build` (needs hipcc / ROCm).")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)       # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().mipnerf_last_error() or b"").decode(errors="replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    """Turn a C error code into the exception the reference would raise."""
+    if rc == OK:
+        return
+    msg = f"{what}: {last_error()}" if what else last_error()
+    if rc == E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == E_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(f"{msg} (code {rc})")

@@ -1,0 +1,454 @@
+// C ABI of libmipnerf_hip.so (see include/mipnerf_hip.h): context, weight packing, per-stage
+// entry points and the level loop of MipNerf.forward (models/mip_nerf.py:172-248).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mipnerf_hip.h"
+#include "kernels.hpp"
+#include "mlp_plan_gen.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(MIPNERF_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+using mip::plan::kOps;
+using mip::plan::kNumOps;
+
+// ---- plan expansion (mirror of mlp_plan.Plan.pack_table / bias_table / pack_table_f32) ----------
+struct Tables {
+    std::vector<int32_t> pack_bf16;   // [kNumChunks*512] flat parameter index or -1
+    std::vector<int32_t> bias;        // [kNumTiles*32]
+    std::vector<int32_t> pack_f32;    // [kNumChunks*512]
+    std::vector<int> tensor_off;      // flat offset of each parameter tensor
+    mip::F32Net net;
+};
+
+int kmap(int kind, int ksl, int hi, int j) {
+    if (kind == 0) return ksl * 16 + hi * 8 + j;
+    const int t = ksl >> 1, u = ksl & 1;
+    return 32 * t + 8 * (2 * u + (j >> 2)) + 4 * hi + (j & 3);
+}
+
+void build_tables(Tables& T) {
+    using namespace mip::plan;
+    T.tensor_off.resize(kNumParamTensors);
+    int off = 0;
+    for (int i = 0; i < kNumParamTensors; ++i) { T.tensor_off[i] = off; off += kParamNumel[i]; }
+    T.pack_bf16.assign((size_t)kNumChunks * 512, -1);
+    T.pack_f32.assign((size_t)kNumChunks * 512, -1);
+    T.bias.assign((size_t)kNumTiles * 32, -1);
+    size_t ci = 0;
+    auto fill_chunk = [&](const OpDesc& op, int ti, int ks) {
+        const TileDesc& tile = op.tiles[ti];
+        int ksl = ks, si = 0;
+        while (ksl >= op.segs[si].nk) { ksl -= op.segs[si].nk; ++si; }
+        const SegDesc& seg = op.segs[si];
+        for (int hi = 0; hi < 2; ++hi)
+            for (int j = 0; j < 8; ++j) {
+                const int c = kmap(seg.kind, ksl, hi, j);
+                if (c >= seg.ncols) continue;
+                for (int m = 0; m < tile.nrows; ++m)
+                    T.pack_bf16[ci * 512 + (size_t)(hi * 32 + m) * 8 + j] =
+                        T.tensor_off[tile.wt] + (tile.row0 + m) * tile.ld + seg.col0 + c;
+            }
+        ++ci;
+    };
+    for (int oi = 0; oi < kNumOps; ++oi) {
+        const OpDesc& op = kOps[oi];
+        int nk = 0;
+        for (int s = 0; s < op.nsegs; ++s) nk += op.segs[s].nk;
+        for (int t = 0; t < op.ntiles; t += 2) {
+            const bool pair = t + 1 < op.ntiles;
+            for (int ks = 0; ks < nk; ++ks) {
+                fill_chunk(op, t, ks);
+                if (pair) fill_chunk(op, t + 1, ks);
+            }
+        }
+        for (int t = 0; t < op.ntiles; ++t)
+            for (int hi = 0; hi < 2; ++hi)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < op.tiles[t].nrows)
+                        T.bias[(size_t)(op.first_tile + t) * 32 + hi * 16 + r] =
+                            T.tensor_off[op.tiles[t].bt] + op.tiles[t].row0 + row;
+                }
+    }
+    // fp32 stream: [op][tile][kb], natural column order
+    mip::F32Net& net = T.net;
+    memset(&net, 0, sizeof net);
+    net.nlayers = kNumOps;
+    net.width = kNetWidth;
+    net.xyz_dim = kXyzDim;
+    net.ldx = kNetWidth + (kXyzDim > 32 ? kXyzDim : 32) + 4;
+    size_t cf = 0;
+    for (int oi = 0; oi < kNumOps; ++oi) {
+        const OpDesc& op = kOps[oi];
+        std::vector<int> colmap;
+        for (int s = 0; s < op.nsegs; ++s)
+            for (int c = 0; c < op.segs[s].nk * 16; ++c)
+                colmap.push_back(c < op.segs[s].ncols ? op.segs[s].col0 + c : -1);
+        const int kb = (int)colmap.size() / 16;
+        mip::F32Layer& L = net.layers[oi];
+        L.x_in = op.xcol_in;
+        L.kb = kb;
+        L.ntiles = op.ntiles;
+        L.first_tile = op.first_tile;
+        L.relu = op.relu;
+        L.kind = op.kind;
+        L.chunk0 = (int)cf;
+        for (int t = 0; t < op.ntiles; ++t)
+            for (int k = 0; k < kb; ++k) {
+                const TileDesc& tile = op.tiles[t];
+                for (int hi = 0; hi < 2; ++hi)
+                    for (int j = 0; j < 8; ++j) {
+                        const int col = colmap[k * 16 + hi * 8 + j];
+                        if (col < 0) continue;
+                        for (int m = 0; m < tile.nrows; ++m)
+                            T.pack_f32[cf * 512 + (size_t)(hi * 32 + m) * 8 + j] =
+                                T.tensor_off[tile.wt] + (tile.row0 + m) * tile.ld + col;
+                    }
+                ++cf;
+            }
+    }
+}
+
+// flat index -> (tensor << 20 | offset) as consumed by k_pack
+std::vector<int32_t> encode(const std::vector<int32_t>& flat, const std::vector<int>& toff) {
+    std::vector<int32_t> out(flat.size());
+    for (size_t i = 0; i < flat.size(); ++i) {
+        const int32_t f = flat[i];
+        if (f < 0) { out[i] = -1; continue; }
+        int t = (int)toff.size() - 1;
+        while (toff[t] > f) --t;
+        out[i] = (t << 20) | (f - toff[t]);
+    }
+    return out;
+}
+
+}  // namespace
+
+struct mipnerf_ctx {
+    mipnerf_config cfg;
+    Tables tab;
+    int32_t* d_pack_bf16 = nullptr;
+    int32_t* d_pack_f32 = nullptr;
+    int32_t* d_bias_idx = nullptr;
+    void* d_stream_bf16 = nullptr;   // kNumChunks * 1 KiB
+    float* d_stream_f32 = nullptr;   // kNumChunks * 2 KiB
+    float* d_bias = nullptr;         // kNumTiles * 32 floats
+    bool params_set = false;
+    int mlp_dma = 1;                 // 1: global_load_lds ring, 0: register-staged ring (debug)
+    int grid_limit = 256;            // persistent workgroups of the bf16 MLP kernel (= CUs)
+};
+
+extern "C" {
+
+const char* mipnerf_last_error(void) { return g_err.c_str(); }
+int mipnerf_abi_version(void) { return MIPNERF_ABI_VERSION; }
+
+int mipnerf_compiled_arch(mipnerf_config* cfg) {
+    if (!cfg) return fail(MIPNERF_E_INVALID, "cfg is null");
+    using namespace mip::plan;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->num_samples = 128; cfg->num_levels = 2; cfg->min_deg_point = 0; cfg->max_deg_point = kXyzDim / 6;
+    cfg->deg_view = (kViewDim - 3) / 6; cfg->use_viewdirs = 1; cfg->net_depth = kNetDepth; cfg->net_width = kNetWidth;
+    cfg->net_depth_condition = kNetDepthCond; cfg->net_width_condition = kNetWidthCond; cfg->skip_index = kSkipIndex;
+    cfg->num_rgb_channels = kNumRgb; cfg->num_density_channels = kNumDensity;
+    cfg->resample_padding = 0.01f; cfg->density_bias = -1.0f; cfg->rgb_padding = 0.001f;
+    return MIPNERF_OK;
+}
+
+int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
+    using namespace mip::plan;
+    if (!cfg || !out) return fail(MIPNERF_E_INVALID, "null argument");
+    if (cfg->num_samples < 1 || cfg->num_samples > MIPNERF_MAX_SAMPLES)
+        return fail(MIPNERF_E_INVALID, "num_samples must be in [1, %d]", MIPNERF_MAX_SAMPLES);
+    if (cfg->num_levels < 1 || cfg->num_levels > 2) return fail(MIPNERF_E_UNSUPPORTED, "num_levels must be 1 or 2");
+    if (!cfg->use_viewdirs)
+        return fail(MIPNERF_E_UNSUPPORTED, "use_viewdirs=False is not implemented (the reference MLP would feed a "
+                                           "net_width tensor to color_layer(net_width_condition))");
+    if (cfg->net_depth != kNetDepth || cfg->net_width != kNetWidth || cfg->net_depth_condition != kNetDepthCond ||
+        cfg->net_width_condition != kNetWidthCond || cfg->skip_index != kSkipIndex ||
+        cfg->num_rgb_channels != kNumRgb || cfg->num_density_channels != kNumDensity ||
+        6 * (cfg->max_deg_point - cfg->min_deg_point) != kXyzDim || 3 + 6 * cfg->deg_view != kViewDim)
+        return fail(MIPNERF_E_UNSUPPORTED,
+                    "MLP shape differs from the one the MFMA kernels were generated for (depth %d width %d cond %dx%d "
+                    "skip %d xyz %d view %d); regenerate with gen_mlp_bf16.py",
+                    kNetDepth, kNetWidth, kNetDepthCond, kNetWidthCond, kSkipIndex, kXyzDim, kViewDim);
+    mipnerf_ctx* c = new mipnerf_ctx();
+    c->cfg = *cfg;
+    build_tables(c->tab);
+    const std::vector<int32_t> e_bf16 = encode(c->tab.pack_bf16, c->tab.tensor_off);
+    const std::vector<int32_t> e_f32 = encode(c->tab.pack_f32, c->tab.tensor_off);
+    const std::vector<int32_t> e_bias = encode(c->tab.bias, c->tab.tensor_off);
+    const size_t nst = (size_t)kNumChunks * 512;
+    hipError_t er = hipSuccess;
+    auto chk = [&](hipError_t e) { if (er == hipSuccess) er = e; };
+    chk(hipMalloc(&c->d_pack_bf16, nst * 4));
+    chk(hipMalloc(&c->d_pack_f32, nst * 4));
+    chk(hipMalloc(&c->d_bias_idx, e_bias.size() * 4));
+    chk(hipMalloc(&c->d_stream_bf16, nst * 2));
+    chk(hipMalloc(&c->d_stream_f32, nst * 4));
+    chk(hipMalloc(&c->d_bias, e_bias.size() * 4));
+    if (er == hipSuccess) {
+        chk(hipMemcpy(c->d_pack_bf16, e_bf16.data(), nst * 4, hipMemcpyHostToDevice));
+        chk(hipMemcpy(c->d_pack_f32, e_f32.data(), nst * 4, hipMemcpyHostToDevice));
+        chk(hipMemcpy(c->d_bias_idx, e_bias.data(), e_bias.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (er != hipSuccess) {
+        mipnerf_destroy(c);
+        return fail(MIPNERF_E_HIP, "mipnerf_create: %s", hipGetErrorString(er));
+    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        c->grid_limit = cus;
+    *out = c;
+    return MIPNERF_OK;
+}
+
+int mipnerf_destroy(mipnerf_ctx* c) {
+    if (!c) return MIPNERF_OK;
+    (void)hipFree(c->d_pack_bf16); (void)hipFree(c->d_pack_f32); (void)hipFree(c->d_bias_idx);
+    (void)hipFree(c->d_stream_bf16); (void)hipFree(c->d_stream_f32); (void)hipFree(c->d_bias);
+    delete c;
+    return MIPNERF_OK;
+}
+
+int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
+    if (!c) return fail(MIPNERF_E_INVALID, "ctx is null");
+    switch (option) {
+        case 0: c->mlp_dma = value ? 1 : 0; return MIPNERF_OK;
+        case 1: if (value < 1) return fail(MIPNERF_E_INVALID, "grid_limit < 1"); c->grid_limit = value; return MIPNERF_OK;
+        default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
+    }
+}
+
+int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* stream) {
+    using namespace mip::plan;
+    if (!c || !params_host) return fail(MIPNERF_E_INVALID, "null argument");
+    mip::ParamPtrs pp;
+    memset(&pp, 0, sizeof pp);
+    for (int i = 0; i < kNumParamTensors; ++i) {
+        if (!params_host[i]) return fail(MIPNERF_E_INVALID, "parameter tensor %d is null", i);
+        pp.p[i] = params_host[i];
+    }
+    const int64_t nst = (int64_t)kNumChunks * 512;
+    HIP_TRY(mip::launch_pack(c->d_pack_bf16, nst, pp, c->d_stream_bf16, true, S(stream)));
+    HIP_TRY(mip::launch_pack(c->d_pack_f32, nst, pp, c->d_stream_f32, false, S(stream)));
+    HIP_TRY(mip::launch_pack(c->d_bias_idx, (int64_t)kNumTiles * 32, pp, c->d_bias, false, S(stream)));
+    c->params_set = true;
+    return MIPNERF_OK;
+}
+
+// ---- per-stage entry points -----------------------------------------------------------------------
+int mipnerf_sample_along_rays(int64_t B, int32_t N, const float* nearp, const float* farp, const float* t_rand,
+                              int32_t disparity, float* t_samples, void* stream) {
+    if (B < 1 || N < 1 || !nearp || !farp || !t_samples) return fail(MIPNERF_E_INVALID, "sample_along_rays: bad argument");
+    HIP_TRY(mip::launch_sample_along_rays(B, N, nearp, farp, t_rand, disparity, t_samples, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_cast_rays(int64_t B, int32_t N, const float* t, const float* origins, const float* dirs, const float* radii,
+                      float* means, float* covs, void* stream) {
+    if (B < 1 || N < 1 || !t || !origins || !dirs || !radii) return fail(MIPNERF_E_INVALID, "cast_rays: bad argument");
+    HIP_TRY(mip::launch_cast_rays(B, N, t, origins, dirs, radii, means, covs, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_cast_ipe(int64_t B, int32_t N, int32_t min_deg, int32_t max_deg, int32_t disable_integration, const float* t,
+                     const float* origins, const float* dirs, const float* radii, void* enc, int out_dtype, void* stream) {
+    if (B < 1 || N < 1 || !t || !origins || !dirs || !radii || !enc) return fail(MIPNERF_E_INVALID, "cast_ipe: bad argument");
+    if (max_deg - min_deg != 16 || min_deg < 0 || max_deg > 31)
+        return fail(MIPNERF_E_UNSUPPORTED, "cast_ipe is generated for max_deg-min_deg == 16");
+    HIP_TRY(mip::launch_cast_ipe(B, N, min_deg, max_deg, disable_integration, t, origins, dirs, radii, enc,
+                                 out_dtype == MIPNERF_PREC_BF16, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_integrated_pos_enc(int64_t M, int32_t min_deg, int32_t max_deg, const float* means, const float* covs,
+                               void* enc, int out_dtype, void* stream) {
+    if (M < 1 || !means || !covs || !enc) return fail(MIPNERF_E_INVALID, "integrated_pos_enc: bad argument");
+    if (max_deg - min_deg != 16 || min_deg < 0 || max_deg > 31)
+        return fail(MIPNERF_E_UNSUPPORTED, "integrated_pos_enc is generated for max_deg-min_deg == 16");
+    HIP_TRY(mip::launch_integrated_pos_enc(M, min_deg, max_deg, means, covs, enc, out_dtype == MIPNERF_PREC_BF16, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_pos_enc(int64_t B, int32_t deg, const float* viewdirs, void* out, int32_t ld, int out_dtype, void* stream) {
+    if (B < 1 || deg < 0 || !viewdirs || !out || ld < 3 + 6 * deg) return fail(MIPNERF_E_INVALID, "pos_enc: bad argument");
+    HIP_TRY(mip::launch_pos_enc(B, deg, viewdirs, out, ld, out_dtype == MIPNERF_PREC_BF16, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_mlp_forward(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, int precision,
+                        float* rgb_sigma, float* raw, void* stream) {
+    if (!c || M < 1 || N < 1 || !enc || !viewenc || !rgb_sigma) return fail(MIPNERF_E_INVALID, "mlp_forward: bad argument");
+    if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward: mipnerf_set_params has not been called");
+    if (precision == MIPNERF_PREC_BF16) {
+        HIP_TRY(mip::launch_mlp_bf16(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias,
+                                     c->cfg.rgb_padding, c->grid_limit, c->mlp_dma != 0, S(stream)));
+    } else if (precision == MIPNERF_PREC_FP32) {
+        HIP_TRY(mip::launch_mlp_f32(c->tab.net, c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
+                                    rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, S(stream)));
+    } else {
+        return fail(MIPNERF_E_INVALID, "unknown precision %d", precision);
+    }
+    return MIPNERF_OK;
+}
+
+int mipnerf_volumetric_rendering(int64_t B, int32_t N, const float* rgb_sigma, const float* t, const float* dirs,
+                                 int32_t white_bkgd, float* comp_rgb, float* distance, float* acc, float* weights,
+                                 void* stream) {
+    if (B < 1 || N < 1 || N > MIPNERF_MAX_SAMPLES || !rgb_sigma || !t || !dirs || !comp_rgb || !distance || !acc || !weights)
+        return fail(MIPNERF_E_INVALID, "volumetric_rendering: bad argument");
+    HIP_TRY(mip::launch_volumetric_rendering(B, N, rgb_sigma, t, dirs, white_bkgd, comp_rgb, distance, acc, weights,
+                                             S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_resample_along_rays(int64_t B, int32_t N, const float* t, const float* weights, const float* u_rand,
+                                float resample_padding, float* t_new, void* stream) {
+    if (B < 1 || N < 1 || N > MIPNERF_MAX_SAMPLES || !t || !weights || !t_new)
+        return fail(MIPNERF_E_INVALID, "resample_along_rays: bad argument");
+    HIP_TRY(mip::launch_piecewise_constant_pdf(B, N, t, weights, N + 1, u_rand, true, resample_padding, t_new, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_sorted_piecewise_constant_pdf(int64_t B, int32_t nbins, const float* bins, const float* weights,
+                                          int32_t ndraws, const float* u_rand, float* samples, void* stream) {
+    if (B < 1 || nbins < 1 || nbins > MIPNERF_MAX_SAMPLES || ndraws < 1 || !bins || !weights || !samples)
+        return fail(MIPNERF_E_INVALID, "sorted_piecewise_constant_pdf: bad argument");
+    HIP_TRY(mip::launch_piecewise_constant_pdf(B, nbins, bins, weights, ndraws, u_rand, false, 0.0f, samples, S(stream)));
+    return MIPNERF_OK;
+}
+
+// ---- the level loop ---------------------------------------------------------------------------------
+size_t mipnerf_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
+    if (!c || B < 1) return 0;
+    const size_t M = (size_t)B * (size_t)c->cfg.num_samples;
+    return align256(M * mip::plan::kXyzDim * 4) + align256((size_t)B * 32 * 4) + align256(M * 16) + 256;
+}
+
+int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* t_rand, const float* u_rand,
+                    uint32_t flags, int precision, void* workspace, size_t workspace_bytes,
+                    const mipnerf_level_out* out, void* stream) {
+    if (!c || !rays || !out || !workspace || B < 1) return fail(MIPNERF_E_INVALID, "forward: bad argument");
+    if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->radii || !rays->near || !rays->far)
+        return fail(MIPNERF_E_INVALID, "forward: a Rays field is null");
+    if (!c->params_set) return fail(MIPNERF_E_INVALID, "forward: mipnerf_set_params has not been called");
+    if ((t_rand == nullptr) != (u_rand == nullptr) && c->cfg.num_levels > 1)
+        return fail(MIPNERF_E_INVALID, "forward: t_rand and u_rand must both be given (randomized) or both null");
+    if (workspace_bytes < mipnerf_workspace_bytes(c, B)) return fail(MIPNERF_E_WORKSPACE, "forward: workspace too small");
+    if (precision != MIPNERF_PREC_BF16 && precision != MIPNERF_PREC_FP32)
+        return fail(MIPNERF_E_INVALID, "unknown precision %d", precision);
+    const mipnerf_config& cfg = c->cfg;
+    const int N = cfg.num_samples;
+    const size_t M = (size_t)B * N;
+    char* ws = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    void* enc = ws;
+    void* viewenc = ws + align256(M * mip::plan::kXyzDim * 4);
+    float* rgb_sigma = reinterpret_cast<float*>(ws + align256(M * mip::plan::kXyzDim * 4) + align256((size_t)B * 32 * 4));
+    const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
+    const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
+    int rc;
+    // pos_enc(viewdirs) is level-independent: computed once (the reference recomputes it, mip_nerf.py:220-226)
+    if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, precision, stream))) return rc;
+    for (int lvl = 0; lvl < cfg.num_levels; ++lvl) {
+        const mipnerf_level_out& o = out[lvl];
+        if (!o.comp_rgb || !o.distance || !o.acc || !o.weights || !o.t_samples)
+            return fail(MIPNERF_E_INVALID, "forward: output pointer of level %d is null", lvl);
+        if (lvl == 0) {
+            if ((rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, o.t_samples, stream))) return rc;
+        } else {
+            if ((rc = mipnerf_resample_along_rays(B, N, out[lvl - 1].t_samples, out[lvl - 1].weights, u_rand,
+                                                  cfg.resample_padding, o.t_samples, stream))) return rc;
+        }
+        if ((rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, o.t_samples,
+                                   rays->origins, rays->directions, rays->radii, enc, precision, stream))) return rc;
+        if ((rc = mipnerf_mlp_forward(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream))) return rc;
+        if ((rc = mipnerf_volumetric_rendering(B, N, rgb_sigma, o.t_samples, rays->directions, white, o.comp_rgb,
+                                               o.distance, o.acc, o.weights, stream))) return rc;
+    }
+    return MIPNERF_OK;
+}
+
+// ---- instrumentation -----------------------------------------------------------------------------------
+int mipnerf_time_mlp(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, int precision,
+                     float* rgb_sigma, int iters, float* ms, void* stream) {
+    if (!ms || iters < 1) return fail(MIPNERF_E_INVALID, "time_mlp: bad argument");
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = mipnerf_mlp_forward(c, M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream);   // warm
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e0, S(stream)));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = mipnerf_mlp_forward(c, M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream))) return rc;
+    HIP_TRY(hipEventRecord(e1, S(stream)));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / iters;
+    return MIPNERF_OK;
+}
+
+int mipnerf_selftest(void* stream) {
+    char msg[256];
+    const int bad = mip::run_selftest(S(stream), msg, sizeof msg);
+    g_err = msg;
+    if (bad < 0) return MIPNERF_E_HIP;
+    return bad == 0 ? MIPNERF_OK : (0x100 | bad);
+}
+
+// Host-only debug export of the plan tables (flat parameter indices), used by the CPU tests to prove the
+// C++ expansion equals mlp_plan.py.  which: 0 bf16 pack, 1 bias, 2 fp32 pack.  Returns element count.
+int64_t mipnerf_debug_table(int which, int32_t* out_host, int64_t cap) {
+    Tables T;
+    build_tables(T);
+    const std::vector<int32_t>& v = which == 0 ? T.pack_bf16 : (which == 1 ? T.bias : T.pack_f32);
+    if (out_host && cap >= (int64_t)v.size()) memcpy(out_host, v.data(), v.size() * 4);
+    return (int64_t)v.size();
+}
+
+// Host-only: fp32 layer descriptors (x_in, kb, ntiles, first_tile, relu, kind, chunk0, ldx) x nlayers
+int64_t mipnerf_debug_f32net(int32_t* out_host, int64_t cap) {
+    Tables T;
+    build_tables(T);
+    const int n = T.net.nlayers;
+    if (out_host && cap >= (int64_t)n * 8)
+        for (int i = 0; i < n; ++i) {
+            const mip::F32Layer& L = T.net.layers[i];
+            const int32_t row[8] = {L.x_in, L.kb, L.ntiles, L.first_tile, L.relu, L.kind, L.chunk0, T.net.ldx};
+            memcpy(out_host + i * 8, row, sizeof row);
+        }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,471 @@
+// Ray-side kernels of the Mip-NeRF hot path for gfx950 (wave64):
+//   sample_along_rays (t part), cast_rays, cast_rays+integrated_pos_enc, pos_enc,
+//   volumetric_rendering (one wavefront per ray, wave scan), resample_along_rays /
+//   sorted_piecewise_constant_pdf (one wavefront per ray, CDF in LDS).
+// All of them are HBM-/VALU-bound elementwise or per-ray-scan work: coalesced SoA reads,
+// 16-byte stores, scans with DPP/shuffle wave primitives.  Compiled with -ffp-contract=off
+// (see raymath.hpp).
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "raymath.hpp"
+
+namespace mip {
+
+// ------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// exclusive prefix sum across the 64 lanes; *total = sum over all lanes
+__device__ __forceinline__ float wave_excl_scan(float v, int lane, float* total) {
+    float inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    *total = __shfl(inc, 63, 64);
+    const float ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 0.0f : ex;
+}
+
+// ------------------------------------------------------------------------------------------
+// sample_along_rays, t part (models/mip.py:143-163)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float level0_t(float nearv, float farv, int n_samples, int i, bool disparity) {
+    const float lin = torch_linspace_at(0.0f, 1.0f, n_samples + 1, i);
+    if (disparity) return 1.0f / (1.0f / nearv * (1.0f - lin) + 1.0f / farv * lin);
+    return nearv + (farv - nearv) * lin;
+}
+
+__global__ void __launch_bounds__(256)
+k_sample_along_rays(int64_t B, int N, const float* __restrict__ nearp, const float* __restrict__ farp,
+                    const float* __restrict__ t_rand, int disparity, float* __restrict__ t_out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = B * (int64_t)(N + 1);
+    if (idx >= total) return;
+    const int64_t b = idx / (N + 1);
+    const int i = (int)(idx - b * (N + 1));
+    const float nv = nearp[b], fv = farp[b];
+    float t = level0_t(nv, fv, N, i, disparity);
+    if (t_rand != nullptr) {
+        // mids = .5*(t[1:]+t[:-1]); upper=[mids, t[-1]]; lower=[t[0], mids]  (mip.py:156-160)
+        const float tm = (i > 0) ? level0_t(nv, fv, N, i - 1, disparity) : t;
+        const float tp = (i < N) ? level0_t(nv, fv, N, i + 1, disparity) : t;
+        const float lower = (i > 0) ? 0.5f * (t + tm) : t;
+        const float upper = (i < N) ? 0.5f * (tp + t) : t;
+        t = lower + (upper - lower) * t_rand[idx];
+    }
+    t_out[idx] = t;
+}
+
+// ------------------------------------------------------------------------------------------
+// cast_rays -> means / covs (models/mip.py:81-103), one thread per sample
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_cast_rays(int64_t B, int N, const float* __restrict__ t, const float* __restrict__ origins,
+            const float* __restrict__ dirs, const float* __restrict__ radii,
+            float* __restrict__ means, float* __restrict__ covs) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B * (int64_t)N) return;
+    const int64_t b = s / N;
+    const int i = (int)(s - b * N);
+    const float d[3] = {dirs[b * 3], dirs[b * 3 + 1], dirs[b * 3 + 2]};
+    const float o[3] = {origins[b * 3], origins[b * 3 + 1], origins[b * 3 + 2]};
+    const float t0 = t[b * (N + 1) + i], t1 = t[b * (N + 1) + i + 1];
+    const Gauss3 g = conical_frustum_to_gaussian(t0, t1, d, o, radii[b]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (means) means[s * 3 + a] = g.mean[a];
+        if (covs) covs[s * 3 + a] = g.cov[a];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// cast_rays + integrated_pos_enc fused (models/mip.py:81-103, 322-350).
+// Two threads per sample: thread q handles degrees [q*L/2, (q+1)*L/2) of BOTH halves
+// (sin | "cos"), so each exp(-0.5*var) is computed once.  Output row = 6L features,
+// written as 16-byte vectors.  L = max_deg - min_deg must be even (16 at the shipped config).
+// ------------------------------------------------------------------------------------------
+template <typename OutT> struct Pack;
+template <> struct Pack<float> {
+    static constexpr int kPer16 = 4;
+    __device__ static void store(float* dst, const float* v, int n) {  // n multiple of 4
+        for (int i = 0; i < n; i += 4)
+            *reinterpret_cast<float4*>(dst + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+    }
+};
+template <> struct Pack<__bf16> {
+    static constexpr int kPer16 = 8;
+    __device__ static void store(__bf16* dst, const float* v, int n) {  // n multiple of 8
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+        for (int i = 0; i < n; i += 8) {
+            bf16x8 p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = (__bf16)v[i + j];   // RNE
+            *reinterpret_cast<bf16x8*>(dst + i) = p;
+        }
+    }
+};
+
+// Thread q in {0,1} of a sample writes degrees [q*L/2, (q+1)*L/2) of both halves (sin | "cos").
+template <typename OutT, int L>
+__device__ __forceinline__ void ipe_write(const Gauss3& g, int q, int min_deg, OutT* row) {
+    constexpr int H = 3 * L / 2;   // features per thread per half
+    float fs[H], fc[H];
+#pragma unroll
+    for (int ll = 0; ll < L / 2; ++ll) {
+        const int l = q * (L / 2) + ll;
+        const float scale = (float)(1u << (l + min_deg));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float y = g.mean[a] * scale;
+            const float yv = g.cov[a] * (scale * scale);
+            const float damp = exp_accurate(-0.5f * yv);
+            fs[ll * 3 + a] = damp * sin_accurate(y);
+            fc[ll * 3 + a] = damp * sin_accurate(y + kHalfPiF);
+        }
+    }
+    Pack<OutT>::store(row + q * H, fs, H);
+    Pack<OutT>::store(row + 3 * L + q * H, fc, H);
+}
+
+template <typename OutT, int L>
+__global__ void __launch_bounds__(256)
+k_cast_ipe(int64_t B, int N, int min_deg, int disable_integration, const float* __restrict__ t,
+           const float* __restrict__ origins, const float* __restrict__ dirs,
+           const float* __restrict__ radii, OutT* __restrict__ enc) {
+    static_assert(L % 2 == 0 && (3 * L / 2) % 8 == 0, "vector stores need 3L/2 % 8 == 0");
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid >> 1;
+    const int q = (int)(gid & 1);
+    if (s >= B * (int64_t)N) return;
+    const int64_t b = s / N;
+    const int i = (int)(s - b * N);
+    const float d[3] = {dirs[b * 3], dirs[b * 3 + 1], dirs[b * 3 + 2]};
+    const float o[3] = {origins[b * 3], origins[b * 3 + 1], origins[b * 3 + 2]};
+    const float t0 = t[b * (N + 1) + i], t1 = t[b * (N + 1) + i + 1];
+    Gauss3 g = conical_frustum_to_gaussian(t0, t1, d, o, radii[b]);
+    if (disable_integration) g.cov[0] = g.cov[1] = g.cov[2] = 0.0f;   // mip_nerf.py:210-211
+    ipe_write<OutT, L>(g, q, min_deg, enc + s * (int64_t)(6 * L));
+}
+
+// integrated_pos_enc on given means / diagonal covariances (models/mip.py:322-350)
+template <typename OutT, int L>
+__global__ void __launch_bounds__(256)
+k_integrated_pos_enc(int64_t M, int min_deg, const float* __restrict__ means, const float* __restrict__ covs,
+                     OutT* __restrict__ enc) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid >> 1;
+    const int q = (int)(gid & 1);
+    if (s >= M) return;
+    Gauss3 g;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g.mean[a] = means[s * 3 + a]; g.cov[a] = covs[s * 3 + a]; }
+    ipe_write<OutT, L>(g, q, min_deg, enc + s * (int64_t)(6 * L));
+}
+
+// ------------------------------------------------------------------------------------------
+// pos_enc(viewdirs) (models/mip.py:353-363), row stride ld, pad columns zeroed
+// ------------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+k_pos_enc(int64_t B, int deg, const float* __restrict__ viewdirs, OutT* __restrict__ out, int ld) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * (int64_t)ld) return;
+    const int64_t b = gid / ld;
+    const int c = (int)(gid - b * ld);
+    const float v[3] = {viewdirs[b * 3], viewdirs[b * 3 + 1], viewdirs[b * 3 + 2]};
+    const float f = (c < 3 + 6 * deg) ? view_feature(v, c, deg) : 0.0f;
+    out[gid] = (OutT)f;
+}
+
+// ------------------------------------------------------------------------------------------
+// volumetric_rendering (models/mip.py:366-401).  One wavefront per ray, 4 rays per block.
+// Lane l owns the K = ceil(N/64) consecutive samples [l*K, l*K+K): a local running sum plus
+// one wave-wide exclusive scan gives the exclusive cumsum of sigma*delta.
+// ------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256)
+k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
+                       const float* __restrict__ t, const float* __restrict__ dirs, int white_bkgd,
+                       float* __restrict__ comp_rgb, float* __restrict__ distance,
+                       float* __restrict__ acc_out, float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;   // whole wave exits together (b is wave-uniform)
+    const float dx = dirs[b * 3], dy = dirs[b * 3 + 1], dz = dirs[b * 3 + 2];
+    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);   // torch.linalg.norm
+    const float* tb = t + b * (int64_t)(N + 1);
+    const float4* cb = rgb_sigma + b * (int64_t)N;
+    const int i0 = lane * K;
+
+    float tv[K + 1];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) tv[k] = (i0 + k <= N) ? tb[i0 + k] : 0.0f;
+    float4 c[K];
+    float dd[K], pre[K];
+    float run = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool ok = i0 + k < N;
+        c[k] = ok ? cb[i0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float delta = (tv[k + 1] - tv[k]) * dn;
+        dd[k] = ok ? c[k].w * delta : 0.0f;   // density_delta
+        pre[k] = run;
+        run += dd[k];
+    }
+    float total;
+    const float off = wave_excl_scan(run, lane, &total);
+
+    float sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f, sd = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool ok = i0 + k < N;
+        const float alpha = 1.0f - expf(-dd[k]);
+        const float trans = expf(-(off + pre[k]));
+        const float w = ok ? alpha * trans : 0.0f;
+        if (ok) weights[b * (int64_t)N + i0 + k] = w;
+        sr += w * c[k].x;
+        sg += w * c[k].y;
+        sb += w * c[k].z;
+        sa += w;
+        sd += w * (0.5f * (tv[k] + tv[k + 1]));
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sa = wave_sum(sa); sd = wave_sum(sd);
+    if (lane == 0) {
+        const float tnear = tb[0], tfar = tb[N];
+        float dist = nan_to_num(sd);
+        dist = fminf(fmaxf(dist, tnear), tfar);   // torch.clamp(x, min, max) = min(max(x,min),max)
+        if (white_bkgd) {
+            const float bg = 1.0f - sa;
+            sr += bg; sg += bg; sb += bg;
+        }
+        comp_rgb[b * 3] = sr; comp_rgb[b * 3 + 1] = sg; comp_rgb[b * 3 + 2] = sb;
+        distance[b] = dist;
+        acc_out[b] = sa;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// resample_along_rays t part (models/mip.py:232-280) and sorted_piecewise_constant_pdf
+// (models/mip.py:168-229).  One wavefront per ray; the ray's CDF and bins live in LDS; each
+// lane inverts the CDF for its draws with a binary search (torch.searchsorted right=True).
+//   BLUR = true : weights are blur-pooled and `padding` added first (resample path)
+//   BLUR = false: weights used as given
+// ------------------------------------------------------------------------------------------
+constexpr int kPdfMaxBins = 512;      // N <= 512
+constexpr int kRaysPerBlock = 4;
+
+template <int K, bool BLUR>
+__global__ void __launch_bounds__(64 * kRaysPerBlock)
+k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const float* __restrict__ weights,
+                         int n_draws, const float* __restrict__ u_rand, float padding,
+                         float u_step, float u_jitter, float* __restrict__ out) {
+    __shared__ float s_w[kRaysPerBlock][kPdfMaxBins + 2];
+    __shared__ float s_cdf[kRaysPerBlock][kPdfMaxBins + 2];
+    __shared__ float s_bins[kRaysPerBlock][kPdfMaxBins + 2];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    const bool active = b < B;
+    const int64_t bb = active ? b : B - 1;    // inactive waves shadow the last ray (no stores)
+    const float* wb = weights + bb * (int64_t)N;
+    const float* binb = bins + bb * (int64_t)(N + 1);
+    const int i0 = lane * K;
+
+    // stage weights and bins
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (i0 + k < N) s_w[wv][i0 + k] = wb[i0 + k];
+    for (int j = lane; j <= N; j += 64) s_bins[wv][j] = binb[j];
+    __syncthreads();
+
+    float w[K];
+    float run = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = i0 + k;
+        float v = 0.0f;
+        if (i < N) {
+            if (BLUR) {
+                // weights_pad = [w0, w, w_{N-1}]; max of neighbours; mean of neighbours (mip.py:252-254)
+                const float wc = s_w[wv][i];
+                const float wl = s_w[wv][i > 0 ? i - 1 : 0];
+                const float wr = s_w[wv][i < N - 1 ? i + 1 : N - 1];
+                v = 0.5f * (fmaxf(wl, wc) + fmaxf(wc, wr)) + padding;
+            } else {
+                v = s_w[wv][i];
+            }
+        }
+        w[k] = v;
+        run += v;
+    }
+    // eps padding so the sum is >= 1e-5 (mip.py:181-185)
+    float wsum = wave_sum(run);
+    const float pad = fmaxf(0.0f, 1e-5f - wsum);
+    const float padn = pad / (float)N;
+    wsum += pad;
+    float pre[K];
+    run = 0.0f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = i0 + k;
+        const float pdf = (i < N) ? (w[k] + padn) / wsum : 0.0f;
+        pre[k] = run;
+        run += pdf;
+    }
+    float total;
+    const float off = wave_excl_scan(run, lane, &total);
+    // cdf = [0, min(1, cumsum(pdf[:-1])), 1]  (mip.py:190-195): cdf[i] = min(1, sum_{j<i} pdf_j)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int i = i0 + k;
+        if (i < N) s_cdf[wv][i] = (i == 0) ? 0.0f : fminf(1.0f, off + pre[k]);
+    }
+    if (lane == 0) s_cdf[wv][N] = 1.0f;
+    __syncthreads();
+
+    const float eps32 = 1.1920928955078125e-07f;
+    const float umax = 1.0f - eps32;
+    for (int j = lane; j < n_draws; j += 64) {
+        float u;
+        if (u_rand != nullptr) {
+            // u = arange*s + U[0, s-eps), clipped to 1-eps (mip.py:198-204)
+            u = (float)j * u_step + u_rand[bb * (int64_t)n_draws + j] * u_jitter;
+            u = fminf(u, umax);
+        } else {
+            u = torch_linspace_at(0.0f, umax, n_draws, j);   // mip.py:207
+        }
+        // searchsorted(cdf, u, right=True): number of entries <= u, over cdf[0..N]
+        int lo = 0, hi = N + 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_cdf[wv][mid] <= u) lo = mid + 1; else hi = mid;
+        }
+        const int below = max(0, lo - 1);
+        const int above = min(N, lo);
+        const float c0 = s_cdf[wv][below], c1 = s_cdf[wv][above];
+        const float b0 = s_bins[wv][below], b1 = s_bins[wv][above];
+        float denom = c1 - c0;
+        denom = (denom < 1e-5f) ? 1.0f : denom;
+        const float tt = (u - c0) / denom;
+        if (active) out[b * (int64_t)n_draws + j] = b0 + tt * (b1 - b0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+hipError_t launch_sample_along_rays(int64_t B, int N, const float* nearp, const float* farp,
+                                    const float* t_rand, int disparity, float* t_out, hipStream_t st) {
+    const int64_t total = B * (int64_t)(N + 1);
+    hipLaunchKernelGGL(k_sample_along_rays, dim3(grid_for(total, 256)), dim3(256), 0, st, B, N, nearp, farp,
+                       t_rand, disparity, t_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_cast_rays(int64_t B, int N, const float* t, const float* origins, const float* dirs,
+                            const float* radii, float* means, float* covs, hipStream_t st) {
+    hipLaunchKernelGGL(k_cast_rays, dim3(grid_for(B * (int64_t)N, 256)), dim3(256), 0, st, B, N, t, origins, dirs,
+                       radii, means, covs);
+    return hipGetLastError();
+}
+
+hipError_t launch_cast_ipe(int64_t B, int N, int min_deg, int max_deg, int disable_integration,
+                           const float* t, const float* origins, const float* dirs, const float* radii,
+                           void* enc, bool bf16, hipStream_t st) {
+    if (max_deg - min_deg != 16) return hipErrorInvalidValue;   // generated for L = 16
+    const int64_t threads = 2 * B * (int64_t)N;
+    if (bf16)
+        hipLaunchKernelGGL((k_cast_ipe<__bf16, 16>), dim3(grid_for(threads, 256)), dim3(256), 0, st, B, N, min_deg,
+                           disable_integration, t, origins, dirs, radii, (__bf16*)enc);
+    else
+        hipLaunchKernelGGL((k_cast_ipe<float, 16>), dim3(grid_for(threads, 256)), dim3(256), 0, st, B, N, min_deg,
+                           disable_integration, t, origins, dirs, radii, (float*)enc);
+    return hipGetLastError();
+}
+
+hipError_t launch_integrated_pos_enc(int64_t M, int min_deg, int max_deg, const float* means, const float* covs,
+                                     void* enc, bool bf16, hipStream_t st) {
+    if (max_deg - min_deg != 16) return hipErrorInvalidValue;
+    const int64_t threads = 2 * M;
+    if (bf16)
+        hipLaunchKernelGGL((k_integrated_pos_enc<__bf16, 16>), dim3(grid_for(threads, 256)), dim3(256), 0, st, M, min_deg,
+                           means, covs, (__bf16*)enc);
+    else
+        hipLaunchKernelGGL((k_integrated_pos_enc<float, 16>), dim3(grid_for(threads, 256)), dim3(256), 0, st, M, min_deg,
+                           means, covs, (float*)enc);
+    return hipGetLastError();
+}
+
+hipError_t launch_pos_enc(int64_t B, int deg, const float* viewdirs, void* out, int ld, bool bf16, hipStream_t st) {
+    const int64_t total = B * (int64_t)ld;
+    if (bf16)
+        hipLaunchKernelGGL((k_pos_enc<__bf16>), dim3(grid_for(total, 256)), dim3(256), 0, st, B, deg, viewdirs,
+                           (__bf16*)out, ld);
+    else
+        hipLaunchKernelGGL((k_pos_enc<float>), dim3(grid_for(total, 256)), dim3(256), 0, st, B, deg, viewdirs,
+                           (float*)out, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_volumetric_rendering(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs,
+                                       int white_bkgd, float* comp_rgb, float* distance, float* acc,
+                                       float* weights, hipStream_t st) {
+    const dim3 grid(grid_for(B, 4)), block(256);
+    const float4* c = reinterpret_cast<const float4*>(rgb_sigma);
+    const int K = (N + 63) / 64;
+#define MIP_VR(KK)                                                                                        \
+    hipLaunchKernelGGL((k_volumetric_rendering<KK>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd,  \
+                       comp_rgb, distance, acc, weights)
+    switch (K) {
+        case 1: MIP_VR(1); break;
+        case 2: MIP_VR(2); break;
+        case 3: MIP_VR(3); break;
+        case 4: MIP_VR(4); break;
+        case 5: case 6: case 7: case 8: MIP_VR(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef MIP_VR
+    return hipGetLastError();
+}
+
+hipError_t launch_piecewise_constant_pdf(int64_t B, int N, const float* bins, const float* weights, int n_draws,
+                                         const float* u_rand, bool blur, float padding, float* out,
+                                         hipStream_t st) {
+    if (N > kPdfMaxBins || N < 1) return hipErrorInvalidValue;
+    const dim3 grid(grid_for(B, kRaysPerBlock)), block(64 * kRaysPerBlock);
+    // s = 1/num_samples ; jitter range (s - eps32) evaluated in double like the Python reference
+    const double s = 1.0 / (double)n_draws;
+    const float u_step = (float)s;
+    const float u_jitter = (float)(s - (double)1.1920928955078125e-07f);
+    const int K = (N + 63) / 64;
+#define MIP_PDF(KK)                                                                                          \
+    do {                                                                                                     \
+        if (blur)                                                                                            \
+            hipLaunchKernelGGL((k_piecewise_constant_pdf<KK, true>), grid, block, 0, st, B, N, bins, weights, \
+                               n_draws, u_rand, padding, u_step, u_jitter, out);                            \
+        else                                                                                                 \
+            hipLaunchKernelGGL((k_piecewise_constant_pdf<KK, false>), grid, block, 0, st, B, N, bins, weights, \
+                               n_draws, u_rand, padding, u_step, u_jitter, out);                            \
+    } while (0)
+    switch (K) {
+        case 1: MIP_PDF(1); break;
+        case 2: MIP_PDF(2); break;
+        case 3: case 4: MIP_PDF(4); break;
+        case 5: case 6: case 7: case 8: MIP_PDF(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef MIP_PDF
+    return hipGetLastError();
+}
+
+}  // namespace mip

@@ -1,0 +1,275 @@
+"""Drop-in `MipNerf` / `MLP` modules with the constructor signatures, parameter names / shapes
+(state_dict keys) and `forward` contracts of the reference (models/mip_nerf.py:14-248), whose
+compute runs in the hand-written gfx950 kernels of libmipnerf_hip.so.
+
+    model = MipNerf(**same_kwargs_as_reference).cuda()
+    ret = model(rays, randomized, white_bkgd)     # list of (comp_rgb, distance, acc, weights, t_samples)
+
+The torch modules below only OWN the fp32 master parameters (so checkpoints, optimizers and
+DDP see ordinary nn.Parameters); no torch op touches activations on the hot path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .rays import Rays
+
+_PREC = {"bf16": L.PREC_BF16, "bfloat16": L.PREC_BF16, "fp32": L.PREC_FP32, "float32": L.PREC_FP32}
+
+
+def _xavier_init(linear):
+    torch.nn.init.xavier_uniform_(linear.weight.data)
+
+
+class NativeContext:
+    """Owns one `mipnerf_ctx` (configuration + packed weight streams on the current device)."""
+
+    def __init__(self, cfg: L.Config, device: torch.device):
+        self.device = device
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        with torch.cuda.device(device):
+            L.check(L.lib().mipnerf_create(C.byref(cfg), C.byref(self._h)), "mipnerf_create")
+        self._packed_key = None
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                L.lib().mipnerf_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync_params(self, params) -> None:
+        """Re-pack the MFMA operand streams when any master parameter changed (in-place updates bump
+        tensor._version; load_state_dict / .to() change version or storage)."""
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key == self._packed_key:
+            return
+        if len(params) != L.NUM_PARAM_TENSORS:
+            raise NotImplementedError(f"expected {L.NUM_PARAM_TENSORS} parameter tensors, got {len(params)}")
+        keep = []
+        arr = (C.c_void_p * L.NUM_PARAM_TENSORS)()
+        for i, p in enumerate(params):
+            if not p.is_cuda or p.device != self.device:
+                raise RuntimeError(f"parameter {i} is on {p.device}, context is on {self.device}")
+            d = p.detach()
+            if d.dtype != torch.float32:
+                raise TypeError("master parameters must be float32")
+            d = d.contiguous()
+            keep.append(d)
+            arr[i] = d.data_ptr()
+        L.check(L.lib().mipnerf_set_params(self._h, arr, ops._stream()), "mipnerf_set_params")
+        self._packed_key = key
+
+    def workspace(self, num_rays: int) -> torch.Tensor:
+        need = int(L.lib().mipnerf_workspace_bytes(self._h, num_rays))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def set_option(self, option: int, value: int) -> None:
+        L.check(L.lib().mipnerf_set_option(self._h, option, value), "mipnerf_set_option")
+
+
+class MLP(torch.nn.Module):
+    """Parameter container + stand-alone entry to the MFMA MLP kernel (models/mip_nerf.py:14-111)."""
+
+    def __init__(self, net_depth: int, net_width: int, net_depth_condition: int, net_width_condition: int,
+                 skip_index: int, num_rgb_channels: int, num_density_channels: int, activation: str,
+                 xyz_dim: int, view_dim: int):
+        super().__init__()
+        if activation != "relu":
+            raise NotImplementedError  # mip_nerf.py:50,70
+        self.skip_index = skip_index
+        self.arch = dict(net_depth=net_depth, net_width=net_width, net_depth_condition=net_depth_condition,
+                         net_width_condition=net_width_condition, skip_index=skip_index,
+                         num_rgb_channels=num_rgb_channels, num_density_channels=num_density_channels,
+                         xyz_dim=xyz_dim, view_dim=view_dim)
+        layers = []
+        for i in range(net_depth):
+            if i == 0:
+                dim_in = xyz_dim
+            elif (i - 1) % skip_index == 0 and i > 1:
+                dim_in = net_width + xyz_dim
+            else:
+                dim_in = net_width
+            linear = torch.nn.Linear(dim_in, net_width)
+            _xavier_init(linear)
+            layers.append(torch.nn.Sequential(linear, torch.nn.ReLU(True)))
+        self.layers = torch.nn.ModuleList(layers)
+        self.density_layer = torch.nn.Linear(net_width, num_density_channels)
+        _xavier_init(self.density_layer)
+        self.extra_layer = torch.nn.Linear(net_width, net_width)
+        _xavier_init(self.extra_layer)
+        layers = []
+        for i in range(net_depth_condition):
+            dim_in = net_width + view_dim if i == 0 else net_width_condition
+            linear = torch.nn.Linear(dim_in, net_width_condition)
+            _xavier_init(linear)
+            layers.append(torch.nn.Sequential(linear, torch.nn.ReLU(True)))
+        self.view_layers = torch.nn.Sequential(*layers)
+        self.color_layer = torch.nn.Linear(net_width_condition, num_rgb_channels)   # default init (mip_nerf.py:73)
+        self._ctx: Optional[NativeContext] = None
+        self._cfg_extra = {}
+        self.precision = L.PREC_BF16
+
+    # -- native context ------------------------------------------------------------------------
+    def ordered_params(self):
+        """state_dict order of the reference MLP = order mipnerf_set_params expects."""
+        return list(self.parameters())
+
+    def native(self, device: torch.device) -> NativeContext:
+        if self._ctx is None or self._ctx.device != device:
+            a = self.arch
+            deg_point = a["xyz_dim"] // 6
+            deg_view = (a["view_dim"] - 3) // 6
+            e = self._cfg_extra
+            cfg = L.Config(
+                num_samples=e.get("num_samples", 128), num_levels=e.get("num_levels", 2),
+                min_deg_point=e.get("min_deg_point", 0), max_deg_point=e.get("max_deg_point", deg_point),
+                deg_view=e.get("deg_view", deg_view), use_viewdirs=e.get("use_viewdirs", 1),
+                disparity=e.get("disparity", 0), disable_integration=e.get("disable_integration", 0),
+                net_depth=a["net_depth"], net_width=a["net_width"], net_depth_condition=a["net_depth_condition"],
+                net_width_condition=a["net_width_condition"], skip_index=a["skip_index"],
+                num_rgb_channels=a["num_rgb_channels"], num_density_channels=a["num_density_channels"],
+                resample_padding=e.get("resample_padding", 0.01), density_bias=e.get("density_bias", -1.0),
+                rgb_padding=e.get("rgb_padding", 0.001))
+            self._ctx = NativeContext(cfg, device)
+        self._ctx.sync_params(self.ordered_params())
+        return self._ctx
+
+    def forward(self, x, view_direction=None, precision: Optional[int] = None, return_activated: bool = False):
+        """x: [B, N, xyz_dim] encodings, view_direction: [B, view_dim] -> (raw_rgb [B,N,3], raw_density [B,N,1])."""
+        if view_direction is None:
+            raise NotImplementedError("use_viewdirs=False is not supported (mipnerf_create explains why)")
+        prec = self.precision if precision is None else precision
+        dt = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
+        if not x.is_cuda:
+            raise RuntimeError("MLP.forward needs HIP device tensors; there is no CPU fallback")
+        B, N, _ = x.shape
+        ctx = self.native(x.device)
+        enc = x.to(dt).contiguous()
+        venc = torch.zeros(B, 32, device=x.device, dtype=dt)
+        venc[:, :view_direction.shape[-1]] = view_direction.to(dt)
+        rgb_sigma = torch.empty(B, N, 4, device=x.device, dtype=torch.float32)
+        raw = torch.empty_like(rgb_sigma)
+        L.check(L.lib().mipnerf_mlp_forward(ctx.handle, B * N, N, enc.data_ptr(), venc.data_ptr(), prec,
+                                            rgb_sigma.data_ptr(), raw.data_ptr(), ops._stream()), "mlp_forward")
+        if return_activated:
+            return raw[..., :3], raw[..., 3:4], rgb_sigma
+        return raw[..., :3], raw[..., 3:4]
+
+
+class MipNerf(torch.nn.Module):
+    """Nerf NN Model with both coarse and fine MLPs (reference: models/mip_nerf.py:114-248).
+
+    Extra keyword (not in the reference): `precision` = 'bf16' (default; bf16 MFMA with fp32
+    accumulation, BASELINE configs[1]) or 'fp32' (exact-fp32 MFMA, parity mode / configs[3])."""
+
+    def __init__(self, num_samples: int = 128, num_levels: int = 2, resample_padding: float = 0.01,
+                 stop_resample_grad: bool = True, use_viewdirs: bool = True, disparity: bool = False,
+                 ray_shape: str = 'cone', min_deg_point: int = 0, max_deg_point: int = 16, deg_view: int = 4,
+                 density_activation: str = 'softplus', density_noise: float = 0., density_bias: float = -1.,
+                 rgb_activation: str = 'sigmoid', rgb_padding: float = 0.001, disable_integration: bool = False,
+                 append_identity: bool = True, mlp_net_depth: int = 8, mlp_net_width: int = 256,
+                 mlp_net_depth_condition: int = 1, mlp_net_width_condition: int = 128, mlp_skip_index: int = 4,
+                 mlp_num_rgb_channels: int = 3, mlp_num_density_channels: int = 1, mlp_net_activation: str = 'relu',
+                 precision: Optional[str] = None):
+        super().__init__()
+        self.num_levels = num_levels
+        self.num_samples = num_samples
+        self.disparity = disparity
+        self.ray_shape = ray_shape
+        self.disable_integration = disable_integration
+        self.min_deg_point = min_deg_point
+        self.max_deg_point = max_deg_point
+        self.use_viewdirs = use_viewdirs
+        self.deg_view = deg_view
+        self.density_noise = density_noise
+        self.density_bias = density_bias
+        self.resample_padding = resample_padding
+        self.stop_resample_grad = stop_resample_grad
+        self.rgb_padding = rgb_padding
+        if ray_shape != 'cone':
+            raise NotImplementedError  # mip.py:97-98
+        if rgb_activation != 'sigmoid' or density_activation != 'softplus':
+            raise NotImplementedError  # mip_nerf.py:165,170
+        if not stop_resample_grad:
+            raise NotImplementedError("stop_resample_grad=False is not implemented")
+        if not use_viewdirs:
+            raise NotImplementedError("use_viewdirs=False is not implemented")
+        mlp_xyz_dim = (max_deg_point - min_deg_point) * 3 * 2
+        mlp_view_dim = deg_view * 3 * 2
+        mlp_view_dim = mlp_view_dim + 3 if append_identity else mlp_view_dim
+        if not append_identity:
+            raise NotImplementedError("append_identity=False: forward always appends (mip_nerf.py:224), as here")
+        self.mlp = MLP(mlp_net_depth, mlp_net_width, mlp_net_depth_condition, mlp_net_width_condition,
+                       mlp_skip_index, mlp_num_rgb_channels, mlp_num_density_channels, mlp_net_activation,
+                       mlp_xyz_dim, mlp_view_dim)
+        precision = precision or os.environ.get("MIPNERF_PRECISION", "bf16")
+        if precision not in _PREC:
+            raise ValueError(f"precision must be one of {sorted(_PREC)}")
+        self.precision = _PREC[precision]
+        self.mlp.precision = self.precision
+        self.mlp._cfg_extra = dict(num_samples=num_samples, num_levels=num_levels, min_deg_point=min_deg_point,
+                                   max_deg_point=max_deg_point, deg_view=deg_view, use_viewdirs=int(use_viewdirs),
+                                   disparity=int(disparity), disable_integration=int(disable_integration),
+                                   resample_padding=resample_padding, density_bias=density_bias,
+                                   rgb_padding=rgb_padding)
+
+    def forward(self, rays: Rays, randomized: bool, white_bkgd: bool, t_rand=None, u_rand=None):
+        """rays: Rays of [B,k] float32 HIP tensors.  Returns [(comp_rgb [B,3], distance [B], acc [B],
+        weights [B,N], t_samples [B,N+1])] * num_levels (mip_nerf.py:246).  `t_rand` / `u_rand`
+        optionally inject the uniform noise of the randomized path (tests)."""
+        o = rays.origins
+        if not o.is_cuda:
+            raise RuntimeError("MipNerf.forward needs rays on a HIP device; there is no CPU fallback "
+                               "(the CPU restatement lives in oracle/ and is test-only)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd import mipnerf_forward_train
+            return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand)
+        return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand)
+
+    def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None):
+        dev = rays.origins.device
+        B, N = rays.origins.shape[0], self.num_samples
+        ctx = self.mlp.native(dev)
+        f = [ops._f32c(getattr(rays, k), k) for k in Rays._fields]
+        rp = L.RaysPtrs(*[t.data_ptr() for t in f])
+        if randomized:
+            # mip.py:159 / 201: the two uniform draws, from torch's device RNG
+            t_rand = torch.rand(B, N + 1, device=dev) if t_rand is None else ops._f32c(t_rand, "t_rand")
+            u_rand = torch.rand(B, N + 1, device=dev) if u_rand is None else ops._f32c(u_rand, "u_rand")
+        outs = (L.LevelOut * self.num_levels)()
+        ret = []
+        for lvl in range(self.num_levels):
+            comp_rgb = torch.empty(B, 3, device=dev)
+            distance = torch.empty(B, device=dev)
+            acc = torch.empty(B, device=dev)
+            weights = torch.empty(B, N, device=dev)
+            t_samples = torch.empty(B, N + 1, device=dev)
+            outs[lvl] = L.LevelOut(comp_rgb.data_ptr(), distance.data_ptr(), acc.data_ptr(), weights.data_ptr(),
+                                   t_samples.data_ptr())
+            ret.append((comp_rgb, distance, acc, weights, t_samples))
+        ws = ctx.workspace(B)
+        flags = L.FLAG_WHITE_BKGD if white_bkgd else 0
+        L.check(L.lib().mipnerf_forward(ctx.handle, B, C.byref(rp), t_rand.data_ptr() if randomized else None,
+                                        u_rand.data_ptr() if randomized else None, flags, self.precision,
+                                        ws.data_ptr(), ws.numel(), outs, ops._stream()), "mipnerf_forward")
+        # mip_nerf.py:232-233 density noise is a no-op at the shipped config (density_noise = 0)
+        if randomized and self.density_noise > 0:
+            raise NotImplementedError("density_noise > 0 is not implemented (reference default 0; upstream code "
+                                      "draws it on the CPU and would fail on GPU)")
+        return ret

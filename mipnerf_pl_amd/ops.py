@@ -1,0 +1,182 @@
+"""Host-side mirror of the free functions of the reference's models/mip.py, same names and
+argument meaning, executing on MI355X through the C ABI of libmipnerf_hip.so.
+
+Every function takes / returns torch tensors that live on a HIP device (`tensor.is_cuda`);
+torch is only the owner of device memory and of the current stream.  There is no CPU path:
+CPU tensors raise.  Randomised variants draw their uniform noise with torch's device RNG
+(`torch.rand`) and hand it to the kernels, which apply it exactly like mip.py:155-160 / 198-204.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the MI355X-native path needs HIP device tensors (got {t.device}); "
+                           "there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _torch_dtype(precision: int):
+    return torch.bfloat16 if precision == L.PREC_BF16 else torch.float32
+
+
+# ---------------------------------------------------------------------------------------------
+def cast_rays(t_samples, origins, directions, radii, ray_shape="cone", diagonal=True):
+    """models/mip.py:81-103 -> (means [B,N,3], covs [B,N,3])."""
+    if ray_shape != "cone" or not diagonal:
+        raise NotImplementedError  # mip.py:97-98 ('cylinder'); full covariances are dead code upstream
+    t_samples = _f32c(t_samples, "t_samples")
+    B, N1 = t_samples.shape
+    N = N1 - 1
+    means = torch.empty(B, N, 3, device=t_samples.device, dtype=torch.float32)
+    covs = torch.empty_like(means)
+    L.check(L.lib().mipnerf_cast_rays(B, N, _ptr(t_samples), _ptr(_f32c(origins, "origins")),
+                                      _ptr(_f32c(directions, "directions")), _ptr(_f32c(radii, "radii")),
+                                      _ptr(means), _ptr(covs), _stream()), "cast_rays")
+    return means, covs
+
+
+def sample_t(num_samples, near, far, randomized, disparity, t_rand=None):
+    """t part of sample_along_rays (mip.py:143-163): [B, N+1]."""
+    near = _f32c(near, "near")
+    far = _f32c(far, "far")
+    B = near.shape[0]
+    if randomized and t_rand is None:
+        t_rand = torch.rand(B, num_samples + 1, device=near.device)   # mip.py:159
+    t = torch.empty(B, num_samples + 1, device=near.device, dtype=torch.float32)
+    L.check(L.lib().mipnerf_sample_along_rays(B, num_samples, _ptr(near), _ptr(far),
+                                              _ptr(_f32c(t_rand, "t_rand")) if randomized else None,
+                                              int(bool(disparity)), _ptr(t), _stream()), "sample_along_rays")
+    return t
+
+
+def sample_along_rays(origins, directions, radii, num_samples, near, far, randomized, disparity, ray_shape,
+                      t_rand=None):
+    """models/mip.py:127-165 -> (t_samples [B,N+1], (means, covs))."""
+    t = sample_t(num_samples, near, far, randomized, disparity, t_rand)
+    return t, cast_rays(t, origins, directions, radii, ray_shape)
+
+
+def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u_rand=None):
+    """models/mip.py:168-229.  `weights` is NOT mutated (the reference pads it in place)."""
+    bins = _f32c(bins, "bins")
+    weights = _f32c(weights, "weights")
+    B, nb = weights.shape
+    if randomized and u_rand is None:
+        u_rand = torch.rand(B, num_samples, device=bins.device)       # stands in for uniform_(mip.py:201)
+    out = torch.empty(B, num_samples, device=bins.device, dtype=torch.float32)
+    L.check(L.lib().mipnerf_sorted_piecewise_constant_pdf(
+        B, nb, _ptr(bins), _ptr(weights), num_samples,
+        _ptr(_f32c(u_rand, "u_rand")) if randomized else None, _ptr(out), _stream()),
+        "sorted_piecewise_constant_pdf")
+    return out
+
+
+def resample_t(t_samples, weights, randomized, resample_padding, u_rand=None):
+    """t part of resample_along_rays (mip.py:250-271): blur-pool + padding + PDF inversion."""
+    t_samples = _f32c(t_samples, "t_samples")
+    weights = _f32c(weights.detach(), "weights")     # stop_grad=True is the only supported mode
+    B, N = weights.shape
+    if randomized and u_rand is None:
+        u_rand = torch.rand(B, N + 1, device=weights.device)
+    out = torch.empty(B, N + 1, device=weights.device, dtype=torch.float32)
+    L.check(L.lib().mipnerf_resample_along_rays(
+        B, N, _ptr(t_samples), _ptr(weights), _ptr(_f32c(u_rand, "u_rand")) if randomized else None,
+        float(resample_padding), _ptr(out), _stream()), "resample_along_rays")
+    return out
+
+
+def resample_along_rays(origins, directions, radii, t_samples, weights, randomized, ray_shape, stop_grad,
+                        resample_padding, u_rand=None):
+    """models/mip.py:232-280 -> (new_t_vals [B,N+1], (means, covs))."""
+    if not stop_grad:
+        raise NotImplementedError("stop_resample_grad=False (gradient through the PDF sampler) is not implemented; "
+                                  "the shipped config uses stop_resample_grad=True")
+    t = resample_t(t_samples, weights, randomized, resample_padding, u_rand)
+    return t, cast_rays(t, origins, directions, radii, ray_shape)
+
+
+def integrated_pos_enc(means_covs, min_deg, max_deg, diagonal=True, precision=L.PREC_FP32):
+    """models/mip.py:322-350 -> [B, N, 6*(max_deg-min_deg)] (float32, or bfloat16 for the bf16 MLP)."""
+    if not diagonal:
+        raise NotImplementedError
+    means, covs = means_covs
+    means = _f32c(means, "means")
+    covs = _f32c(covs, "covs")
+    M = means.numel() // 3
+    enc = torch.empty(*means.shape[:-1], 6 * (max_deg - min_deg), device=means.device, dtype=_torch_dtype(precision))
+    L.check(L.lib().mipnerf_integrated_pos_enc(M, min_deg, max_deg, _ptr(means), _ptr(covs), _ptr(enc),
+                                               precision, _stream()), "integrated_pos_enc")
+    return enc
+
+
+def cast_ipe(t_samples, origins, directions, radii, min_deg, max_deg, disable_integration=False,
+             precision=L.PREC_FP32):
+    """cast_rays + integrated_pos_enc fused (what MipNerf.forward uses): [B, N, 6L]."""
+    t_samples = _f32c(t_samples, "t_samples")
+    B, N1 = t_samples.shape
+    enc = torch.empty(B, N1 - 1, 6 * (max_deg - min_deg), device=t_samples.device, dtype=_torch_dtype(precision))
+    L.check(L.lib().mipnerf_cast_ipe(B, N1 - 1, min_deg, max_deg, int(bool(disable_integration)), _ptr(t_samples),
+                                     _ptr(_f32c(origins, "origins")), _ptr(_f32c(directions, "directions")),
+                                     _ptr(_f32c(radii, "radii")), _ptr(enc), precision, _stream()), "cast_ipe")
+    return enc
+
+
+def pos_enc(x, min_deg, max_deg, append_identity=True, precision=L.PREC_FP32, ld=None):
+    """models/mip.py:353-363 for min_deg == 0, append_identity=True -> [B, 3 + 6*max_deg] (row stride ld)."""
+    if min_deg != 0 or not append_identity:
+        raise NotImplementedError("pos_enc is implemented for min_deg=0, append_identity=True (the only call "
+                                  "on the hot path, mip_nerf.py:220-225)")
+    x = _f32c(x, "x")
+    B = x.shape[0]
+    width = 3 + 6 * max_deg
+    ld = width if ld is None else ld
+    out = torch.empty(B, ld, device=x.device, dtype=_torch_dtype(precision))
+    L.check(L.lib().mipnerf_pos_enc(B, max_deg, _ptr(x), _ptr(out), ld, precision, _stream()), "pos_enc")
+    return out
+
+
+def volumetric_rendering(rgb, density, t_samples, dirs, white_bkgd):
+    """models/mip.py:366-401 -> (comp_rgb [B,3], distance [B], acc [B], weights [B,N])."""
+    rgb_sigma = torch.cat([_f32c(rgb, "rgb"), _f32c(density, "density")], dim=-1).contiguous()
+    return volumetric_rendering_packed(rgb_sigma, t_samples, dirs, white_bkgd)
+
+
+def volumetric_rendering_packed(rgb_sigma, t_samples, dirs, white_bkgd):
+    """Same, on the MLP kernel's packed output [B, N, 4] = (r, g, b, sigma)."""
+    rgb_sigma = _f32c(rgb_sigma, "rgb_sigma")
+    t_samples = _f32c(t_samples, "t_samples")
+    B, N1 = t_samples.shape
+    N = N1 - 1
+    dev = t_samples.device
+    comp_rgb = torch.empty(B, 3, device=dev)
+    distance = torch.empty(B, device=dev)
+    acc = torch.empty(B, device=dev)
+    weights = torch.empty(B, N, device=dev)
+    L.check(L.lib().mipnerf_volumetric_rendering(B, N, _ptr(rgb_sigma), _ptr(t_samples), _ptr(_f32c(dirs, "dirs")),
+                                                 int(bool(white_bkgd)), _ptr(comp_rgb), _ptr(distance), _ptr(acc),
+                                                 _ptr(weights), _stream()), "volumetric_rendering")
+    return comp_rgb, distance, acc, weights
+
+
+def selftest() -> str:
+    """Run the hardware self-test (MFMA lane layouts, LDS DMA); returns the report, raises on failure."""
+    rc = L.lib().mipnerf_selftest(_stream())
+    msg = L.last_error()
+    if rc != 0:
+        raise RuntimeError(f"gfx950 self-test failed (code {rc:#x}): {msg}")
+    return msg

@@ -34,8 +34,10 @@ def _f32(x):
 
 
 def torch_linspace(start, end, steps):
-    """torch.linspace(start, end, steps) for float32 on CPU (ATen RangeFactories:
-    value = start + step*i for i < steps/2, else end - step*(steps-1-i))."""
+    """torch.linspace(start, end, steps) for float32 (ATen RangeFactories: value =
+    start + step*i for i < steps/2, else end - step*(steps-1-i), with the multiply-add FUSED,
+    as ATen's CPU (FMA) and CUDA (-fmad) builds do; checked bit-for-bit against torch in
+    tests/test_hostmath_cpu.py).  The fused op is emulated in float64 (exact product)."""
     start = F32(start)
     end = F32(end)
     if steps == 1:
@@ -43,8 +45,8 @@ def torch_linspace(start, end, steps):
     step = F32((end - start) / F32(steps - 1))
     i = np.arange(steps)
     half = steps // 2
-    lo = (start + step * i.astype(F32)).astype(F32)
-    hi = (end - step * (steps - 1 - i).astype(F32)).astype(F32)
+    lo = (np.float64(start) + np.float64(step) * i).astype(F32)
+    hi = (np.float64(end) - np.float64(step) * (steps - 1 - i)).astype(F32)
     return np.where(i < half, lo, hi).astype(F32)
 
 
@@ -135,10 +137,10 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u_rand
     cdf = np.concatenate([np.zeros(shp, F32), cdf, np.ones(shp, F32)], axis=-1)
 
     if randomized:
-        s = F32(1 / num_samples)
-        u = (np.arange(num_samples).astype(F32) * s)[None, :]
+        s = 1 / num_samples                       # python float (double), mip.py:199
+        u = (np.arange(num_samples).astype(F32) * F32(s))[None, :]
         assert u_rand is not None
-        u = u + _f32(u_rand) * F32(s - EPS32)
+        u = u + _f32(u_rand) * F32(s - float(EPS32))   # uniform_(to=s-eps): x * float32(to)
         u = np.minimum(u, F32(1. - EPS32)).astype(F32)
     else:
         u = torch_linspace(0., 1. - EPS32, num_samples)

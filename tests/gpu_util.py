@@ -1,0 +1,60 @@
+"""Helpers shared by the -m gpu tests (the parity tests proper)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from mipnerf_pl_amd import Rays
+from oracle import mipnerf_oracle as orc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(REPO, "gpurun_out")
+DEV = "cuda:0"
+
+# ---- stated tolerances ---------------------------------------------------------------------------
+# fp32 mode (exact-fp32 MFMA): differences from the fp32 reference come from summation order
+# (GEMM k-order, wave scans vs sequential cumsum) and libm ulps; 1-ulp changes of the resampled t move
+# high-frequency IPE features by up to 3e-4, which reaches the outputs attenuated (measured with the
+# oracle: rgb 7e-7, weights 7e-6).  Tolerance on every final output of MipNerf.forward:
+TOL_FP32 = dict(rgb=5e-5, distance=2e-4, acc=5e-5, weights=5e-5, t_samples=2e-5)
+# bf16 mode (bf16 operands, fp32 accumulate, 10 chained layers): measured with a numpy bf16 emulation
+# against the fp32 oracle: rgb 7e-4, distance 6e-3, acc 1.4e-4, weights 3.7e-3 (PSNR of bf16 vs fp32
+# renders 74 dB, i.e. < 0.001 dB change of a 35 dB PSNR).  Tolerance = ~5x that:
+TOL_BF16 = dict(rgb=5e-3, distance=3e-2, acc=2e-3, weights=2e-2, t_samples=2e-2)
+NAMES = ("rgb", "distance", "acc", "weights", "t_samples")
+
+
+def to_dev(rays_np):
+    return Rays(*[torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in rays_np])
+
+
+def rays_of(g):
+    return orc.Rays(*[g["rays_" + k] for k in orc.Rays._fields])
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(REPO, "tests", "golden", name + ".npz")))
+
+
+def make_model(params, num_samples, precision, **kw):
+    from mipnerf_pl_amd import MipNerf
+    m = MipNerf(num_samples=num_samples, precision=precision, **kw)
+    sd = {"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    return m.to(DEV)
+
+
+def record(tag, **vals):
+    """Append one JSON line of measured errors to gpurun_out/parity.jsonl (merged back by gpurun)."""
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity.jsonl"), "a") as f:
+        f.write(json.dumps(dict(tag=tag, **{k: float(v) for k, v in vals.items()})) + "\n")
+
+
+def maxdiff(a, b):
+    a = a.detach().float().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0

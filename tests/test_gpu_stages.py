@@ -1,0 +1,199 @@
+"""GPU parity, stage by stage: every C-ABI entry point against the oracle on identical inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mipnerf_oracle as orc
+from mipnerf_pl_amd.mlp_plan import bf16_round
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_util
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    return gpu_util
+
+
+@pytest.fixture(scope="module")
+def stage(G):
+    g = G.load_golden("stages_16x64_trained")
+    return g, G.rays_of(g), G.to_dev(G.rays_of(g))
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def test_hardware_selftest(G):
+    from mipnerf_pl_amd import ops
+    print(ops.selftest())
+
+
+@pytest.mark.parametrize("N", [64, 100, 128, 256])
+@pytest.mark.parametrize("disparity", [False, True])
+@pytest.mark.parametrize("randomized", [False, True])
+def test_sample_along_rays(G, N, disparity, randomized):
+    from mipnerf_pl_amd import ops
+    rays = orc.synthetic_rays(37, seed=N, unbounded=True)
+    R = G.to_dev(rays)
+    t_rand = np.random.default_rng(1).random((37, N + 1), dtype=np.float32) if randomized else None
+    t, (m, c) = ops.sample_along_rays(R.origins, R.directions, R.radii, N, R.near, R.far, randomized, disparity, "cone",
+                                      t_rand=T(t_rand) if randomized else None)
+    to, (mo, co) = orc.sample_along_rays(rays.origins, rays.directions, rays.radii, N, rays.near, rays.far,
+                                         randomized, disparity, t_rand=t_rand)
+    G.record(f"sample_along_rays N={N} disp={disparity} rand={randomized}", t=G.maxdiff(t, to), means=G.maxdiff(m, mo))
+    # same op order, IEEE ops: t bit-exact except 1/x in the disparity form (1 ulp)
+    assert G.maxdiff(t, to) <= (0 if not disparity else 4e-6)
+    assert G.maxdiff(m, mo) <= (0 if not disparity else 2e-5)
+    np.testing.assert_allclose(c.cpu().numpy(), co, rtol=2e-5, atol=1e-12)
+
+
+def test_cast_rays_and_ipe(G, stage):
+    from mipnerf_pl_amd import ops, _lib as L
+    g, rays, R = stage
+    t1 = T(g["t1"])
+    m, c = ops.cast_rays(t1, R.origins, R.directions, R.radii)
+    assert G.maxdiff(m, g["means1"]) == 0.0          # bit-exact (no FMA contraction, same order)
+    np.testing.assert_allclose(c.cpu().numpy(), g["covs1"], rtol=3e-6, atol=1e-14)
+    enc = ops.integrated_pos_enc((T(g["means1"]), T(g["covs1"])), 0, 16)
+    e1 = G.maxdiff(enc, g["enc1"])
+    fused = ops.cast_ipe(t1, R.origins, R.directions, R.radii, 0, 16)
+    e2 = G.maxdiff(fused, g["enc1"])
+    encb = ops.cast_ipe(t1, R.origins, R.directions, R.radii, 0, 16, precision=L.PREC_BF16)
+    e3 = G.maxdiff(encb.float(), bf16_round(g["enc1"]))
+    G.record("ipe", separate=e1, fused=e2, bf16_vs_rounded=e3)
+    assert e1 <= 2e-6 and e2 <= 2e-6      # sin/exp within a few ulp of torch's
+    assert e3 <= 2 ** -8                  # at most one bf16 ulp (|enc| <= 1) where fp32 differs at a rounding tie
+    # disable_integration: covariance zeroed -> plain positional encoding
+    pe = ops.cast_ipe(t1, R.origins, R.directions, R.radii, 0, 16, disable_integration=True)
+    peo = orc.integrated_pos_enc((g["means1"], np.zeros_like(g["covs1"])), 0, 16)
+    assert G.maxdiff(pe, peo) <= 2e-6
+
+
+def test_pos_enc(G, stage):
+    from mipnerf_pl_amd import ops
+    g, rays, R = stage
+    v = ops.pos_enc(R.viewdirs, 0, 4, True)
+    assert v.shape == (16, 27)
+    assert G.maxdiff(v, g["viewdirs_enc"]) <= 1e-6
+    v32 = ops.pos_enc(R.viewdirs, 0, 4, True, ld=32)
+    assert float(v32[:, 27:].abs().max()) == 0.0
+
+
+def test_mlp_fp32(G, stage):
+    from mipnerf_pl_amd import _lib as L
+    g, rays, R = stage
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    model = G.make_model(params, 64, "fp32")
+    with torch.no_grad():
+        raw_rgb, raw_density, act = model.mlp(T(g["enc0"]), T(g["viewdirs_enc"]), precision=L.PREC_FP32,
+                                              return_activated=True)
+    er, ed = G.maxdiff(raw_rgb, g["raw_rgb0"]), G.maxdiff(raw_density, g["raw_density0"])
+    ea = G.maxdiff(act[..., :3], g["rgb0"])
+    es = float(np.max(np.abs(act[..., 3:].cpu().numpy() - g["density0"]) / (1 + np.abs(g["density0"]))))
+    G.record("mlp_fp32", raw_rgb=er, raw_density=ed, rgb=ea, density_rel=es)
+    assert er <= 2e-5 and ed <= 2e-4 and ea <= 5e-6 and es <= 2e-5
+
+
+def mlp_bf16_emulation(params, x, v):
+    """numpy model of the bf16 kernel: bf16 weights/activations, fp32 accumulate, fp32 bias/ReLU."""
+    r = bf16_round
+    P = {k: (r(w) if k.endswith("weight") else w) for k, w in params.items()}
+    inputs = r(x)
+    x = inputs
+    for i in range(8):
+        x = r(np.maximum(x @ P[f"layers.{i}.0.weight"].T + P[f"layers.{i}.0.bias"], 0))
+        if i % 4 == 0 and i > 0:
+            x = np.concatenate([x, inputs], -1)
+    dens = x @ P["density_layer.weight"].T + P["density_layer.bias"]
+    b = r(x @ P["extra_layer.weight"].T + P["extra_layer.bias"])
+    vd = np.broadcast_to(r(v)[:, None, :], (x.shape[0], x.shape[1], v.shape[-1]))
+    x = r(np.maximum(np.concatenate([b, vd], -1) @ P["view_layers.0.0.weight"].T + P["view_layers.0.0.bias"], 0))
+    return (x @ P["color_layer.weight"].T + P["color_layer.bias"]).astype(np.float32), dens.astype(np.float32)
+
+
+def test_mlp_bf16(G, stage):
+    from mipnerf_pl_amd import _lib as L
+    g, rays, R = stage
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    model = G.make_model(params, 64, "bf16")
+    enc, venc = T(g["enc0"]), T(g["viewdirs_enc"])
+    with torch.no_grad():
+        rgb_dma, den_dma = [x.clone() for x in model.mlp(enc, venc, precision=L.PREC_BF16)]
+        ctx = model.mlp.native(enc.device)
+        ctx.set_option(0, 0)          # register-staged ring instead of LDS DMA: must be bit-identical
+        rgb_reg, den_reg = [x.clone() for x in model.mlp(enc, venc, precision=L.PREC_BF16)]
+        ctx.set_option(0, 1)
+    assert torch.equal(rgb_dma, rgb_reg) and torch.equal(den_dma, den_reg)
+    er_, ed_ = mlp_bf16_emulation(params, g["enc0"], g["viewdirs_enc"])
+    e_emu_r, e_emu_d = G.maxdiff(rgb_dma, er_), G.maxdiff(den_dma, ed_)
+    e_f32_r, e_f32_d = G.maxdiff(rgb_dma, g["raw_rgb0"]), G.maxdiff(den_dma, g["raw_density0"])
+    G.record("mlp_bf16", vs_emulation_rgb=e_emu_r, vs_emulation_density=e_emu_d, vs_fp32_rgb=e_f32_r,
+             vs_fp32_density=e_f32_d)
+    # vs the bf16 emulation only accumulation order differs (occasional 1-bf16-ulp flips of an activation)
+    assert e_emu_r <= 6e-3 and e_emu_d <= 0.15
+    # vs the fp32 reference: bf16 rounding of 10 chained layers (|raw_density| up to ~23 here)
+    assert e_f32_r <= 2e-2 and e_f32_d <= 0.4
+
+
+@pytest.mark.parametrize("N", [64, 100, 128, 256, 300])
+@pytest.mark.parametrize("white", [True, False])
+def test_volumetric_rendering(G, N, white):
+    from mipnerf_pl_amd import ops
+    B = 33
+    rng = np.random.default_rng(N)
+    rays = orc.synthetic_rays(B, seed=3)
+    t = np.sort(rng.uniform(2, 6, (B, N + 1)).astype(np.float32), axis=-1)
+    rgb = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    dens = (rng.uniform(0, 1, (B, N, 1)) ** 8 * 60).astype(np.float32)
+    dens[0] = 0            # empty ray
+    dens[1] = 0
+    dens[1, N // 2] = 1e6  # single opaque bin
+    out = ops.volumetric_rendering(T(rgb), T(dens), T(t), T(rays.directions), white)
+    ref = orc.volumetric_rendering(rgb, dens, t, rays.directions, white)
+    errs = [G.maxdiff(a, b) for a, b in zip(out, ref)]
+    G.record(f"volumetric_rendering N={N} white={white}", rgb=errs[0], distance=errs[1], acc=errs[2], weights=errs[3])
+    assert errs[0] <= 1e-5 and errs[1] <= 5e-5 and errs[2] <= 1e-5 and errs[3] <= 1e-5
+    # known answers: zero density => acc 0, rgb = background, distance = near
+    assert float(out[2][0]) == 0.0 and float(out[1][0]) == float(t[0, 0])
+    assert torch.all(out[0][0] == (1.0 if white else 0.0))
+    assert abs(float(out[3][1, N // 2]) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("N", [64, 100, 128, 256])
+@pytest.mark.parametrize("randomized", [False, True])
+def test_resample_along_rays(G, N, randomized):
+    from mipnerf_pl_amd import ops
+    B = 29
+    rng = np.random.default_rng(N + 7)
+    rays = orc.synthetic_rays(B, seed=5)
+    t = np.sort(rng.uniform(2, 6, (B, N + 1)).astype(np.float32), axis=-1)
+    w = (rng.uniform(0, 1, (B, N)) ** 6).astype(np.float32)
+    w[0] = 0
+    w[1] = 0
+    w[1, 7] = 1.0
+    u = rng.random((B, N + 1), dtype=np.float32) if randomized else None
+    R = G.to_dev(rays)
+    tn, (m, c) = ops.resample_along_rays(R.origins, R.directions, R.radii, T(t), T(w), randomized, "cone", True, 0.01,
+                                         u_rand=T(u) if randomized else None)
+    to, _ = orc.resample_along_rays(rays.origins, rays.directions, rays.radii, t, w, randomized, u_rand=u)
+    e = G.maxdiff(tn, to)
+    G.record(f"resample N={N} rand={randomized}", t=e)
+    assert e <= 5e-6
+    tn_np = tn.cpu().numpy()
+    assert np.all(np.diff(tn_np, axis=-1) >= 0)                       # sorted, no explicit sort needed
+    assert np.all(tn_np >= t[:, :1] - 1e-6) and np.all(tn_np <= t[:, -1:] + 1e-6)
+
+
+def test_sorted_piecewise_constant_pdf_edge_cases(G, stage):
+    from mipnerf_pl_amd import ops
+    g, _, _ = stage
+    w = T(g["pdf_w"])
+    w0 = w.clone()
+    out = ops.sorted_piecewise_constant_pdf(T(g["pdf_bins"]), w, g["pdf_t"].shape[-1], False)
+    assert torch.equal(w, w0), "weights must not be mutated (the reference mutates its argument, mip.py:184)"
+    e = G.maxdiff(out, g["pdf_t"])
+    G.record("pdf_edge_cases", t=e)
+    assert e <= 5e-6
