@@ -197,11 +197,23 @@ def test_resample_along_rays(G, N, randomized):
     to, _ = orc.resample_along_rays(rays.origins, rays.directions, rays.radii, t, w, randomized, u_rand=u)
     e = G.maxdiff(tn, to)
     G.record(f"resample N={N} rand={randomized}", t=e)
-    # prefix sums in fp64 like torch's CPU cumsum; what is left is the fp32 rounding of weight_sum / pdf
-    assert e <= 1e-5
+    # Adversarial input: weights ~ U^6 give bins whose pdf is ~5e-4 and (random fence posts) up to 0.2 wide, where the
+    # reference itself is ill-conditioned: a 1e-7 relative change of weight_sum (fp32 summation order) moves t by
+    # 1e-7 / 5e-4 * 0.2 = 4e-5.  Prefix sums run in fp64 like torch's CPU cumsum.  Realistic weights: see
+    # test_resample_matches_reference_stage (5e-6).
+    assert e <= 1e-4
     tn_np = tn.cpu().numpy()
     assert np.all(np.diff(tn_np, axis=-1) >= 0)                       # sorted, no explicit sort needed
     assert np.all(tn_np >= t[:, :1] - 1e-6) and np.all(tn_np <= t[:, -1:] + 1e-6)
+
+
+def test_resample_matches_reference_stage(G, stage):
+    from mipnerf_pl_amd import ops
+    g, rays, R = stage
+    t1 = ops.resample_t(T(g["t0"]), T(g["weights0"]), False, 0.01)
+    e = G.maxdiff(t1, g["t1"])
+    G.record("resample_stage_golden", t=e)
+    assert e <= 5e-6
 
 
 def test_sorted_piecewise_constant_pdf_edge_cases(G, stage):
