@@ -72,6 +72,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    ctx = model.mlp.native(dev)
+    ctx.set_option(2, 1)          # HIP events around every MLP launch of the timed region (launch stream)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -87,27 +89,30 @@ def main():
     samples_per_step = B * N * model.num_levels
     value = samples_per_step * world * args.steps / dt
 
-    # ---- roofline of the dominant kernel (bf16 / fp32 MFMA MLP), HIP events on the launch stream ----
+    # ---- roofline of the dominant kernel (bf16 / fp32 MFMA MLP): average duration of the MLP launches made
+    # INSIDE the timed region, from HIP events recorded on the launch stream by the library ----
     roofline = None
     cpu_baseline = None
+    import ctypes as C
+    tot_ms, nl = C.c_double(), C.c_int64()
+    L.check(L.lib().mipnerf_mlp_launch_stats(ctx.handle, C.byref(tot_ms), C.byref(nl)), "mlp_launch_stats")
+    ctx.set_option(2, 0)
     if rank == 0:
         prec = model.precision
-        dt_t = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
         M = B * N
-        enc = (torch.rand(M, 96, device=dev) * 2 - 1).to(dt_t)
-        venc = torch.zeros(B, 32, device=dev, dtype=dt_t)
-        venc[:, :27] = (torch.rand(B, 27, device=dev) * 2 - 1).to(dt_t)
-        rgbs = torch.empty(M, 4, device=dev)
-        ctx = model.mlp.native(dev)
-        import ctypes as C
-        ms = C.c_float()
-        L.check(L.lib().mipnerf_time_mlp(ctx.handle, M, N, enc.data_ptr(), venc.data_ptr(), prec, rgbs.data_ptr(),
-                                         20, C.byref(ms), torch.cuda.current_stream().cuda_stream), "time_mlp")
-        tflops = FLOP_PER_SAMPLE * M / (ms.value * 1e-3) / 1e12
+        launch_ms = tot_ms.value / max(1, nl.value)
+        tflops = FLOP_PER_SAMPLE * M / (launch_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.precision]
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "mlp_pmc.json")     # HBM bytes/launch from rocprofv3 --pmc passes
+        if os.path.exists(pmc):
+            pj = json.load(open(pmc))
+            if pj.get("precision") == args.precision and pj.get("samples_per_launch") == M:
+                traffic = pj.get("hbm_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "k_mlp_bf16" if prec == L.PREC_BF16 else "k_mlp_f32",
                     "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
-                    "traffic": None, "launch_ms": round(ms.value, 4), "samples_per_launch": M}
+                    "traffic": traffic, "launch_ms": round(launch_ms, 4), "launches_timed": int(nl.value),
+                    "samples_per_launch": M, "flop_per_sample": FLOP_PER_SAMPLE}
         if world == 1 and not args.no_cpu_baseline:
             # bounded sample of the same workload: 256 rays x N x 2 levels through the numpy oracle
             nb = 256

@@ -189,8 +189,12 @@ int mipnerf_time_mlp(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples, 
 int mipnerf_selftest(void* stream);
 /* Tuning / debug knobs.  option 0: bf16 MLP weight staging (1 = global_load_lds ring
  * [default], 0 = register-staged ring, same schedule); option 1: persistent grid size of the
- * bf16 MLP kernel (default = number of CUs). */
+ * bf16 MLP kernel (default = number of CUs); option 2: 1 = record a HIP event pair around
+ * every MLP launch issued by mipnerf_forward (read with mipnerf_mlp_launch_stats). */
 int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
+/* Sum of the elapsed times (ms) and the number of MLP launches recorded since the last call
+ * (option 2); synchronises on the recorded events. */
+int mipnerf_mlp_launch_stats(mipnerf_ctx* ctx, double* total_ms, int64_t* launches);
 /* Host-only exports of the static plan tables (no GPU needed), used by the CPU tests to
  * prove the C++ plan expansion equals mipnerf_pl_amd/mlp_plan.py.  which: 0 = bf16 stream
  * pack table, 1 = bias table, 2 = fp32 stream pack table (flat parameter indices, -1 = 0).

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libmipnerf_hip.so")
+LIB_PATH = os.environ.get("MIPNERF_LIB", os.path.join(HERE, "csrc", "libmipnerf_hip.so"))   # override: A/B builds
 
 OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_WORKSPACE = 0, 1, 2, 3, 4
 PREC_FP32, PREC_BF16 = 0, 1
@@ -59,6 +59,7 @@ SIGNATURES = {
     "mipnerf_time_mlp": (C.c_int, [_P, _I64, _I32, _P, _P, C.c_int, _P, C.c_int, C.POINTER(_F), _P]),
     "mipnerf_selftest": (C.c_int, [_P]),
     "mipnerf_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
+    "mipnerf_mlp_launch_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "mipnerf_debug_table": (_I64, [C.c_int, _P, _I64]),
     "mipnerf_debug_f32net": (_I64, [_P, _I64]),
 }

@@ -17,7 +17,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(CSRC, "libmipnerf_hip.so")
+LIB = os.path.join(CSRC, os.environ.get("MIPNERF_LIB_NAME", "libmipnerf_hip.so"))
 ARCH = "gfx950"
 
 UNITS = [
@@ -58,8 +58,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     generate()
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "mipnerf_hip.h"))
-    stamp = os.path.join(CSRC, ".build_stamp")
-    dig = _digest(deps, COMMON + sum((f for _, f in UNITS), []))
+    stamp = os.path.join(CSRC, ".build_stamp_" + os.path.basename(LIB))
+    dig = _digest(deps, COMMON + sum((f for _, f in UNITS), []) + [f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MLP_")])
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         if verbose:
             print(f"[build] {LIB} is up to date")

@@ -163,6 +163,10 @@ struct mipnerf_ctx {
     bool params_set = false;
     int mlp_dma = 1;                 // 1: global_load_lds ring, 0: register-staged ring (debug)
     int grid_limit = 256;            // persistent workgroups of the bf16 MLP kernel (= CUs)
+    // optional instrumentation: HIP events around every MLP launch made by mipnerf_forward
+    int time_mlp = 0;
+    std::vector<hipEvent_t> ev;      // pairs (start, stop)
+    size_t ev_used = 0;
 };
 
 extern "C" {
@@ -235,6 +239,7 @@ int mipnerf_destroy(mipnerf_ctx* c) {
     if (!c) return MIPNERF_OK;
     (void)hipFree(c->d_pack_bf16); (void)hipFree(c->d_pack_f32); (void)hipFree(c->d_bias_idx);
     (void)hipFree(c->d_stream_bf16); (void)hipFree(c->d_stream_f32); (void)hipFree(c->d_bias);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
     return MIPNERF_OK;
 }
@@ -244,6 +249,7 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
     switch (option) {
         case 0: c->mlp_dma = value ? 1 : 0; return MIPNERF_OK;
         case 1: if (value < 1) return fail(MIPNERF_E_INVALID, "grid_limit < 1"); c->grid_limit = value; return MIPNERF_OK;
+        case 2: c->time_mlp = value ? 1 : 0; c->ev_used = 0; return MIPNERF_OK;
         default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
     }
 }
@@ -390,7 +396,16 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
         }
         if ((rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, o.t_samples,
                                    rays->origins, rays->directions, rays->radii, enc, precision, stream))) return rc;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (c->time_mlp) {
+            if (c->ev_used + 2 > c->ev.size()) {
+                for (int i = 0; i < 64; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->ev.push_back(e); }
+            }
+            e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1]; c->ev_used += 2;
+            HIP_TRY(hipEventRecord(e0, S(stream)));
+        }
         if ((rc = mipnerf_mlp_forward(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream))) return rc;
+        if (c->time_mlp) HIP_TRY(hipEventRecord(e1, S(stream)));
         if ((rc = mipnerf_volumetric_rendering(B, N, rgb_sigma, o.t_samples, rays->directions, white, o.comp_rgb,
                                                o.distance, o.acc, o.weights, stream))) return rc;
     }
@@ -416,6 +431,21 @@ int mipnerf_time_mlp(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, cons
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms = t / iters;
+    return MIPNERF_OK;
+}
+
+int mipnerf_mlp_launch_stats(mipnerf_ctx* c, double* total_ms, int64_t* launches) {
+    if (!c || !total_ms || !launches) return fail(MIPNERF_E_INVALID, "mlp_launch_stats: null argument");
+    double tot = 0;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(c->ev[i + 1]));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+        tot += t;
+    }
+    *total_ms = tot;
+    *launches = (int64_t)(c->ev_used / 2);
+    c->ev_used = 0;
     return MIPNERF_OK;
 }
 

@@ -133,6 +133,18 @@ template <> struct Pack<__bf16> {
     }
 };
 
+// Accuracy policy per output type: float rows feed the exact-fp32 MLP (parity mode) and use the accurate
+// libm sin/exp (<= 1-2 ulp, like torch); bf16 rows are rounded to 8 bits anyway and use the fast pair.
+template <typename OutT> struct IpeMath;
+template <> struct IpeMath<float> {
+    __device__ static float sin(float x) { return sin_accurate(x); }
+    __device__ static float exp(float x) { return exp_accurate(x); }
+};
+template <> struct IpeMath<__bf16> {
+    __device__ static float sin(float x) { return sin_fast(x); }
+    __device__ static float exp(float x) { return exp_fast(x); }
+};
+
 // Thread q in {0,1} of a sample writes degrees [q*L/2, (q+1)*L/2) of both halves (sin | "cos").
 template <typename OutT, int L>
 __device__ __forceinline__ void ipe_write(const Gauss3& g, int q, int min_deg, OutT* row) {
@@ -146,9 +158,9 @@ __device__ __forceinline__ void ipe_write(const Gauss3& g, int q, int min_deg, O
         for (int a = 0; a < 3; ++a) {
             const float y = g.mean[a] * scale;
             const float yv = g.cov[a] * (scale * scale);
-            const float damp = exp_accurate(-0.5f * yv);
-            fs[ll * 3 + a] = damp * sin_accurate(y);
-            fc[ll * 3 + a] = damp * sin_accurate(y + kHalfPiF);
+            const float damp = IpeMath<OutT>::exp(-0.5f * yv);
+            fs[ll * 3 + a] = damp * IpeMath<OutT>::sin(y);
+            fc[ll * 3 + a] = damp * IpeMath<OutT>::sin(y + kHalfPiF);
         }
     }
     Pack<OutT>::store(row + q * H, fs, H);

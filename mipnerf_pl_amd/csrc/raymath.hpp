@@ -60,6 +60,19 @@ MIP_HD Gauss3 conical_frustum_to_gaussian(float t0, float t1, const float d[3], 
 MIP_HD float sin_accurate(float x) { return sinf(x); }
 MIP_HD float exp_accurate(float x) { return expf(x); }
 
+#if defined(__HIPCC__)
+// Fast variants for the bf16 pipeline (features are rounded to 8 mantissa bits right after):
+// exact argument reduction in fp64 -- x/(2 pi) is formed with a 53-bit product, so even at |x| = 3e5 rad
+// the reduced phase is good to 1e-11 turns -- followed by the hardware v_sin_f32 (input in turns) and
+// v_exp_f32.  ~12 issue slots instead of ~150 for the accurate libm pair.
+__device__ __forceinline__ float sin_fast(float x) {
+    double r = (double)x * 0.15915494309189535;   // 1 / (2 pi)
+    r -= rint(r);                                 // [-0.5, 0.5] turns
+    return __builtin_amdgcn_sinf((float)r);
+}
+__device__ __forceinline__ float exp_fast(float x) { return __expf(x); }
+#endif
+
 // models/mip.py:322-350 + 283-289: feature (half, l, axis) of the integrated positional
 // encoding, index = half*3L + l*3 + axis; "cos" is sin(fl32(y + fl32(pi/2))) as the reference.
 MIP_HD float ipe_feature(const Gauss3& g, int half, int l, int axis, int min_deg) {
