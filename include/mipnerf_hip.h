@@ -177,6 +177,24 @@ int mipnerf_sorted_piecewise_constant_pdf(int64_t num_rays, int32_t num_bins, co
                                           const float* weights, int32_t num_draws,
                                           const float* u_rand, float* samples, void* stream);
 
+/* ---- training side ---------------------------------------------------------------------- */
+/* activations (mip_nerf.py:236-238): raw [M,4] = (raw_rgb, raw_density) -> rgb_sigma [M,4]. */
+int mipnerf_activate(int64_t num_points, const float* raw, float rgb_padding, float density_bias,
+                     float* rgb_sigma, void* stream);
+/* backward of volumetric_rendering (mip.py:366-401) fused with the activation derivatives:
+ * upstream g_rgb [B,3], g_dist [B], g_acc [B], g_w [B,N] (any may be NULL = zero) ->
+ * d_raw [B*N,4] = dL/d(raw_rgb, raw_density).  rgb_sigma is the ACTIVATED forward tensor. */
+int mipnerf_volumetric_rendering_bwd(int64_t num_rays, int32_t num_samples, const float* rgb_sigma,
+                                     const float* t_samples, const float* directions,
+                                     int32_t white_bkgd, const float* g_rgb, const float* g_dist,
+                                     const float* g_acc, const float* g_w, float rgb_padding,
+                                     float* d_raw, void* stream);
+/* distloss (mip.py:8-20) without the [B,N,N] temporaries: ray_loss [B] (the reference value is
+ * its mean over rays); if g_ray [B] is given also d_w [B,N] = g_ray[b] * d ray_loss[b] / d w. */
+int mipnerf_distloss(int64_t num_rays, int32_t num_samples, const float* weights,
+                     const float* t_samples, float* ray_loss, const float* g_ray, float* d_w,
+                     void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------ */
 /* Times `iters` launches of the bf16 MLP kernel with hipEvents on `stream`; returns the
  * average milliseconds per launch in *ms (used by bench.py for roofline.achieved). */

@@ -23,6 +23,7 @@ ARCH = "gfx950"
 UNITS = [
     # (source, extra flags)
     ("kernels_ray.hip", ["-ffp-contract=off"]),
+    ("kernels_train.hip", ["-ffp-contract=off"]),
     ("kernels_pack.hip", []),
     ("kernels_mlp_f32.hip", ["-ffp-contract=off"]),
     ("mlp_bf16_gen.hip", []),

@@ -353,6 +353,31 @@ int mipnerf_sorted_piecewise_constant_pdf(int64_t B, int32_t nbins, const float*
     return MIPNERF_OK;
 }
 
+// ---- training-side entry points ------------------------------------------------------------------
+int mipnerf_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, float* rgb_sigma, void* stream) {
+    if (M < 1 || !raw || !rgb_sigma) return fail(MIPNERF_E_INVALID, "activate: bad argument");
+    HIP_TRY(mip::launch_activate(M, raw, rgb_padding, density_bias, rgb_sigma, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_volumetric_rendering_bwd(int64_t B, int32_t N, const float* rgb_sigma, const float* t, const float* dirs,
+                                     int32_t white_bkgd, const float* g_rgb, const float* g_dist, const float* g_acc,
+                                     const float* g_w, float rgb_padding, float* d_raw, void* stream) {
+    if (B < 1 || N < 1 || N > MIPNERF_MAX_SAMPLES || !rgb_sigma || !t || !dirs || !d_raw)
+        return fail(MIPNERF_E_INVALID, "volumetric_rendering_bwd: bad argument");
+    HIP_TRY(mip::launch_volumetric_rendering_bwd(B, N, rgb_sigma, t, dirs, white_bkgd, g_rgb, g_dist, g_acc, g_w,
+                                                 rgb_padding, d_raw, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_distloss(int64_t B, int32_t N, const float* weights, const float* t, float* ray_loss, const float* g_ray,
+                     float* d_w, void* stream) {
+    if (B < 1 || N < 1 || N > MIPNERF_MAX_SAMPLES || !weights || !t || (!ray_loss && !d_w) || ((g_ray == nullptr) != (d_w == nullptr)))
+        return fail(MIPNERF_E_INVALID, "distloss: bad argument");
+    HIP_TRY(mip::launch_distloss(B, N, weights, t, ray_loss, g_ray, d_w, S(stream)));
+    return MIPNERF_OK;
+}
+
 // ---- the level loop ---------------------------------------------------------------------------------
 size_t mipnerf_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
     if (!c || B < 1) return 0;

@@ -24,6 +24,14 @@ hipError_t launch_piecewise_constant_pdf(int64_t B, int N, const float* bins, co
                                          const float* u_rand, bool blur, float padding, float* out,
                                          hipStream_t st);
 
+// ---- kernels_train.hip ------------------------------------------------------------------------
+hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, float* out, hipStream_t st);
+hipError_t launch_volumetric_rendering_bwd(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs,
+                                           int white_bkgd, const float* g_rgb, const float* g_dist, const float* g_acc,
+                                           const float* g_w, float rgb_padding, float* d_raw, hipStream_t st);
+hipError_t launch_distloss(int64_t B, int N, const float* weights, const float* t, float* ray_loss, const float* g_ray,
+                           float* d_w, hipStream_t st);
+
 // ---- mlp_bf16_gen.hip (generated) -------------------------------------------------------------
 int mlp_bf16_lds_bytes();
 hipError_t launch_mlp_bf16(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,

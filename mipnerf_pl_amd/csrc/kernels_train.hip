@@ -1,0 +1,229 @@
+// Training-side ray kernels for gfx950: activations of the raw MLP outputs, backward of
+// volumetric_rendering (models/mip.py:366-401) fused with the activation derivatives
+// (models/mip_nerf.py:236-238), and the distortion loss (models/mip.py:8-20) forward/backward in O(N)
+// per ray (the reference builds two [B,N,N] tensors).  One wavefront per ray, scans in fp64.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "raymath.hpp"
+
+namespace mip {
+
+__device__ __forceinline__ double wsum64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// exclusive prefix (forward) / exclusive suffix (reverse) sums over the 64 lanes
+__device__ __forceinline__ double wexcl_prefix64(double v, int lane) {
+    double inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double n = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += n;
+    }
+    const double ex = __shfl_up(inc, 1, 64);
+    return lane == 0 ? 0.0 : ex;
+}
+__device__ __forceinline__ double wexcl_suffix64(double v, int lane) {
+    double inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double n = __shfl_down(inc, o, 64);
+        if (lane + o < 64) inc += n;
+    }
+    const double ex = __shfl_down(inc, 1, 64);
+    return lane == 63 ? 0.0 : ex;
+}
+
+// raw [M,4] = (raw_rgb, raw_density) -> (sigmoid*(1+2p)-p, softplus(raw+bias))  (mip_nerf.py:236-238)
+__global__ void __launch_bounds__(256)
+k_activate(int64_t M, const float4* __restrict__ raw, float rgb_padding, float density_bias, float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float4 r = raw[i];
+    out[i] = make_float4(rgb_activation(r.x, rgb_padding), rgb_activation(r.y, rgb_padding),
+                         rgb_activation(r.z, rgb_padding), density_activation(r.w, density_bias));
+}
+
+// Backward of volumetric_rendering + activations.
+//   w_i = (1 - e^{-x_i}) T_i,  x_i = sigma_i * delta_i,  T_i = exp(-sum_{j<i} x_j)
+//   G_i  = dL/dw_i = sum_c g_rgb_c (c_ic - [white]) + g_acc + g_dist * tmid_i + g_w_i
+//   dL/dx_i = G_i T_{i+1} - sum_{k>i} G_k w_k ,  dL/dsigma_i = delta_i dL/dx_i ,  dL/dc_i = w_i g_rgb
+//   d raw_rgb = dL/dc * (1+2p) s (1-s),  s = (c + p)/(1+2p) ;  d raw_density = dL/dsigma * (1 - e^{-sigma})
+template <int K>
+__global__ void __launch_bounds__(256)
+k_volumetric_rendering_bwd(int64_t B, int N, const float4* __restrict__ rgb_sigma, const float* __restrict__ t,
+                           const float* __restrict__ dirs, int white_bkgd, const float* __restrict__ g_rgb,
+                           const float* __restrict__ g_dist, const float* __restrict__ g_acc,
+                           const float* __restrict__ g_w, float rgb_padding, float4* __restrict__ d_raw) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float dx = dirs[b * 3], dy = dirs[b * 3 + 1], dz = dirs[b * 3 + 2];
+    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float* tb = t + b * (int64_t)(N + 1);
+    const float4* cb = rgb_sigma + b * (int64_t)N;
+    const int i0 = lane * K;
+    const float gr = g_rgb ? g_rgb[b * 3] : 0.f, gg = g_rgb ? g_rgb[b * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[b * 3 + 2] : 0.f;
+    const float ga = g_acc ? g_acc[b] : 0.f;
+    const float bg = white_bkgd ? (gr + gg + gb) : 0.f;
+
+    float tv[K + 1];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) tv[k] = (i0 + k <= N) ? tb[i0 + k] : 0.0f;
+    float4 c[K];
+    float xx[K], delta[K];
+    double pre[K];
+    double run = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool ok = i0 + k < N;
+        c[k] = ok ? cb[i0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        delta[k] = (tv[k + 1] - tv[k]) * dn;
+        xx[k] = ok ? c[k].w * delta[k] : 0.0f;
+        pre[k] = run;
+        run += (double)xx[k];
+    }
+    const double off = wexcl_prefix64(run, lane);
+    // distance = clamp(nan_to_num(sum w tmid), t0, tN): gradient flows only strictly inside the clamp
+    float gd = 0.f;
+    float w[K], T1[K], G[K];
+    double sd = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool ok = i0 + k < N;
+        const float ex = expf(-xx[k]);
+        const float trans = expf(-(float)(off + pre[k]));
+        w[k] = ok ? (1.0f - ex) * trans : 0.0f;
+        T1[k] = trans * ex;                     // T_{i+1}
+        sd += (double)(w[k] * (0.5f * (tv[k] + tv[k + 1])));
+    }
+    if (g_dist) {
+        const float dsum = (float)wsum64(sd);
+        const float tn = tb[0], tf = tb[N];
+        gd = (dsum == dsum && dsum >= tn && dsum <= tf) ? g_dist[b] : 0.f;
+    }
+    double loc = 0.0;       // sum over this lane's samples of G_k w_k
+    double suf[K];          // suffix within the lane (exclusive)
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) {
+        const bool ok = i0 + k < N;
+        const float gw = (g_w && ok) ? g_w[b * (int64_t)N + i0 + k] : 0.f;
+        G[k] = gr * c[k].x + gg * c[k].y + gb * c[k].z - bg + ga + gd * (0.5f * (tv[k] + tv[k + 1])) + gw;
+        suf[k] = loc;
+        loc += (double)(G[k] * w[k]);
+    }
+    const double soff = wexcl_suffix64(loc, lane);
+    const float p = rgb_padding, sc = 1.0f + 2.0f * rgb_padding;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (i0 + k < N) {
+            const float dxk = G[k] * T1[k] - (float)(soff + suf[k]);
+            const float dsig = delta[k] * dxk;
+            const float s0 = (c[k].x + p) / sc, s1 = (c[k].y + p) / sc, s2 = (c[k].z + p) / sc;
+            float4 o;
+            o.x = w[k] * gr * sc * s0 * (1.0f - s0);
+            o.y = w[k] * gg * sc * s1 * (1.0f - s1);
+            o.z = w[k] * gb * sc * s2 * (1.0f - s2);
+            o.w = dsig * (1.0f - expf(-c[k].w));          // softplus'(x) = sigmoid(x) = 1 - e^{-softplus(x)}
+            d_raw[b * (int64_t)N + i0 + k] = o;
+        }
+    }
+}
+
+// distloss (models/mip.py:8-20) per ray, O(N): t is sorted, so |m_i - m_j| = m_max - m_min and
+//   sum_ij w_i w_j |m_i - m_j| = 2 sum_i w_i (m_i P_i - Q_i),  P_i = sum_{j<i} w_j,  Q_i = sum_{j<i} w_j m_j
+// ray_loss[b] = (1/3) sum_i interval_i w_i^2 + that double sum   (the reference then takes the batch mean)
+// If g_ray != nullptr also writes d_w[b,i] = g_ray[b] * ( (2/3) interval_i w_i + 2 sum_j w_j |m_i - m_j| ).
+template <int K>
+__global__ void __launch_bounds__(256)
+k_distloss(int64_t B, int N, const float* __restrict__ weights, const float* __restrict__ t,
+           float* __restrict__ ray_loss, const float* __restrict__ g_ray, float* __restrict__ d_w) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* tb = t + b * (int64_t)(N + 1);
+    const float* wb = weights + b * (int64_t)N;
+    const int i0 = lane * K;
+    float w[K], m[K], iv[K];
+    double pP[K], pQ[K];
+    double rP = 0.0, rQ = 0.0, uni = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const bool ok = i0 + k < N;
+        const float t0 = ok ? tb[i0 + k] : 0.f, t1 = ok ? tb[i0 + k + 1] : 0.f;
+        w[k] = ok ? wb[i0 + k] : 0.f;
+        m[k] = (t1 + t0) * 0.5f;
+        iv[k] = t1 - t0;
+        pP[k] = rP; pQ[k] = rQ;
+        rP += (double)w[k];
+        rQ += (double)w[k] * (double)m[k];
+        uni += (double)(iv[k] * w[k] * w[k]);
+    }
+    const double oP = wexcl_prefix64(rP, lane), oQ = wexcl_prefix64(rQ, lane);
+    const double totP = wsum64(rP), totQ = wsum64(rQ);
+    double bi = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) bi += (double)w[k] * ((double)m[k] * (oP + pP[k]) - (oQ + pQ[k]));
+    const double tot = wsum64(uni) / 3.0 + 2.0 * wsum64(bi);
+    if (lane == 0 && ray_loss) ray_loss[b] = (float)tot;
+    if (g_ray && d_w) {
+        const float g = g_ray[b];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (i0 + k < N) {
+                const double P = oP + pP[k], Q = oQ + pQ[k];
+                const double wi = w[k], mi = m[k];
+                // sum_j w_j |m_i - m_j| = m_i P - Q + (Qtot - Q - w_i m_i) - m_i (Ptot - P - w_i)
+                const double sj = mi * P - Q + (totQ - Q - wi * mi) - mi * (totP - P - wi);
+                d_w[b * (int64_t)N + i0 + k] = g * (float)((2.0 / 3.0) * iv[k] * wi + 2.0 * sj);
+            }
+        }
+    }
+}
+
+static inline unsigned gridf(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_activate, dim3(gridf(M, 256)), dim3(256), 0, st, M, (const float4*)raw, rgb_padding,
+                       density_bias, (float4*)out);
+    return hipGetLastError();
+}
+
+hipError_t launch_volumetric_rendering_bwd(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs,
+                                           int white_bkgd, const float* g_rgb, const float* g_dist, const float* g_acc,
+                                           const float* g_w, float rgb_padding, float* d_raw, hipStream_t st) {
+    const dim3 grid(gridf(B, 4)), block(256);
+    const int K = (N + 63) / 64;
+#define MIP_VB(KK)                                                                                                  \
+    hipLaunchKernelGGL((k_volumetric_rendering_bwd<KK>), grid, block, 0, st, B, N, (const float4*)rgb_sigma, t, dirs, \
+                       white_bkgd, g_rgb, g_dist, g_acc, g_w, rgb_padding, (float4*)d_raw)
+    switch (K) {
+        case 1: MIP_VB(1); break;
+        case 2: MIP_VB(2); break;
+        case 3: case 4: MIP_VB(4); break;
+        case 5: case 6: case 7: case 8: MIP_VB(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef MIP_VB
+    return hipGetLastError();
+}
+
+hipError_t launch_distloss(int64_t B, int N, const float* weights, const float* t, float* ray_loss, const float* g_ray,
+                           float* d_w, hipStream_t st) {
+    const dim3 grid(gridf(B, 4)), block(256);
+    const int K = (N + 63) / 64;
+#define MIP_DL(KK) hipLaunchKernelGGL((k_distloss<KK>), grid, block, 0, st, B, N, weights, t, ray_loss, g_ray, d_w)
+    switch (K) {
+        case 1: MIP_DL(1); break;
+        case 2: MIP_DL(2); break;
+        case 3: case 4: MIP_DL(4); break;
+        case 5: case 6: case 7: case 8: MIP_DL(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef MIP_DL
+    return hipGetLastError();
+}
+
+}  // namespace mip

@@ -1,0 +1,67 @@
+"""CPU, world_size 2 over gloo: the N>1 pieces of the hot path (gradient all-reduce in one flat buffer,
+ray sharding + gather for rendering).  No kernels run here."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mipnerf_pl_amd import Rays
+from mipnerf_pl_amd.parallel import FlatGradAllReduce, gather_rendered, shard_bounds, shard_rays
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(5)),
+                  torch.nn.Parameter(torch.zeros(2, 2))]
+        for i, p in enumerate(params[:2]):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))      # rank-dependent gradients
+        # params[2].grad stays None on purpose (an unused parameter)
+        FlatGradAllReduce(params)()
+        mean01 = (1 + 2) / 2.0
+        ok = all(torch.allclose(p.grad, torch.full_like(p, mean01 * (i + 1))) for i, p in enumerate(params[:2]))
+        ok = ok and torch.count_nonzero(params[2].grad) == 0
+        # rendering: shard 11 rays, "render" = 2*origin, gather
+        n = 11
+        rays = Rays(*[torch.arange(n * k, dtype=torch.float32).reshape(n, k) for k in (3, 3, 3, 1, 1, 1, 1)])
+        local = shard_rays(rays, rank, world)
+        lo, hi = shard_bounds(n, rank, world)
+        ok = ok and local.origins.shape[0] == hi - lo
+        full = gather_rendered(local.origins * 2, n)
+        ok = ok and torch.equal(full, rays.origins * 2)
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_and_ray_shards_world2():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("n,world", [(640000, 8), (10, 3), (7, 8), (4096, 4)])
+def test_shard_bounds_partition(n, world):
+    b = [shard_bounds(n, r, world) for r in range(world)]
+    assert b[0][0] == 0 and b[-1][1] == n
+    assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+    sizes = [hi - lo for lo, hi in b]
+    assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,46 @@
+"""CPU: host logic of the LightningModule mirror (no kernels): hyper-parameter contract, state_dict keys,
+LR schedule, render-chunk slicing."""
+import numpy as np
+import torch
+
+from mipnerf_pl_amd import Rays
+from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem, rearrange_render_image
+from oracle import mipnerf_oracle as orc
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    sys_ = MipNeRFSystem(DEFAULT_HPARAMS)
+    keys = list(sys_.state_dict().keys())
+    assert keys == ["mip_nerf.mlp." + k for k in orc.param_shapes()]      # SURVEY.md section 5 (checkpoint surface)
+    for k, shp in orc.param_shapes().items():
+        assert tuple(sys_.state_dict()["mip_nerf.mlp." + k].shape) == shp
+
+
+def test_lr_schedule_matches_reference_formula():
+    sys_ = MipNeRFSystem(DEFAULT_HPARAMS)
+    (opt,), (sch,) = sys_.configure_optimizers()
+    assert sch["interval"] == "step" and isinstance(opt, torch.optim.Adam)
+    s = sch["scheduler"]
+    hp = DEFAULT_HPARAMS
+    for step in (0, 1, 100, 2500, 5000, 500000, 1000000, 1200000):
+        s.last_epoch = step
+        delay = hp["optimizer.lr_delay_mult"] + (1 - hp["optimizer.lr_delay_mult"]) * np.sin(
+            0.5 * np.pi * np.clip(step / hp["optimizer.lr_delay_steps"], 0, 1))
+        t = np.clip(step / hp["optimizer.max_steps"], 0, 1)
+        want = delay * np.exp(np.log(hp["optimizer.lr_init"]) * (1 - t) + np.log(hp["optimizer.lr_final"]) * t)
+        assert abs(s.get_lr()[0] - want) <= 1e-12
+    s.last_epoch = 0
+    assert abs(s.get_lr()[0] - 5e-6) < 1e-12 and abs(MipNeRFSystem(DEFAULT_HPARAMS).configure_optimizers()[1][0][
+        "scheduler"].get_last_lr()[0] - 5e-6) < 1e-12
+
+
+def test_rearrange_render_image_chunks():
+    H, W = 10, 13          # 130 rays, chunk 32 -> 4 full + ragged 2
+    rays = Rays(*[torch.arange(H * W * k, dtype=torch.float32).reshape(1, H, W, k) for k in (3, 3, 3, 1, 1, 1, 1)])
+    chunks, val_mask = rearrange_render_image(rays, 32)
+    assert len(chunks) == 5 and [c.origins.shape[0] for c in chunks] == [32, 32, 32, 32, 2]
+    assert val_mask.shape == (1, H, W, 1) and torch.equal(val_mask, rays.lossmult)
+    assert torch.equal(torch.cat([c.directions for c in chunks]), rays.directions.reshape(-1, 3))
+    # BASELINE configs[4]: 800x800 frame in 8192-ray chunks -> 79 chunks, ragged tail 1024
+    n = 800 * 800
+    assert -(-n // 8192) == 79 and n % 8192 == 1024
