@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="inference", choices=["inference", "train"],
+                    help="inference (headline): MipNerf.forward; train: forward + loss + backward + grad all-reduce + Adam")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,9 +63,31 @@ def main():
     model = model.to(dev)
     R = Rays(*[torch.from_numpy(a).to(dev) for a in rays_np])
 
-    def step():
-        with torch.no_grad():
-            return model(R, False, True)
+    if args.mode == "train":
+        from mipnerf_pl_amd.parallel import FlatGradAllReduce
+        from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+        hp = dict(DEFAULT_HPARAMS)
+        hp.update({"nerf.num_samples": N})
+        system = MipNeRFSystem(hp, precision=args.precision)
+        system.mip_nerf.load_state_dict(model.state_dict())
+        system = system.to(dev)
+        model = system.mip_nerf
+        (opt,), (sch,) = system.configure_optimizers()
+        reduce_grads = FlatGradAllReduce(list(model.parameters()))
+        gt = torch.rand(B, 3, device=dev)
+
+        def step():
+            opt.zero_grad(set_to_none=False)
+            loss = system.training_step((R, gt), 0)      # randomized=True, nerf_system.py:95-121
+            loss.backward()
+            reduce_grads()                                # one flat all-reduce over RCCL (no-op at world 1)
+            opt.step()
+            sch["scheduler"].step()
+            return [(loss.detach().reshape(1),)]
+    else:
+        def step():
+            with torch.no_grad():
+                return model(R, False, True)
 
     def barrier():
         if world > 1:
@@ -73,7 +97,8 @@ def main():
     for _ in range(args.warmup):
         step()
     ctx = model.mlp.native(dev)
-    ctx.set_option(2, 1)          # HIP events around every MLP launch of the timed region (launch stream)
+    if args.mode == "inference":
+        ctx.set_option(2, 1)      # HIP events around every MLP launch of the timed region (launch stream)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -97,7 +122,7 @@ def main():
     tot_ms, nl = C.c_double(), C.c_int64()
     L.check(L.lib().mipnerf_mlp_launch_stats(ctx.handle, C.byref(tot_ms), C.byref(nl)), "mlp_launch_stats")
     ctx.set_option(2, 0)
-    if rank == 0:
+    if rank == 0 and nl.value > 0:
         prec = model.precision
         M = B * N
         launch_ms = tot_ms.value / max(1, nl.value)
@@ -113,7 +138,8 @@ def main():
                     "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
                     "traffic": traffic, "launch_ms": round(launch_ms, 4), "launches_timed": int(nl.value),
                     "samples_per_launch": M, "flop_per_sample": FLOP_PER_SAMPLE}
-        if world == 1 and not args.no_cpu_baseline:
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and args.mode == "inference":
             # bounded sample of the same workload: 256 rays x N x 2 levels through the numpy oracle
             nb = 256
             sub = orc.Rays(*[a[:nb] for a in rays_np])
@@ -135,8 +161,11 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) "
-                                   f"samples per GPU, 8x256 MLP, random-init trained-like weights",
+            "config": {"workload": (f"BASELINE.json configs[1]: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) "
+                                    f"samples per GPU, 8x256 MLP, random-init trained-like weights") if args.mode == "inference"
+                       else (f"training step (forward randomized + loss incl. distloss + backward + grad all-reduce + Adam), "
+                             f"{B} rays x ({N}+{N}) samples per GPU; MLP fwd/bwd through torch GEMMs (interim), rest native"),
+                       "mode": args.mode,
                        "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
                        "parallelism": f"ray-split x{world} (no data-path collective)"},
             "per_gpu": round(value / world, 1),
