@@ -164,7 +164,7 @@ def main():
             "config": {"workload": (f"BASELINE.json configs[1]: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) "
                                     f"samples per GPU, 8x256 MLP, random-init trained-like weights") if args.mode == "inference"
                        else (f"training step (forward randomized + loss incl. distloss + backward + grad all-reduce + Adam), "
-                             f"{B} rays x ({N}+{N}) samples per GPU; MLP fwd/bwd through torch GEMMs (interim), rest native"),
+                             f"{B} rays x ({N}+{N}) samples per GPU; MLP forward-with-save / dgrad / wgrad = native bf16 MFMA kernels"),
                        "mode": args.mode,
                        "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
                        "parallelism": f"ray-split x{world} (no data-path collective)"},

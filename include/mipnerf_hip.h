@@ -195,6 +195,21 @@ int mipnerf_distloss(int64_t num_rays, int32_t num_samples, const float* weights
                      const float* t_samples, float* ray_loss, const float* g_ray, float* d_w,
                      void* stream);
 
+/* ---- native MLP training step (bf16 MFMA kernels; what torch autograd does to mip_nerf.py:75-111) ----
+ * mipnerf_mlp_forward_train = mipnerf_mlp_forward (bf16) that also saves, per 32-sample wave tile, the
+ * transposed activations of every layer input (`act`) and the ReLU bit masks (`masks`).
+ * mipnerf_mlp_backward: d_raw [M,4] = dL/d(raw_rgb, raw_density) -> grad_flat [612,740] fp32, the gradients
+ * of the 24 parameter tensors concatenated in state_dict order (OVERWRITTEN, not accumulated).  `delta` and
+ * `partials` are scratch.  Buffer sizes for M samples come from mipnerf_mlp_train_sizes. */
+int mipnerf_mlp_train_sizes(const mipnerf_ctx* ctx, int64_t num_points, size_t* act_bytes,
+                            size_t* mask_bytes, size_t* delta_bytes, size_t* partial_bytes);
+int mipnerf_mlp_forward_train(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples,
+                              const void* enc, const void* viewenc, float* rgb_sigma, float* raw,
+                              void* act, void* masks, void* stream);
+int mipnerf_mlp_backward(mipnerf_ctx* ctx, int64_t num_points, const float* d_raw, const void* act,
+                         const void* masks, void* delta, float* partials, float* grad_flat,
+                         void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------ */
 /* Times `iters` launches of the bf16 MLP kernel with hipEvents on `stream`; returns the
  * average milliseconds per launch in *ms (used by bench.py for roofline.achieved). */
@@ -215,7 +230,8 @@ int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
 int mipnerf_mlp_launch_stats(mipnerf_ctx* ctx, double* total_ms, int64_t* launches);
 /* Host-only exports of the static plan tables (no GPU needed), used by the CPU tests to
  * prove the C++ plan expansion equals mipnerf_pl_amd/mlp_plan.py.  which: 0 = bf16 stream
- * pack table, 1 = bias table, 2 = fp32 stream pack table (flat parameter indices, -1 = 0).
+ * pack table, 1 = bias table, 2 = fp32 stream pack table (flat parameter indices, -1 = 0),
+ * 3 = dgrad (W^T) stream pack table, 4 = wgrad partial -> parameter index table, 5 = wgrad job table.
  * Return the element count; copy only when cap is large enough. */
 int64_t mipnerf_debug_table(int which, int32_t* out_host, int64_t cap);
 int64_t mipnerf_debug_f32net(int32_t* out_host, int64_t cap);

@@ -1,10 +1,11 @@
 """Training path of MipNerf.forward (gradients w.r.t. the 24 MLP parameter tensors).
 
-Native (HIP) in both directions: sampling, conical-frustum + IPE, view encoding, activations,
-volumetric rendering and its backward (fused with the activation derivatives), resampling, distloss.
-INTERIM (round 1): the MLP itself runs through torch's Linear ops (hipBLASLt GEMMs, bf16 or fp32 per
-`precision`) so that autograd supplies dgrad/wgrad; the register-resident MFMA kernel is used for every
-no-grad forward.  The native backward kernels (dgrad chain + wgrad split-K) are the next step.
+Native (HIP) in both directions: sampling, conical-frustum + IPE, view encoding, the MLP (bf16 mode:
+forward-with-save, dgrad and wgrad MFMA kernels, see mlp_train_plan.py), activations, volumetric rendering and
+its backward (fused with the activation derivatives), resampling, distloss.  torch.autograd only chains the
+native pieces (custom Functions) and owns the buffers.
+fp32 ("parity") mode: the MLP runs through torch's Linear ops in fp32 so that autograd supplies exact-fp32
+dgrad/wgrad for the gradient-parity tests against the reference; every other stage is the same native kernel.
 """
 from __future__ import annotations
 
@@ -73,6 +74,60 @@ class _DistLossRays(torch.autograd.Function):
         return d_w, None
 
 
+class _MLPNative(torch.autograd.Function):
+    """MLP.forward (models/mip_nerf.py:75-111) on the bf16 MFMA kernels, differentiable w.r.t. the parameters.
+    forward: k_mlp_bf16_trainfwd (saves transposed activations + ReLU bit masks); backward: k_mlp_bf16_dgrad ->
+    k_mlp_wgrad -> k_wgrad_reduce, one flat fp32 gradient buffer sliced into the 24 parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, mlp, enc, venc, *params):
+        dev = enc.device
+        nctx = mlp.native(dev)                    # re-packs the weight streams if a parameter changed
+        B, N = enc.shape[0], enc.shape[1]
+        M = B * N
+        if enc.dtype != torch.bfloat16 or venc.dtype != torch.bfloat16 or venc.shape[-1] != 32:
+            raise TypeError("native MLP training path: enc [B,N,96] and viewenc [B,32] must be bfloat16")
+        enc = enc.contiguous()
+        venc = venc.contiguous()
+        sz = nctx.train_sizes(M)
+        act = torch.empty(sz[0], dtype=torch.uint8, device=dev)
+        masks = torch.empty(sz[1], dtype=torch.uint8, device=dev)
+        raw = torch.empty(B, N, 4, device=dev, dtype=torch.float32)
+        rgb_sigma = torch.empty_like(raw)
+        L.check(L.lib().mipnerf_mlp_forward_train(nctx.handle, M, N, enc.data_ptr(), venc.data_ptr(), rgb_sigma.data_ptr(),
+                                                  raw.data_ptr(), act.data_ptr(), masks.data_ptr(), ops._stream()),
+                "mlp_forward_train")
+        ctx.save_for_backward(act, masks)
+        ctx.nctx, ctx.M, ctx.sizes = nctx, M, sz
+        ctx.shapes = [p.shape for p in params]
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        act, masks = ctx.saved_tensors
+        nctx = ctx.nctx
+        dev = act.device
+        d_raw = d_raw.contiguous().float()
+        delta = nctx.scratch("delta", ctx.sizes[2])
+        partials = nctx.scratch("partials", ctx.sizes[3])
+        total = sum(int(torch.Size(s).numel()) for s in ctx.shapes)
+        grad_flat = torch.empty(total, device=dev, dtype=torch.float32)
+        L.check(L.lib().mipnerf_mlp_backward(nctx.handle, ctx.M, d_raw.data_ptr(), act.data_ptr(), masks.data_ptr(),
+                                             delta.data_ptr(), partials.data_ptr(), grad_flat.data_ptr(), ops._stream()),
+                "mlp_backward")
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = int(torch.Size(shp).numel())
+            grads.append(grad_flat[off:off + n].view(shp))
+            off += n
+        return (None, None, None, *grads)
+
+
+def mlp_native(mlp, samples_enc, viewdirs_enc):
+    """Differentiable bf16 MLP: samples_enc [B,N,96] bf16, viewdirs_enc [B,32] bf16 -> raw [B,N,4] fp32."""
+    return _MLPNative.apply(mlp, samples_enc, viewdirs_enc, *mlp.ordered_params())
+
+
 def distloss(weight, samples):
     """Drop-in for models/mip.py:8-20: scalar distortion loss (t_samples must be sorted, as they always are)."""
     return _DistLossRays.apply(weight, samples).mean()
@@ -106,10 +161,15 @@ def mlp_torch(mlp, samples_enc, viewdirs_enc, dtype):
 def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_rand=None):
     """Differentiable MipNerf.forward (mip_nerf.py:172-248): list of (comp_rgb, distance, acc, weights, t_samples)."""
     dev = rays.origins.device
-    dtype = torch.bfloat16 if model.precision == L.PREC_BF16 else torch.float32
+    native = model.precision == L.PREC_BF16
+    dtype = torch.bfloat16 if native else torch.float32
     N = model.num_samples
+    model.mlp.native(dev)      # raises NotImplementedError for an MLP shape the kernels were not generated for
     with torch.no_grad():
-        venc = ops.pos_enc(rays.viewdirs, 0, model.deg_view, True)
+        if native:
+            venc = ops.pos_enc(rays.viewdirs, 0, model.deg_view, True, precision=L.PREC_BF16, ld=32)
+        else:
+            venc = ops.pos_enc(rays.viewdirs, 0, model.deg_view, True)
     ret = []
     t_samples, weights = None, None
     for lvl in range(model.num_levels):
@@ -120,7 +180,7 @@ def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_ra
                 t_samples = ops.resample_t(t_samples, weights.detach(), randomized, model.resample_padding, u_rand)
             enc = ops.cast_ipe(t_samples, rays.origins, rays.directions, rays.radii, model.min_deg_point,
                                model.max_deg_point, model.disable_integration, precision=model.precision)
-        raw = mlp_torch(model.mlp, enc, venc, dtype)
+        raw = mlp_native(model.mlp, enc, venc) if native else mlp_torch(model.mlp, enc, venc, dtype)
         comp_rgb, distance, acc, weights = render_from_raw(raw, t_samples, rays.directions, white_bkgd,
                                                            model.rgb_padding, model.density_bias)
         ret.append((comp_rgb, distance, acc, weights, t_samples))

@@ -12,6 +12,9 @@
 #include "kernels.hpp"
 #include "mlp_plan_gen.hpp"
 
+// binary tables of the training kernels (mlp_train_plan.TrainPlan.blob()), linked in through train_tables.c (.incbin)
+extern "C" const unsigned char mip_train_tables[];
+
 namespace {
 
 thread_local std::string g_err;
@@ -136,6 +139,10 @@ void build_tables(Tables& T) {
     }
 }
 
+int off_total(const Tables& T) {
+    return T.tensor_off.back() + mip::plan::kParamNumel[mip::plan::kNumParamTensors - 1];
+}
+
 // flat index -> (tensor << 20 | offset) as consumed by k_pack
 std::vector<int32_t> encode(const std::vector<int32_t>& flat, const std::vector<int>& toff) {
     std::vector<int32_t> out(flat.size());
@@ -149,6 +156,24 @@ std::vector<int32_t> encode(const std::vector<int32_t>& flat, const std::vector<
     return out;
 }
 
+// ---- training tables: binary blob produced by mlp_train_plan.TrainPlan.blob(), linked in by train_tables.c ------
+struct TrainTables {
+    int n_bchunks, njobs, NH, NG, NMASK, job_floats, nparams;
+    const int32_t* bpack;    // [n_bchunks * 512] flat parameter index or -1
+    const int32_t* jobs;     // [njobs * 20]
+    const int32_t* otab;     // [njobs * job_floats] flat parameter index or -1
+};
+
+bool train_tables(TrainTables& T) {
+    const int32_t* h = reinterpret_cast<const int32_t*>(mip_train_tables);
+    if (h[0] != 0x54524E31) return false;
+    T.n_bchunks = h[1]; T.njobs = h[2]; T.NH = h[3]; T.NG = h[4]; T.NMASK = h[5]; T.job_floats = h[6]; T.nparams = h[7];
+    T.bpack = h + 16;
+    T.jobs = T.bpack + h[8];
+    T.otab = T.jobs + h[9];
+    return h[9] == T.njobs * 20 && h[10] == T.njobs * T.job_floats && T.job_floats == mip::kWgradJobFloats;
+}
+
 }  // namespace
 
 struct mipnerf_ctx {
@@ -160,6 +185,15 @@ struct mipnerf_ctx {
     void* d_stream_bf16 = nullptr;   // kNumChunks * 1 KiB
     float* d_stream_f32 = nullptr;   // kNumChunks * 2 KiB
     float* d_bias = nullptr;         // kNumTiles * 32 floats
+    // training (bf16): W^T stream of the dgrad kernel, wgrad job tables
+    TrainTables tt;
+    int32_t* d_pack_dgrad = nullptr;
+    void* d_stream_dgrad = nullptr;
+    mip::WgradJob* d_jobs = nullptr;
+    int32_t* d_otab = nullptr;
+    int4* d_wgtab = nullptr;
+    int2* d_jobslots = nullptr;
+    int num_wgrad_wgs = 0;
     bool params_set = false;
     int mlp_dma = 1;                 // 1: global_load_lds ring, 0: register-staged ring (debug)
     int grid_limit = 256;            // persistent workgroups of the bf16 MLP kernel (= CUs)
@@ -231,6 +265,46 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
         c->grid_limit = cus;
+    // ---- training tables ----
+    if (!train_tables(c->tt) || c->tt.nparams != off_total(c->tab)) {
+        mipnerf_destroy(c);
+        return fail(MIPNERF_E_INVALID, "mipnerf_create: embedded training tables are inconsistent with the compiled plan");
+    }
+    {
+        const TrainTables& tt = c->tt;
+        const std::vector<int32_t> flat(tt.bpack, tt.bpack + (size_t)tt.n_bchunks * 512);
+        const std::vector<int32_t> e_dg = encode(flat, c->tab.tensor_off);
+        // workgroups per job ~ HBM bytes per wave tile (blocks loaded); every job gets at least one
+        std::vector<int> splits(tt.njobs);
+        double csum = 0;
+        for (int j = 0; j < tt.njobs; ++j) csum += tt.jobs[j * 20 + 0] + tt.jobs[j * 20 + 1];
+        std::vector<int4> wgtab;
+        std::vector<int2> slots(tt.njobs);
+        for (int j = 0; j < tt.njobs; ++j) {
+            int sp = (int)((tt.jobs[j * 20 + 0] + tt.jobs[j * 20 + 1]) / csum * c->grid_limit);
+            if (sp < 1) sp = 1;
+            slots[j] = make_int2((int)wgtab.size(), sp);
+            for (int k = 0; k < sp; ++k) wgtab.push_back(make_int4(j, k, sp, (int)wgtab.size()));
+        }
+        c->num_wgrad_wgs = (int)wgtab.size();
+        chk(hipMalloc(&c->d_pack_dgrad, e_dg.size() * 4));
+        chk(hipMalloc(&c->d_stream_dgrad, e_dg.size() * 2));
+        chk(hipMalloc(&c->d_jobs, (size_t)tt.njobs * sizeof(mip::WgradJob)));
+        chk(hipMalloc(&c->d_otab, (size_t)tt.njobs * tt.job_floats * 4));
+        chk(hipMalloc(&c->d_wgtab, wgtab.size() * sizeof(int4)));
+        chk(hipMalloc(&c->d_jobslots, slots.size() * sizeof(int2)));
+        if (er == hipSuccess) {
+            chk(hipMemcpy(c->d_pack_dgrad, e_dg.data(), e_dg.size() * 4, hipMemcpyHostToDevice));
+            chk(hipMemcpy(c->d_jobs, tt.jobs, (size_t)tt.njobs * sizeof(mip::WgradJob), hipMemcpyHostToDevice));
+            chk(hipMemcpy(c->d_otab, tt.otab, (size_t)tt.njobs * tt.job_floats * 4, hipMemcpyHostToDevice));
+            chk(hipMemcpy(c->d_wgtab, wgtab.data(), wgtab.size() * sizeof(int4), hipMemcpyHostToDevice));
+            chk(hipMemcpy(c->d_jobslots, slots.data(), slots.size() * sizeof(int2), hipMemcpyHostToDevice));
+        }
+        if (er != hipSuccess) {
+            mipnerf_destroy(c);
+            return fail(MIPNERF_E_HIP, "mipnerf_create (training tables): %s", hipGetErrorString(er));
+        }
+    }
     *out = c;
     return MIPNERF_OK;
 }
@@ -239,6 +313,8 @@ int mipnerf_destroy(mipnerf_ctx* c) {
     if (!c) return MIPNERF_OK;
     (void)hipFree(c->d_pack_bf16); (void)hipFree(c->d_pack_f32); (void)hipFree(c->d_bias_idx);
     (void)hipFree(c->d_stream_bf16); (void)hipFree(c->d_stream_f32); (void)hipFree(c->d_bias);
+    (void)hipFree(c->d_pack_dgrad); (void)hipFree(c->d_stream_dgrad); (void)hipFree(c->d_jobs); (void)hipFree(c->d_otab);
+    (void)hipFree(c->d_wgtab); (void)hipFree(c->d_jobslots);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
     return MIPNERF_OK;
@@ -267,6 +343,7 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
     HIP_TRY(mip::launch_pack(c->d_pack_bf16, nst, pp, c->d_stream_bf16, true, S(stream)));
     HIP_TRY(mip::launch_pack(c->d_pack_f32, nst, pp, c->d_stream_f32, false, S(stream)));
     HIP_TRY(mip::launch_pack(c->d_bias_idx, (int64_t)kNumTiles * 32, pp, c->d_bias, false, S(stream)));
+    HIP_TRY(mip::launch_pack(c->d_pack_dgrad, (int64_t)c->tt.n_bchunks * 512, pp, c->d_stream_dgrad, true, S(stream)));
     c->params_set = true;
     return MIPNERF_OK;
 }
@@ -378,6 +455,41 @@ int mipnerf_distloss(int64_t B, int32_t N, const float* weights, const float* t,
     return MIPNERF_OK;
 }
 
+// ---- native MLP training step (bf16) ------------------------------------------------------------------
+int mipnerf_mlp_train_sizes(const mipnerf_ctx* c, int64_t M, size_t* act_bytes, size_t* mask_bytes, size_t* delta_bytes,
+                            size_t* partial_bytes) {
+    if (!c || M < 1) return fail(MIPNERF_E_INVALID, "mlp_train_sizes: bad argument");
+    const size_t n_wt = (size_t)((M + 255) / 256) * 8;          // wave tiles (32 samples) of whole workgroup tiles
+    if (act_bytes) *act_bytes = n_wt * c->tt.NH * 2048;
+    if (mask_bytes) *mask_bytes = n_wt * c->tt.NMASK * 1024;
+    if (delta_bytes) *delta_bytes = n_wt * c->tt.NG * 2048;
+    if (partial_bytes) *partial_bytes = (size_t)c->num_wgrad_wgs * c->tt.job_floats * 4;
+    return MIPNERF_OK;
+}
+
+int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, float* rgb_sigma,
+                              float* raw, void* act, void* masks, void* stream) {
+    if (!c || M < 1 || N < 1 || !enc || !viewenc || !rgb_sigma || !raw || !act || !masks)
+        return fail(MIPNERF_E_INVALID, "mlp_forward_train: bad argument");
+    if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train: mipnerf_set_params has not been called");
+    HIP_TRY(mip::launch_mlp_bf16_trainfwd(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, act, masks, M, N,
+                                          c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_mlp_backward(mipnerf_ctx* c, int64_t M, const float* d_raw, const void* act, const void* masks, void* delta,
+                         float* partials, float* grad_flat, void* stream) {
+    if (!c || M < 1 || !d_raw || !act || !masks || !delta || !partials || !grad_flat)
+        return fail(MIPNERF_E_INVALID, "mlp_backward: bad argument");
+    if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_backward: mipnerf_set_params has not been called");
+    const int64_t n_wt = ((M + 255) / 256) * 8;
+    HIP_TRY(mip::launch_mlp_bf16_dgrad(c->d_stream_dgrad, d_raw, masks, delta, M, c->grid_limit, S(stream)));
+    HIP_TRY(mip::launch_mlp_wgrad(act, delta, c->d_jobs, c->d_wgtab, c->num_wgrad_wgs, n_wt, c->tt.NH, c->tt.NG, partials,
+                                  S(stream)));
+    HIP_TRY(mip::launch_wgrad_reduce(partials, c->d_otab, c->d_jobslots, c->tt.njobs, grad_flat, S(stream)));
+    return MIPNERF_OK;
+}
+
 // ---- the level loop ---------------------------------------------------------------------------------
 size_t mipnerf_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
     if (!c || B < 1) return 0;
@@ -485,6 +597,14 @@ int mipnerf_selftest(void* stream) {
 // Host-only debug export of the plan tables (flat parameter indices), used by the CPU tests to prove the
 // C++ expansion equals mlp_plan.py.  which: 0 bf16 pack, 1 bias, 2 fp32 pack.  Returns element count.
 int64_t mipnerf_debug_table(int which, int32_t* out_host, int64_t cap) {
+    if (which >= 3 && which <= 5) {
+        TrainTables tt;
+        if (!train_tables(tt)) return -1;
+        const int32_t* src = which == 3 ? tt.bpack : (which == 4 ? tt.otab : tt.jobs);
+        const int64_t n = which == 3 ? (int64_t)tt.n_bchunks * 512 : (which == 4 ? (int64_t)tt.njobs * tt.job_floats : tt.njobs * 20);
+        if (out_host && cap >= n) memcpy(out_host, src, (size_t)n * 4);
+        return n;
+    }
     Tables T;
     build_tables(T);
     const std::vector<int32_t>& v = which == 0 ? T.pack_bf16 : (which == 1 ? T.bias : T.pack_f32);

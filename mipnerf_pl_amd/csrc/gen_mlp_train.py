@@ -1,0 +1,579 @@
+#!/usr/bin/env python3
+"""Generate the bf16 TRAINING kernels of the Mip-NeRF MLP from mlp_train_plan.TrainPlan:
+
+  mlp_bf16_trainfwd_gen.hip  k_mlp_bf16_trainfwd: the inference schedule (gen_mlp_bf16.py) + per output tile the
+                             ReLU bit mask and the transposed activations (T-blocks) the weight-gradient kernel
+                             consumes (see mlp_train_plan.py);
+  mlp_bf16_dgrad_gen.hip     k_mlp_bf16_dgrad: delta_j = (W_{j+1}^T delta_{j+1}) * relu' with delta resident in
+                             registers across all layers, W^T streamed through the same LDS ring, T-blocks of
+                             every delta written for the weight-gradient kernel.
+
+Both are straight-line code per 32-sample wave tile with compile-time ring offsets, exactly like the
+inference kernel; the extra work of a tile (mask, two selection MFMAs, bf16 packing, 2 x 1 KiB stores) is
+spread over the MFMA slots of the following panel.
+
+Usage: python gen_mlp_train.py [outdir]
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+from mipnerf_pl_amd.mlp_plan import Plan  # noqa: E402
+from mipnerf_pl_amd.mlp_train_plan import GROUP, SLOTS, TrainPlan  # noqa: E402
+from gen_mlp_bf16 import KERNEL_PREAMBLE  # noqa: E402
+
+WAVES = 8
+CHUNK_BYTES = 1024
+PREFETCH = int(os.environ.get("MLP_TRAIN_PREFETCH", "4"))
+NE = 3
+
+TRAIN_PREAMBLE = r"""
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define TMFMA0(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), f32x16{0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, 0, 0, 0)
+#define LDM(off) (*reinterpret_cast<const u32x4*>(priv_lane + (off)))
+
+// Half of a T-block store: accumulator registers R0..R0+7 of a selection-MFMA result are 8 samples of one
+// feature column (exact bf16 values); 64 lanes x 16 B = one lane-linear 1-KiB operand fragment.
+template <int R0>
+__device__ __forceinline__ void store_tfrag(const f32x16& acc, char* blk, unsigned lane16) {
+    bf16x8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = (__bf16)acc[R0 + r];
+    *reinterpret_cast<bf16x8*>(blk + (R0 / 8) * 1024 + lane16) = o;
+}
+
+// 16 ReLU bits of one output tile from its two (post-ReLU, bf16) k-step registers: bit p = reg 2p > 0,
+// bit 16+p = reg 2p+1 > 0 (mlp_train_plan.pack_mask).
+__device__ __forceinline__ unsigned pk_nonzero(unsigned x, unsigned one2) {
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "s"(one2));
+    return r;
+}
+__device__ __forceinline__ unsigned tile_mask(const bf16x8& a, const bf16x8& b) {
+    const u32x4 da = __builtin_bit_cast(u32x4, a), db = __builtin_bit_cast(u32x4, b);
+    unsigned m = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) m |= pk_nonzero(da[p], 0x00010001u) << p;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) m |= pk_nonzero(db[p], 0x00010001u) << (4 + p);
+    return m;
+}
+
+// dgrad epilogue of half a tile: fp32 -> bf16 (RNE), then AND with the expanded ReLU bits.
+// `mw` = mask dword of the tile pair, SH = 8 * (tile & 1); pair p of the tile sits at bits (p, 16 + p) + SH.
+template <bool MASK, int R0, int SH>
+__device__ __forceinline__ void depilogue_half(const f32x16& acc, unsigned mw, bf16x8& o) {
+    bf16x8 v;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = (__bf16)acc[R0 + r];
+    if (MASK) {
+        u32x4 d = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned fl = (mw >> (SH + R0 / 2 + p)) & 0x00010001u;
+            d[p] &= fl * 0xFFFFu;
+        }
+        v = __builtin_bit_cast(bf16x8, d);
+    }
+    o = v;
+}
+
+// one 1-KiB lane-linear DMA (global -> wave-private LDS), per-lane 64-bit source address
+__device__ __forceinline__ void dma_1k(const void* src_lane, char* lds_dst) {
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src_lane), "s"(lds_addr)
+        : "memory");
+}
+"""
+
+
+class Prog:
+    """A straight-line tile program: slots (one MFMA each), per-slot side statements, panels."""
+
+    def __init__(self):
+        self.slots = []       # dict(acc, b, panel, ks, first_of_ks, zero)
+        self.panels = []      # dict(first, n, pair, spk, post (list of stmts run during the next panel), pre)
+
+
+def place_sides(prog, nchunks):
+    """Spread each panel's `post` statements (and the next-next panel's `pre`) over the next panel's slots."""
+    side = {c: [] for c in range(nchunks)}
+    for pi, pn in enumerate(prog.panels):
+        work = []
+        if pi > 0:
+            work += prog.panels[pi - 1]["post"]
+        if pi + 1 < len(prog.panels):
+            work += prog.panels[pi + 1]["pre"]
+        n = pn["n"]
+        for wi, stmt in enumerate(work):
+            at = min(2 + wi, n - 1)
+            side[pn["first"] + at].append(stmt)
+    return side
+
+
+def emit_tile_body(e, prog, side, nchunks_total, prologue_lines, final_lines, lda):
+    """MFMA slots with A prefetch PREFETCH chunks ahead and ring-group boundaries where the load cursor
+    enters a new group.  nchunks_total >= len(slots): trailing (padding) groups are still cycled through so
+    that the ring phase is tile-invariant."""
+    nslots = len(prog.slots)
+    e("        GROUP_BEGIN(0, 1);")
+    for c in range(min(PREFETCH, nslots)):
+        e(f"        {lda(c)}")
+    for ln in prologue_lines:
+        e(f"        {ln}")
+    e("        PIN();")
+    cur_op = None
+    for c, sl in enumerate(prog.slots):
+        if sl.get("opname") != cur_op:
+            cur_op = sl.get("opname")
+            e(f"        // ---- {cur_op}")
+        if sl["zero"]:
+            e(f"        TMFMA0({sl['acc']}, A{c % PREFETCH}, {sl['bexpr']});")
+        else:
+            e(f"        MFMA({sl['acc']}, A{c % PREFETCH}, {sl['bexpr']});")
+        lc = c + PREFETCH
+        if lc < nslots:
+            if lc % GROUP == 0:
+                g = lc // GROUP
+                e(f"        GROUP_BEGIN({g}, {(g + 1) % SLOTS});")
+            e(f"        {lda(lc)}")
+        for stmt in side[c]:
+            e(f"        {stmt}")
+        e("        PIN();")
+    # groups the load cursor never entered (stream padding): keep the ring protocol going
+    first_unentered = (nslots - 1) // GROUP + 1
+    for g in range(first_unentered, nchunks_total // GROUP):
+        e(f"        GROUP_BEGIN({g}, {(g + 1) % SLOTS});")
+    for ln in final_lines:
+        e(f"        {ln}")
+
+
+def check_hazards(prog, side, prologue=()):
+    """Register-set discipline: op i reads the activation registers written by op i-1.  Epilogue statements
+    carry an `/*opN*/` tag; replay the tile in program order and assert that every B operand X[k] / Y[k] read by a
+    slot of op i was last written by op i-1, and every register read by a transposing MFMA / tile_mask was
+    written by the op that issues the statement."""
+    import re
+    last = {}
+    wr = re.compile(r"epilogue_half<[^>]*>\(\w+, (?:[\w\[\]]+, )?([XY]\[\d+\])\);\s*/\*op(\d+)\*/")
+    rd = re.compile(r"(?:TMFMA0|MFMA)\(\w+, ([XY]\[\d+\]), P[12]\);\s*/\*op(\d+)\*/")
+    opidx = {}
+    for sl in prog.slots:
+        opidx.setdefault(sl["opname"], len(opidx))
+
+    def run(stmts):
+        for st in stmts:
+            m = wr.search(st)
+            if m:
+                last[m.group(1)] = int(m.group(2))
+            m = rd.search(st)
+            if m:
+                assert last.get(m.group(1)) == int(m.group(2)), ("transpose reads a stale register", st, last.get(m.group(1)))
+    run(prologue)
+    for c, sl in enumerate(prog.slots):
+        b = sl["bexpr"]
+        if b[0] in "XY":
+            assert last.get(b) == opidx[sl["opname"]] - 1, ("slot reads a register not produced by the previous op",
+                                                           c, sl["opname"], b, last.get(b))
+        run(side[c])
+    return True
+
+
+# =================================================================================================================
+#  forward-with-save
+# =================================================================================================================
+def build_fwd_prog(tp: TrainPlan):
+    plan = tp.fwd
+    a = plan.arch
+    prog = Prog()
+    for oi, op in enumerate(plan.ops):
+        hb, ml = tp.fwd_out[oi]
+        relu = "true" if op.relu else "false"
+        for (t0, t1) in plan.panels(op):
+            pair = len(prog.panels) & 1
+            first = len(prog.slots)
+            spk = 1 if t1 is None else 2
+            for ks in range(op.nk):
+                seg, ksl = plan.seg_of(op, ks)
+                if seg.regset in ("X", "Y"):
+                    b = ("reg", f"{seg.regset}[{seg.reg0 + ksl}]")
+                elif seg.regset == "enc":
+                    b = ("lds", ksl * 1024)
+                else:
+                    b = ("lds", (a.xyz_dim // 16) * 1024 + ksl * 1024)
+                for w in range(spk):
+                    prog.slots.append(dict(acc=f"acc{pair}{w}", b=b, panel=len(prog.panels), ks=ks,
+                                           first_of_ks=(w == 0), zero=False, opname=op.name))
+            post, post_t, post_late = [], [], []
+            for which, t in ((0, t0), (1, t1)):
+                if t is None:
+                    continue
+                acc = f"acc{pair}{which}"
+                if op.out in ("X", "Y"):
+                    if op.name == "head" and t == len(op.tiles) - 1:
+                        post.append(f"raw_density = {acc}[0];")
+                        continue
+                    post.append(f"epilogue_half<{relu}, 0>({acc}, {op.out}[{2 * t}]);  /*op{oi}*/")
+                    post.append(f"epilogue_half<{relu}, 8>({acc}, {op.out}[{2 * t + 1}]);  /*op{oi}*/")
+                    if hb is not None:
+                        post_t.append(f"TMFMA0({acc}, {op.out}[{2 * t}], P1);  /*op{oi}*/")
+                        post_t.append(f"MFMA({acc}, {op.out}[{2 * t + 1}], P2);  /*op{oi}*/")
+                        post_late.append(f"store_tfrag<0>({acc}, ht_wave + {(hb + t) * 2048}, lane16);")
+                        post_late.append(f"store_tfrag<8>({acc}, ht_wave + {(hb + t) * 2048}, lane16);")
+                    if ml is not None:
+                        if t % 2 == 0:
+                            post_late.append(f"mq{t // 2} = tile_mask({op.out}[{2 * t}], {op.out}[{2 * t + 1}]);")
+                        else:
+                            post_late.append(f"mq{t // 2} |= tile_mask({op.out}[{2 * t}], {op.out}[{2 * t + 1}]) << 8;")
+                        last_tile = len(op.tiles) - 1
+                        if t == last_tile:
+                            nq = (last_tile + 2) // 2
+                            vals = ", ".join(f"mq{q}" if q < nq else "0u" for q in range(4))
+                            post_late.append(f"*reinterpret_cast<u32x4*>(mask_wave + {ml * 1024} + lane16) = u32x4{{{vals}}};")
+                else:
+                    post.append(f"raw_r = {acc}[0]; raw_g = {acc}[1]; raw_b = {acc}[2];")
+            pre = [f"BIAS(acc{pair}0, {op.first_tile + t0});"]
+            if t1 is not None:
+                pre.append(f"BIAS(acc{pair}1, {op.first_tile + t1});")
+            prog.panels.append(dict(first=first, n=len(prog.slots) - first, pair=pair, spk=spk,
+                                    post=post + post_t + post_late, pre=pre))
+    return prog
+
+
+def assign_lds_b(prog, nchunks):
+    """E-register rotation for LDS-resident B operands (as gen_mlp_bf16.py)."""
+    side_extra = {c: [] for c in range(nchunks)}
+    prologue = []
+    ecount = 0
+    cur_e = None
+    for c, sl in enumerate(prog.slots):
+        kind, val = sl["b"]
+        if kind == "reg":
+            sl["bexpr"] = val
+            continue
+        if sl["first_of_ks"]:
+            cur_e = f"E{ecount % NE}"
+            ecount += 1
+            spk = prog.panels[sl["panel"]]["spk"]
+            at = c - 2 * spk
+            stmt = f"{cur_e} = LDB({val});"
+            if at < 0:
+                prologue.append(stmt)
+            else:
+                side_extra[at].append(stmt)
+        sl["bexpr"] = cur_e
+    return side_extra, prologue
+
+
+def file_header(e, ns, consts):
+    e("// AUTO-GENERATED by gen_mlp_train.py from mlp_train_plan.py -- do not edit by hand.")
+    e("#include <hip/hip_runtime.h>")
+    e('#include "kernels.hpp"')
+    e('#include "raymath.hpp"')
+    e(f"namespace mip {{ namespace {ns} {{")
+    e("typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;")
+    e("typedef __attribute__((ext_vector_type(16))) float f32x16;")
+    for k, v in consts.items():
+        e(f"constexpr int {k} = {v};")
+    e(KERNEL_PREAMBLE.replace("BARRIER_INSN", "s_barrier"))
+    e(TRAIN_PREAMBLE)
+    e("constexpr bool DMA = true;")
+
+
+SELECTORS = [
+    "bf16x8 P1, P2;   // selection matrices of the transposing MFMAs: P1[k][n] = (n == k), P2[k][n] = (n == 16 + k)",
+    "#pragma unroll",
+    "for (int j = 0; j < 8; ++j) {",
+    "    P1[j] = (__bf16)((n == hi * 8 + j) ? 1.0f : 0.0f);",
+    "    P2[j] = (__bf16)((n == 16 + hi * 8 + j) ? 1.0f : 0.0f);",
+    "}",
+]
+
+
+def gen_trainfwd(tp: TrainPlan) -> str:
+    plan = tp.fwd
+    a = plan.arch
+    nchunks = len(plan.chunks)
+    assert nchunks % GROUP == 0 and (nchunks // GROUP) % SLOTS == 0
+    nenc = a.xyz_dim // 16
+    enc_wave_bytes = 8192
+    assert (nenc + 2) * 1024 <= enc_wave_bytes
+    nbias_bytes = plan.n_tiles * 128
+    ring_bytes = SLOTS * GROUP * CHUNK_BYTES
+    enc_off = (ring_bytes + nbias_bytes + 1023) // 1024 * 1024
+    lds_bytes = enc_off + WAVES * enc_wave_bytes
+    assert lds_bytes <= 160 * 1024
+    prog = build_fwd_prog(tp)
+    assert len(prog.slots) == nchunks
+    side_e, prologue_e = assign_lds_b(prog, nchunks)
+    side = place_sides(prog, nchunks)
+    for c in range(nchunks):
+        side[c] = side_e[c] + side[c]
+    check_hazards(prog, side)
+    lines = []
+    e = lines.append
+    file_header(e, "trainfwd", dict(kRingBytes=ring_bytes, kBiasBytes=nbias_bytes, kEncOff=enc_off,
+                                    kEncWaveBytes=enc_wave_bytes, kLdsBytes=lds_bytes,
+                                    kGroupBytes=GROUP * CHUNK_BYTES, kNumGroups=nchunks // GROUP,
+                                    kTileSamples=WAVES * 32, kNH=tp.NH, kNMask=tp.NMASK))
+    e(f"__global__ void __launch_bounds__({WAVES * 64})")
+    e("k_mlp_bf16_trainfwd(const char* __restrict__ stream, const float* __restrict__ bias_tab,")
+    e("                    const __bf16* __restrict__ enc, const __bf16* __restrict__ viewenc, float4* __restrict__ rgb_sigma,")
+    e("                    float4* __restrict__ raw_out, char* __restrict__ HT, char* __restrict__ masks, int64_t M,")
+    e("                    int num_samples, int ntiles, float density_bias, float rgb_padding) {")
+    e("    extern __shared__ __attribute__((aligned(16))) char smem[];")
+    e("    const int tid = threadIdx.x;")
+    e("    const int lane = tid & 63;")
+    e("    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);")
+    e("    const int hi = lane >> 5, n = lane & 31;")
+    e("    const unsigned lane16 = (unsigned)lane * 16u;")
+    e("    const char* ring_lane = smem + lane16;")
+    e("    const char* bias_lane = smem + kRingBytes + hi * 64;")
+    e("    char* encw = smem + kEncOff + wave * kEncWaveBytes;")
+    e("    const char* enc_lane = encw + lane16;")
+    for ln in SELECTORS:
+        e("    " + ln)
+    e("    for (int i = tid; i < kBiasBytes / 16; i += blockDim.x)")
+    e("        reinterpret_cast<float4*>(smem + kRingBytes)[i] = reinterpret_cast<const float4*>(bias_tab)[i];")
+    e("    __syncthreads();")
+    e("    if ((int)blockIdx.x < ntiles) issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
+    e("    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {")
+    e("        const bool has_next = tile + (int)gridDim.x < ntiles;")
+    e("        const int64_t wt = (int64_t)tile * 8 + wave;                 // wave tile (uniform)")
+    e("        const int64_t s = wt * 32 + n;")
+    e("        const int64_t sc = s < M ? s : M - 1;")
+    e("        const int64_t ray = sc / num_samples;")
+    e("        char* ht_wave = HT + wt * (int64_t)(kNH * 2048);")
+    e("        char* mask_wave = masks + wt * (int64_t)(kNMask * 1024);")
+    e(f"        issue_encodings<DMA, {nenc}>(enc + sc * {a.xyz_dim} + hi * 8, viewenc + ray * 32 + hi * 8, encw, lane16);")
+    e("        bf16x8 X[16], Y[16], " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ", E0, E1, E2;")
+    e("        f32x16 acc00, acc01, acc10, acc11;")
+    e("        unsigned mq0 = 0, mq1 = 0, mq2 = 0, mq3 = 0;")
+    e("        float raw_density = 0.0f, raw_r = 0.0f, raw_g = 0.0f, raw_b = 0.0f;")
+
+    def lda(c):
+        slot = (c // GROUP) % SLOTS
+        off = slot * GROUP * CHUNK_BYTES + (c % GROUP) * CHUNK_BYTES
+        return f"A{c % PREFETCH} = LDA({off});"
+    # tile prologue: transposed encodings (inputs of layer 0 / the skip layer / the view layer for wgrad)
+    pro = []
+    e0 = tp.h_blocks["enc"][0]
+    accs = ["acc10", "acc11"]
+    k = 0
+    for b in range(nenc // 2):
+        acc = accs[k % 2]
+        k += 1
+        pro.append(f"E0 = LDB({2 * b * 1024}); E1 = LDB({(2 * b + 1) * 1024});")
+        pro.append(f"TMFMA0({acc}, E0, P1); MFMA({acc}, E1, P2);")
+        pro.append(f"store_tfrag<0>({acc}, ht_wave + {(e0 + b) * 2048}, lane16); store_tfrag<8>({acc}, ht_wave + {(e0 + b) * 2048}, lane16);")
+    acc = accs[k % 2]
+    vb = tp.h_blocks["view"][0]
+    pro.append(f"E0 = LDB({nenc * 1024}); E1 = LDB({(nenc + 1) * 1024});")
+    pro.append(f"TMFMA0({acc}, E0, P1); MFMA({acc}, E1, P2);")
+    pro.append(f"store_tfrag<0>({acc}, ht_wave + {vb * 2048}, lane16); store_tfrag<8>({acc}, ht_wave + {vb * 2048}, lane16);")
+    pro += prologue_e
+    pro += prog.panels[0]["pre"]
+    final = list(prog.panels[-1]["post"])
+    final += [
+        "if (hi == 0 && s < M) {",
+        "    rgb_sigma[s] = make_float4(rgb_activation(raw_r, rgb_padding), rgb_activation(raw_g, rgb_padding),",
+        "                               rgb_activation(raw_b, rgb_padding), density_activation(raw_density, density_bias));",
+        "    raw_out[s] = make_float4(raw_r, raw_g, raw_b, raw_density);",
+        "}",
+    ]
+    emit_tile_body(e, prog, side, nchunks, pro, final, lda)
+    e("    }")
+    e("}")
+    e("}  // namespace trainfwd")
+    e("")
+    e("int mlp_trainfwd_lds_bytes() { return trainfwd::kLdsBytes; }")
+    e("hipError_t launch_mlp_bf16_trainfwd(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,")
+    e("                                    float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,")
+    e("                                    float density_bias, float rgb_padding, int grid_limit, hipStream_t st) {")
+    e("    using namespace trainfwd;")
+    e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
+    e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
+    e("    if (grid < 1) grid = 1;")
+    e("    static bool attr_done = false;")
+    e("    if (!attr_done) {")
+    e("        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_bf16_trainfwd, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
+    e("        if (er != hipSuccess) return er;")
+    e("        attr_done = true;")
+    e("    }")
+    e(f"    hipLaunchKernelGGL(k_mlp_bf16_trainfwd, dim3(grid), dim3({WAVES * 64}), kLdsBytes, st, (const char*)stream_w, bias_tab,")
+    e("                       (const __bf16*)enc, (const __bf16*)viewenc, (float4*)rgb_sigma, (float4*)raw_out, (char*)HT,")
+    e("                       (char*)masks, M, num_samples, ntiles, density_bias, rgb_padding);")
+    e("    return hipGetLastError();")
+    e("}")
+    e("}  // namespace mip")
+    return "\n".join(lines) + "\n"
+
+
+# =================================================================================================================
+#  dgrad
+# =================================================================================================================
+def build_dgrad_prog(tp: TrainPlan):
+    prog = Prog()
+    mk_toggle = 0
+    mk_of_op = {}
+    for oi, op in enumerate(tp.bops):
+        if op.mask is not None:
+            mk_of_op[oi] = f"MK{mk_toggle}"
+            mk_toggle ^= 1
+    for oi, op in enumerate(tp.bops):
+        first_panel_of_op = True
+        for t0 in range(0, op.ntiles, 2):
+            t1 = t0 + 1 if t0 + 1 < op.ntiles else None
+            pair = len(prog.panels) & 1
+            first = len(prog.slots)
+            spk = 1 if t1 is None else 2
+            for ks in range(op.nk):
+                seg, ksl = tp.bseg_of(op, ks)
+                bexpr = "R" if seg.regset == "raw" else f"{seg.regset}[{seg.reg0 + ksl}]"
+                for w in range(spk):
+                    prog.slots.append(dict(acc=f"acc{pair}{w}", bexpr=bexpr, panel=len(prog.panels), ks=ks,
+                                           first_of_ks=(w == 0), zero=(ks == 0), opname=op.name))
+            post, post_t, post_late = [], [], []
+            for which, t in ((0, t0), (1, t1)):
+                if t is None:
+                    continue
+                acc = f"acc{pair}{which}"
+                if op.mask is not None:
+                    mk = f"{mk_of_op[oi]}[{t // 2}]"
+                    sh = 8 * (t & 1)
+                    post.append(f"depilogue_half<true, 0, {sh}>({acc}, {mk}, {op.out}[{2 * t}]);  /*op{oi}*/")
+                    post.append(f"depilogue_half<true, 8, {sh}>({acc}, {mk}, {op.out}[{2 * t + 1}]);  /*op{oi}*/")
+                else:
+                    post.append(f"depilogue_half<false, 0, 0>({acc}, 0u, {op.out}[{2 * t}]);  /*op{oi}*/")
+                    post.append(f"depilogue_half<false, 8, 0>({acc}, 0u, {op.out}[{2 * t + 1}]);  /*op{oi}*/")
+                post_t.append(f"TMFMA0({acc}, {op.out}[{2 * t}], P1);  /*op{oi}*/")
+                post_t.append(f"MFMA({acc}, {op.out}[{2 * t + 1}], P2);  /*op{oi}*/")
+                post_late.append(f"store_tfrag<0>({acc}, gt_wave + {(op.gblock + t) * 2048}, lane16);")
+                post_late.append(f"store_tfrag<8>({acc}, gt_wave + {(op.gblock + t) * 2048}, lane16);")
+            pre = []
+            if first_panel_of_op and op.mask is not None:
+                # the mask dwords of this op, read from the wave-private LDS copy while the previous op finishes
+                pre.append(f"{mk_of_op[oi]} = LDM({op.mask * 1024});")
+            first_panel_of_op = False
+            prog.panels.append(dict(first=first, n=len(prog.slots) - first, pair=pair, spk=spk,
+                                    post=post + post_t + post_late, pre=pre))
+    return prog
+
+
+def gen_dgrad(tp: TrainPlan) -> str:
+    nchunks = len(tp.bchunks)
+    nreal = tp.n_bchunks_real
+    assert nchunks % GROUP == 0 and (nchunks // GROUP) % SLOTS == 0
+    ring_bytes = SLOTS * GROUP * CHUNK_BYTES
+    priv_wave_bytes = (tp.NMASK + 1) * 1024          # mask rows + the d_raw row
+    priv_off = ring_bytes
+    lds_bytes = priv_off + WAVES * priv_wave_bytes
+    assert lds_bytes <= 160 * 1024
+    prog = build_dgrad_prog(tp)
+    assert len(prog.slots) == nreal
+    side = place_sides(prog, nreal)
+    check_hazards(prog, side)
+    lines = []
+    e = lines.append
+    file_header(e, "dgrad", dict(kRingBytes=ring_bytes, kPrivOff=priv_off, kPrivWaveBytes=priv_wave_bytes,
+                                 kLdsBytes=lds_bytes, kGroupBytes=GROUP * CHUNK_BYTES, kNumGroups=nchunks // GROUP,
+                                 kTileSamples=WAVES * 32, kNG=tp.NG, kNMask=tp.NMASK))
+    e(f"__global__ void __launch_bounds__({WAVES * 64})")
+    e("k_mlp_bf16_dgrad(const char* __restrict__ stream, const float4* __restrict__ d_raw, const char* __restrict__ masks,")
+    e("                 char* __restrict__ GT, int64_t M, int ntiles) {")
+    e("    extern __shared__ __attribute__((aligned(16))) char smem[];")
+    e("    const int tid = threadIdx.x;")
+    e("    const int lane = tid & 63;")
+    e("    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);")
+    e("    const int hi = lane >> 5, n = lane & 31;")
+    e("    const unsigned lane16 = (unsigned)lane * 16u;")
+    e("    const char* ring_lane = smem + lane16;")
+    e("    char* privw = smem + kPrivOff + wave * kPrivWaveBytes;          // wave-private (uniform base)")
+    e("    const char* priv_lane = privw + lane16;")
+    for ln in SELECTORS:
+        e("    " + ln)
+    e("    if ((int)blockIdx.x < ntiles) issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
+    e("    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {")
+    e("        const bool has_next = tile + (int)gridDim.x < ntiles;")
+    e("        const int64_t wt = (int64_t)tile * 8 + wave;")
+    e("        const int64_t s = wt * 32 + n;")
+    e("        const int64_t sc = s < M ? s : M - 1;")
+    e("        char* gt_wave = GT + wt * (int64_t)(kNG * 2048);")
+    e("        const char* mask_lane = masks + wt * (int64_t)(kNMask * 1024) + lane16;")
+    e("        // stage this wave's ReLU masks (kNMask rows) and upstream gradients into its private LDS area")
+    e("#pragma unroll")
+    e("        for (int l = 0; l < kNMask; ++l) dma_1k(mask_lane + l * 1024, privw + l * 1024);")
+    e("        dma_1k(d_raw + sc, privw + kNMask * 1024);")
+    e("        bf16x8 X[16], Y[16], R, " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ";")
+    e("        f32x16 acc00, acc01, acc10, acc11;")
+    e("        u32x4 MK0, MK1;")
+
+    def lda(c):
+        slot = (c // GROUP) % SLOTS
+        off = slot * GROUP * CHUNK_BYTES + (c % GROUP) * CHUNK_BYTES
+        return f"A{c % PREFETCH} = LDA({off});"
+    rb = tp.g_blocks["raw"][0]
+    pro = [
+        "{",
+        "    const float4 dr = *reinterpret_cast<const float4*>(priv_lane + kNMask * 1024);",
+        "    const bool live = hi == 0 && s < M;          // B operand: k = hi*8 + j, only k < 4 carries data",
+        "    R[0] = (__bf16)(live ? dr.x : 0.0f); R[1] = (__bf16)(live ? dr.y : 0.0f);",
+        "    R[2] = (__bf16)(live ? dr.z : 0.0f); R[3] = (__bf16)(live ? dr.w : 0.0f);",
+        "    R[4] = R[5] = R[6] = R[7] = (__bf16)0.0f;",
+        "}",
+        "TMFMA0(acc10, R, P1);",
+    ]
+    pro += prog.panels[0]["pre"]
+    pro += [f"store_tfrag<0>(acc10, gt_wave + {rb * 2048}, lane16); store_tfrag<8>(acc10, gt_wave + {rb * 2048}, lane16);"]
+    final = list(prog.panels[-1]["post"])
+    emit_tile_body(e, prog, side, nchunks, pro, final, lda)
+    e("    }")
+    e("}")
+    e("}  // namespace dgrad")
+    e("")
+    e("int mlp_dgrad_lds_bytes() { return dgrad::kLdsBytes; }")
+    e("hipError_t launch_mlp_bf16_dgrad(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,")
+    e("                                 int grid_limit, hipStream_t st) {")
+    e("    using namespace dgrad;")
+    e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
+    e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
+    e("    if (grid < 1) grid = 1;")
+    e("    static bool attr_done = false;")
+    e("    if (!attr_done) {")
+    e("        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_bf16_dgrad, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
+    e("        if (er != hipSuccess) return er;")
+    e("        attr_done = true;")
+    e("    }")
+    e(f"    hipLaunchKernelGGL(k_mlp_bf16_dgrad, dim3(grid), dim3({WAVES * 64}), kLdsBytes, st, (const char*)stream_wT,")
+    e("                       (const float4*)d_raw, (const char*)masks, (char*)GT, M, ntiles);")
+    e("    return hipGetLastError();")
+    e("}")
+    e("}  // namespace mip")
+    return "\n".join(lines) + "\n"
+
+
+def main():
+    outdir = sys.argv[1] if len(sys.argv) > 1 else HERE
+    tp = TrainPlan.build()
+    with open(os.path.join(outdir, "mlp_bf16_trainfwd_gen.hip"), "w") as f:
+        f.write(gen_trainfwd(tp))
+    with open(os.path.join(outdir, "mlp_bf16_dgrad_gen.hip"), "w") as f:
+        f.write(gen_dgrad(tp))
+    with open(os.path.join(outdir, "_gen_train_tables.bin"), "wb") as f:
+        f.write(tp.blob())
+    print(f"generated training kernels: fwd {len(tp.fwd.chunks)} chunks, dgrad {tp.n_bchunks_real} (+{len(tp.bchunks) - tp.n_bchunks_real} pad) "
+          f"chunks, {len(tp.jobs)} wgrad jobs -> {outdir}")
+
+
+if __name__ == "__main__":
+    main()

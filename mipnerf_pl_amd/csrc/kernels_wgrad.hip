@@ -1,0 +1,159 @@
+// Weight-gradient kernel of the bf16 Mip-NeRF MLP (torch autograd of models/mip_nerf.py:75-111:
+// dW_j = sum_samples delta_j a_j^T, db_j = sum_samples delta_j) and the split reduction.
+//
+// Operands are the "T-blocks" written by the forward-with-save and dgrad kernels (mlp_train_plan.py): per wave
+// tile (32 samples) and 32-feature block, two lane-linear 1-KiB fragments in which lane (hi, n) holds feature
+// column n for 8 samples -- directly an A (delta) or B (activation) operand of v_mfma_f32_32x32x16_bf16 with the
+// contraction running over samples.  A job = (<= 8 delta blocks) x (<= 8 activation blocks) of one weight matrix;
+// a workgroup (8 waves, wave w owns delta block w and the 8+1 accumulator tiles of its row) streams its share of
+// the wave tiles through a 4-deep LDS ring filled with global_load_lds (every wave moves its own delta block and
+// one activation block per stage: exactly four 1-KiB DMAs per wave per stage, so the ring is synchronised with one
+// counted s_waitcnt + one s_barrier per stage), accumulates in fp32 registers and writes one partial per split.
+// Bound: HBM (1 KiB of operands per 32 KFLOP... 128 FLOP/B at 8x8 blocks); see DESIGN.md.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace mip {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+constexpr int kStages = 4;
+constexpr int kStageBytes = 16 * 2048;       // [8 activation blocks | 8 delta blocks] x 2 KiB
+constexpr int kWgradLds = kStages * kStageBytes;
+
+// two 1-KiB DMAs: global (uniform base + lane*16, +1024) -> LDS (uniform dst, +1024)
+__device__ __forceinline__ void dma_block(const char* gbase, char* lbase, unsigned lane16) {
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lbase;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane16), "s"(gbase), "s"(lds_addr)
+        : "memory");
+}
+}  // namespace
+
+__global__ void __launch_bounds__(512)
+k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const WgradJob* __restrict__ jobs,
+            const int4* __restrict__ wg_tab, int64_t n_wt, int NH, int NG, float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int4 wg = wg_tab[blockIdx.x];                     // job, split, nsplits, partial slot
+    const WgradJob* jp = jobs + wg.x;                       // uniform: scalar loads
+    const int nA = jp->nA, nB = jp->nB;
+    const bool with_bias = jp->bias != 0;
+    const int64_t lo = n_wt * wg.y / wg.z, hi = n_wt * (wg.y + 1) / wg.z;
+    const int nst = (int)(hi - lo);
+    const int a_blk = jp->a_blk[wave], b_blk = jp->b_blk[wave];
+    const bool active = wave < nA;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    auto issue = [&](int64_t wt, int stage) {
+        char* st = smem + stage * kStageBytes;
+        dma_block(HT + (wt * NH + b_blk) * 2048, st + wave * 2048, lane16);
+        dma_block(GT + (wt * NG + a_blk) * 2048, st + 16384 + wave * 2048, lane16);
+    };
+
+    if (nst > 0) {
+#pragma unroll
+        for (int s = 0; s < kStages - 1; ++s) issue(lo + (s < nst ? s : nst - 1), s);
+        for (int i = 0; i < nst; ++i) {
+            // own DMAs of stage i have landed (stages i+1 .. i+kStages-2 may still be in flight) ...
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kStages - 2)) : "memory");
+            // ... and everybody's: stage i is readable, and the slot of stage i-1 is free for refilling
+            __builtin_amdgcn_s_barrier();
+            const int nxt = i + kStages - 1;
+            issue(lo + (nxt < nst ? nxt : nst - 1), nxt % kStages);
+            if (active) {
+                const char* st = smem + (i % kStages) * kStageBytes + lane16;
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + 16384 + wave * 2048);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + 16384 + wave * 2048 + 1024);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < nB) {
+                        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + j * 2048);
+                        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(st + j * 2048 + 1024);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
+                    }
+                }
+                if (with_bias) {
+                    acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ones, acc[8], 0, 0, 0);
+                    acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ones, acc[8], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped tail DMAs before the LDS is released
+    }
+    if (active) {
+        float* out = partials + (int64_t)wg.w * kWgradJobFloats + (int64_t)wave * 9 * 1024 + lane * 16;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j < nB || (j == 8 && with_bias)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(out + j * 1024 + q * 4) =
+                        make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+            }
+        }
+    }
+}
+
+// grad[idx] = sum over the job's splits of the partial at `pos`, for every position that feeds a parameter
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce(const float* __restrict__ partials, const int32_t* __restrict__ otab, const int2* __restrict__ job_slots,
+               float* __restrict__ grad_flat) {
+    const int job = blockIdx.y;
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= kWgradJobFloats) return;
+    const int32_t idx = otab[(int64_t)job * kWgradJobFloats + pos];
+    if (idx < 0) return;
+    const int2 js = job_slots[job];                          // first partial slot, number of splits
+    const float* p = partials + (int64_t)js.x * kWgradJobFloats + pos;
+    float s = 0.0f;
+    for (int k = 0; k < js.y; ++k) s += p[(int64_t)k * kWgradJobFloats];
+    grad_flat[idx] = s;
+}
+
+int mlp_wgrad_lds_bytes() { return kWgradLds; }
+
+hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs, const void* wg_tab, int num_wgs,
+                            int64_t n_wt, int NH, int NG, float* partials, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLds);
+        if (er != hipSuccess) return er;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_mlp_wgrad, dim3(num_wgs), dim3(512), kWgradLds, st, (const char*)HT, (const char*)GT, jobs,
+                       (const int4*)wg_tab, n_wt, NH, NG, partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_wgrad_reduce(const float* partials, const int32_t* otab, const void* job_slots, int njobs,
+                               float* grad_flat, hipStream_t st) {
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((kWgradJobFloats + 255) / 256, njobs), dim3(256), 0, st, partials, otab,
+                       (const int2*)job_slots, grad_flat);
+    return hipGetLastError();
+}
+
+}  // namespace mip

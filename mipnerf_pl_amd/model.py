@@ -79,6 +79,22 @@ class NativeContext:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def train_sizes(self, num_points: int):
+        """(act, masks, delta, partials) buffer sizes in bytes of the native MLP training step."""
+        v = [C.c_size_t() for _ in range(4)]
+        L.check(L.lib().mipnerf_mlp_train_sizes(self._h, num_points, *[C.byref(x) for x in v]), "mlp_train_sizes")
+        return tuple(int(x.value) for x in v)
+
+    def scratch(self, name: str, nbytes: int) -> torch.Tensor:
+        """Cached device scratch buffer (grown on demand, reused across steps)."""
+        if not hasattr(self, "_scratch"):
+            self._scratch = {}
+        t = self._scratch.get(name)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._scratch[name] = t
+        return t
+
     def set_option(self, option: int, value: int) -> None:
         L.check(L.lib().mipnerf_set_option(self._h, option, value), "mipnerf_set_option")
 

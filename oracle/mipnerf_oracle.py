@@ -312,6 +312,61 @@ def mlp_forward(params, x, view_direction=None, skip_index=4, net_depth=8, net_d
     return raw_rgb.astype(F32), raw_density.astype(F32)
 
 
+def mlp_backward(params, x, view_direction, d_raw_rgb, d_raw_density, skip_index=4, net_depth=8,
+                 net_depth_condition=1):
+    """Gradients of MLP.forward (models/mip_nerf.py:75-111) w.r.t. its 24 parameter tensors for
+    the upstream gradients d_raw_rgb [B,N,3], d_raw_density [B,N,1]: what torch autograd derives
+    from those lines (pinned against the reference's autograd by tests/golden/mlp_bwd_*.npz).
+    Returns an OrderedDict with the keys / shapes of `params`."""
+    B, N = x.shape[0], x.shape[1]
+    inputs = x.reshape(B * N, -1).astype(F32)
+    # forward, keeping the input of every Linear (mip_nerf.py:88-110)
+    acts = []
+    h = inputs
+    for i in range(net_depth):
+        acts.append(h)
+        h = np.maximum(h @ params[f"layers.{i}.0.weight"].T + params[f"layers.{i}.0.bias"], F32(0))
+        if i % skip_index == 0 and i > 0:
+            h = np.concatenate([h, inputs], axis=-1)
+    trunk = h
+    bottleneck = trunk @ params["extra_layer.weight"].T + params["extra_layer.bias"]
+    vd = np.repeat(view_direction.astype(F32), N, axis=0)
+    hv = np.concatenate([bottleneck, vd], axis=-1)
+    vacts = []
+    for i in range(net_depth_condition):
+        vacts.append(hv)
+        hv = np.maximum(hv @ params[f"view_layers.{i}.0.weight"].T + params[f"view_layers.{i}.0.bias"], F32(0))
+    # backward
+    g = collections.OrderedDict((k, None) for k in params)
+    d_rgb = d_raw_rgb.reshape(B * N, -1).astype(F32)
+    d_den = d_raw_density.reshape(B * N, -1).astype(F32)
+    g["color_layer.weight"] = d_rgb.T @ hv
+    g["color_layer.bias"] = d_rgb.sum(0)
+    d = d_rgb @ params["color_layer.weight"]
+    for i in reversed(range(net_depth_condition)):
+        d = d * (hv > 0)                                   # ReLU of view layer i (hv is its output)
+        g[f"view_layers.{i}.0.weight"] = d.T @ vacts[i]
+        g[f"view_layers.{i}.0.bias"] = d.sum(0)
+        d = d @ params[f"view_layers.{i}.0.weight"]
+        hv = vacts[i]
+    d_bott = d[:, :bottleneck.shape[1]]                    # the view features get no gradient
+    g["extra_layer.weight"] = d_bott.T @ trunk
+    g["extra_layer.bias"] = d_bott.sum(0)
+    g["density_layer.weight"] = d_den.T @ trunk
+    g["density_layer.bias"] = d_den.sum(0)
+    d = d_bott @ params["extra_layer.weight"] + d_den @ params["density_layer.weight"]
+    out = trunk
+    width = params["layers.0.0.weight"].shape[0]
+    for i in reversed(range(net_depth)):
+        d = d[:, :width] * (out[:, :width] > 0)            # drop the skip-concat columns, ReLU of layer i
+        g[f"layers.{i}.0.weight"] = d.T @ acts[i]
+        g[f"layers.{i}.0.bias"] = d.sum(0)
+        if i > 0:
+            d = d @ params[f"layers.{i}.0.weight"]
+            out = acts[i]
+    return collections.OrderedDict((k, v.astype(F32)) for k, v in g.items())
+
+
 def softplus(x):
     """torch.nn.Softplus(beta=1, threshold=20)."""
     x = _f32(x)

@@ -191,8 +191,45 @@ def grad_case(name, batch, num_samples, param_seed, gain, ray_seed):
     print(f"wrote {name}.npz loss={loss.item():.6f}")
 
 
+def mlp_grad_case(name, batch, num_samples, param_seed, gain, seed):
+    """MLP-only backward golden: the reference MLP (models/mip_nerf.py:14-111) on seeded encodings, upstream
+    gradients d_raw given; autograd grads of all 24 tensors stored as (l2, sum, <=256 strided samples)."""
+    rng = np.random.default_rng(seed)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples)
+    load_params(model, params)
+    # encodings with the statistics of IPE features (|x| <= 1, many near 0) and unit-ish view features
+    enc = (rng.uniform(-1, 1, (batch, num_samples, 96)) * rng.uniform(0, 1, (1, 1, 96)) ** 2).astype(np.float32)
+    vdir = rng.normal(0, 1, (batch, 3)).astype(np.float32)
+    vdir /= np.linalg.norm(vdir, axis=-1, keepdims=True)
+    venc = orc.pos_enc(vdir, 0, 4, True).astype(np.float32)
+    d_rgb = (rng.normal(0, 1, (batch, num_samples, 3)) * 1e-2).astype(np.float32)
+    d_den = (rng.normal(0, 1, (batch, num_samples, 1)) * 1e-3).astype(np.float32)
+    raw_rgb, raw_density = model.mlp(torch.from_numpy(enc), torch.from_numpy(venc))
+    ((raw_rgb * torch.from_numpy(d_rgb)).sum() + (raw_density * torch.from_numpy(d_den)).sum()).backward()
+    out = dict(enc=enc, venc=venc, d_rgb=d_rgb, d_den=d_den, raw_rgb=raw_rgb.detach().numpy(),
+               raw_density=raw_density.detach().numpy(), num_samples=num_samples, param_seed=param_seed,
+               density_gain=gain)
+    og = orc.mlp_backward(params, enc, venc, d_rgb, d_den)
+    worst = 0.0
+    for k, p in model.mlp.named_parameters():
+        g = p.grad.detach().numpy()
+        worst = max(worst, maxdiff(g, og[k]) / max(1e-12, float(np.abs(g).max())))
+        flat = g.ravel()
+        stride = max(1, flat.size // 256)
+        out["g_l2_" + k] = np.float64(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        out["g_sum_" + k] = np.float64(flat.astype(np.float64).sum())
+        out["g_smp_" + k] = flat[::stride][:256].copy()
+    assert worst < 1e-4, worst
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz  oracle.mlp_backward vs reference autograd rel max err {worst:.2e}")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
+    if "--only-mlp-grad" in sys.argv:       # added after the other files were frozen
+        mlp_grad_case("mlp_bwd_8x32_trained", 8, 32, param_seed=8, gain=40.0, seed=8)
+        sys.exit(0)
     # BASELINE.json configs[0]: 256 rays x 64 samples (the reference's CPU-runnable case)
     forward_case("fwd_c1_256x64_xavier", 256, 64, param_seed=0, gain=1.0, ray_seed=0)
     forward_case("fwd_c1_256x64_trained", 256, 64, param_seed=1, gain=40.0, ray_seed=1)
@@ -208,4 +245,5 @@ if __name__ == "__main__":
                     torch_seed=1234)
     stage_case("stages_16x64_trained", 16, 64, param_seed=6, gain=40.0, ray_seed=6)
     grad_case("train_64x64_trained", 64, 64, param_seed=7, gain=40.0, ray_seed=7)
+    mlp_grad_case("mlp_bwd_8x32_trained", 8, 32, param_seed=8, gain=40.0, seed=8)
     print("done")

@@ -168,3 +168,103 @@ def test_render_image_chunked_equals_unchunked(G):
     assert torch.equal(fine.reshape(-1, 3), ret[1][0]) and torch.equal(coarse.reshape(-1, 3), ret[0][0])
     out = system.validation_step((img_rays, rgbs), 0)
     assert torch.isfinite(out['val/psnr'])
+
+
+# ---- native bf16 MLP training kernels (forward-with-save, dgrad, wgrad) ---------------------------------------
+def _mlp_case(B, N, seed):
+    rng = np.random.default_rng(seed)
+    params = orc.make_params(seed=seed, density_gain=40.0)
+    enc = (rng.uniform(-1, 1, (B, N, 96)) * rng.uniform(0, 1, (1, 1, 96)) ** 2).astype(np.float32)
+    vdir = rng.normal(0, 1, (B, 3)).astype(np.float32)
+    vdir /= np.linalg.norm(vdir, axis=-1, keepdims=True)
+    venc = orc.pos_enc(vdir, 0, 4, True).astype(np.float32)
+    d_raw = np.concatenate([rng.normal(0, 1e-2, (B, N, 3)), rng.normal(0, 1e-3, (B, N, 1))], -1).astype(np.float32)
+    return params, enc, venc, d_raw
+
+
+def _run_native_mlp(G, params, enc, venc, d_raw):
+    from mipnerf_pl_amd.autograd import mlp_native
+    B, N = enc.shape[:2]
+    model = G.make_model(params, N, "bf16")
+    v32 = np.zeros((B, 32), np.float32)
+    v32[:, :27] = venc
+    e = torch.from_numpy(enc).to(DEV).to(torch.bfloat16)
+    v = torch.from_numpy(v32).to(DEV).to(torch.bfloat16)
+    raw = mlp_native(model.mlp, e, v)
+    (raw * torch.from_numpy(d_raw).to(DEV)).sum().backward()
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in model.mlp.named_parameters()}
+    return raw.detach().cpu().numpy(), grads, e.float().cpu().numpy(), v.float().cpu().numpy()
+
+
+@pytest.mark.parametrize("B,N", [(8, 32), (5, 24), (3, 100)])
+def test_native_mlp_backward_equals_bf16_emulation(G, B, N):
+    """The three training kernels against the numpy emulation of the SAME dataflow with bf16 operand rounding
+    (fp32 accumulation order is the only difference) and against the fp32 oracle gradients."""
+    from mipnerf_pl_amd.mlp_train_plan import TrainPlan, emulate_train
+    params, enc, venc, d_raw = _mlp_case(B, N, seed=B * 100 + N)
+    raw, grads, enc_bf, v_bf = _run_native_mlp(G, params, enc, venc, d_raw)
+    tp = TrainPlan.build()
+    flatp = np.concatenate([v.ravel() for v in params.values()])
+    S = B * N
+    flat, seen, raw_em = emulate_train(tp, flatp, enc_bf.reshape(S, 96), np.repeat(v_bf, N, axis=0),
+                                       d_raw.reshape(S, 4), round_bf16=True)
+    e_raw = G.maxdiff(raw.reshape(S, 4), raw_em)
+    og = orc.mlp_backward(params, enc, venc, d_raw[..., :3], d_raw[..., 3:])
+    off, worst_em, worst_or = 0, 0.0, 0.0
+    for k, v in og.items():
+        g = grads[k].ravel().astype(np.float64)
+        em = flat[off:off + v.size].astype(np.float64)
+        off += v.size
+        rel_em = np.linalg.norm(g - em) / max(np.linalg.norm(em), 1e-30)
+        rel_or = np.linalg.norm(g - v.ravel()) / max(np.linalg.norm(v.ravel()), 1e-30)
+        worst_em, worst_or = max(worst_em, rel_em), max(worst_or, rel_or)
+    G.record(f"native_mlp_bwd B={B} N={N}", raw_vs_emul=e_raw, grad_rel_l2_vs_emul=worst_em, grad_rel_l2_vs_fp32=worst_or)
+    # same dataflow: only the fp32 accumulation order (and rare bf16 round-to-even tie flips) differ
+    assert worst_em <= 1e-2, worst_em
+    # bf16 operands (8-bit mantissa) for activations AND deltas through up to 10 chained layers: measured 0.11-0.13
+    # relative L2 on layers.0.weight (the deepest gradient), < 0.05 on the heads
+    assert worst_or <= 0.25, worst_or
+    assert e_raw <= 2e-2 * max(1.0, float(np.abs(raw_em).max()))
+
+
+def test_native_mlp_backward_against_reference_golden(G):
+    """bf16 kernels vs the reference's own autograd gradients (golden, fp32): direction and norm."""
+    g = G.load_golden("mlp_bwd_8x32_trained")
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    d_raw = np.concatenate([g["d_rgb"], g["d_den"]], -1)
+    raw, grads, _, _ = _run_native_mlp(G, params, g["enc"], g["venc"], d_raw)
+    assert G.maxdiff(raw[..., :3], g["raw_rgb"]) <= 3e-2 and G.maxdiff(raw[..., 3:], g["raw_density"]) <= 0.5
+    worst = 0.0
+    for k, gr in grads.items():
+        flat = gr.ravel()
+        ref = g["g_smp_" + k]
+        stride = max(1, flat.size // ref.size)
+        smp = flat[::stride][:ref.size].astype(np.float64)
+        l2 = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        rel_l2 = abs(l2 - float(g["g_l2_" + k])) / float(g["g_l2_" + k])
+        cos = float((smp * ref).sum() / max(np.linalg.norm(smp) * np.linalg.norm(ref), 1e-30))
+        worst = max(worst, rel_l2, 1 - cos)
+        G.record("native_mlp_bwd_vs_reference_golden " + k, rel_l2_norm=rel_l2, cosine=cos)
+        assert rel_l2 <= 5e-2 and cos >= 0.98, (k, rel_l2, cos)      # measured: cos 0.992 on layers.0.weight
+
+
+def test_native_mlp_full_size_linearity_and_split_invariance(G):
+    """BASELINE configs[1] size (4096 x 128 samples): size-independent properties of the backward --
+    linear in d_raw, and the sum of the gradients of two ray halves equals the gradient of the whole batch."""
+    B, N = 4096, 128
+    params, enc, venc, d_raw = _mlp_case(64, N, seed=77)
+    reps = B // 64
+    enc, venc, d_raw = np.tile(enc, (reps, 1, 1)), np.tile(venc, (reps, 1)), np.tile(d_raw, (reps, 1, 1))
+    d_raw = d_raw * np.random.default_rng(5).uniform(0.5, 1.5, (B, 1, 1)).astype(np.float32)
+    _, g_all, _, _ = _run_native_mlp(G, params, enc, venc, d_raw)
+    _, g_a, _, _ = _run_native_mlp(G, params, enc[:B // 2], venc[:B // 2], d_raw[:B // 2])
+    _, g_b, _, _ = _run_native_mlp(G, params, enc[B // 2:], venc[B // 2:], d_raw[B // 2:])
+    _, g_2x, _, _ = _run_native_mlp(G, params, enc, venc, 2.0 * d_raw)
+    worst = 0.0
+    for k in g_all:
+        scale = float(np.abs(g_all[k]).max()) + 1e-30
+        e_split = float(np.abs(g_a[k] + g_b[k] - g_all[k]).max()) / scale
+        e_lin = float(np.abs(g_2x[k] - 2.0 * g_all[k]).max()) / scale
+        worst = max(worst, e_split, e_lin)
+        assert np.isfinite(g_all[k]).all() and e_split <= 1e-3 and e_lin <= 1e-6, (k, e_split, e_lin)
+    G.record("native_mlp_bwd_full_size", worst=worst)

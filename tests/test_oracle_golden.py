@@ -122,3 +122,31 @@ def test_known_answers():
     rr, dd = orc.mlp_forward(p, np.zeros((1, 2, 96), np.float32), np.zeros((1, 27), np.float32))
     np.testing.assert_allclose(rr[0, 0], p["color_layer.bias"], atol=1e-7)
     np.testing.assert_allclose(dd[0, 0], p["density_layer.bias"], atol=1e-7)
+
+
+def grad_check(g, grads, rtol_l2, rtol_smp):
+    """Compare full gradient tensors with the (l2, strided samples) summary stored in a golden file."""
+    worst = 0.0
+    for k, gr in grads.items():
+        flat = np.asarray(gr, dtype=np.float32).ravel()
+        l2 = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        ref_l2 = float(g["g_l2_" + k])
+        smp_ref = g["g_smp_" + k]
+        stride = max(1, flat.size // smp_ref.size)
+        smp = flat[::stride][:smp_ref.size]
+        rel = abs(l2 - ref_l2) / max(ref_l2, 1e-20)
+        es = float(np.max(np.abs(smp - smp_ref))) / max(float(np.max(np.abs(smp_ref))), 1e-20)
+        assert rel <= rtol_l2 and es <= rtol_smp, (k, rel, es)
+        worst = max(worst, rel, es)
+    return worst
+
+
+def test_mlp_backward_matches_reference_autograd(golden_dir):
+    g = load(golden_dir, "mlp_bwd_8x32_trained")
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    rr, dd = orc.mlp_forward(params, g["enc"], g["venc"])
+    np.testing.assert_allclose(rr, g["raw_rgb"], atol=2e-5)
+    np.testing.assert_allclose(dd, g["raw_density"], atol=2e-4)
+    grads = orc.mlp_backward(params, g["enc"], g["venc"], g["d_rgb"], g["d_den"])
+    assert list(grads) == list(params)
+    grad_check(g, grads, 1e-5, 1e-5)

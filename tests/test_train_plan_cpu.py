@@ -1,0 +1,99 @@
+"""CPU: the plan of the bf16 training kernels (mipnerf_pl_amd/mlp_train_plan.py).  The numpy emulation moves data
+exactly like the generated forward-with-save / dgrad kernels and the table-driven wgrad kernel (same pack tables,
+T-block layout, ReLU bit packing, partial -> parameter index table); in fp32 it must reproduce the oracle's
+gradients, which are pinned against the reference's autograd (tests/golden/mlp_bwd_8x32_trained.npz)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mipnerf_pl_amd.mlp_train_plan import (JOB_FLOATS, TrainPlan, colfeat, emulate_train, frag_sample, pack_mask,
+                                           unpack_mask)
+from oracle import mipnerf_oracle as orc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tp():
+    return TrainPlan.build()
+
+
+def _case(golden_dir, S):
+    g = dict(np.load(os.path.join(golden_dir, "mlp_bwd_8x32_trained.npz")))
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    enc = g["enc"].reshape(-1, 96)[:S]
+    venc = np.repeat(g["venc"], int(g["num_samples"]), axis=0)[:S]
+    view = np.zeros((S, 32), np.float32)
+    view[:, :27] = venc
+    d_raw = np.concatenate([g["d_rgb"].reshape(-1, 3), g["d_den"].reshape(-1, 1)], -1)[:S]
+    return params, enc, venc, view, d_raw
+
+
+def test_layout_maps_are_bijections(tp):
+    for kind in (0, 1):
+        assert sorted(colfeat(kind, n) for n in range(32)) == list(range(32))
+    assert sorted(frag_sample(f, hi, j) for f in range(2) for hi in range(2) for j in range(8)) == list(range(32))
+    assert tp.NH == 80 and tp.NG == 77 and tp.NMASK == 9
+    assert len(tp.bchunks) % 64 == 0 and tp.n_bchunks_real == 1100
+    rng = np.random.default_rng(0)
+    r0, r1 = rng.normal(size=(64, 8)).astype(np.float32), rng.normal(size=(64, 8)).astype(np.float32)
+    words = np.zeros((64, 4), np.uint32)
+    for t in range(8):
+        words[:, t >> 1] |= pack_mask(r0 * (t + 1), r1 - t) << np.uint32(8 * (t & 1))
+    for t in range(8):
+        assert (unpack_mask(words, t) == (np.concatenate([r0 * (t + 1), r1 - t], 1) > 0)).all()
+
+
+def test_every_parameter_has_exactly_one_partial(tp):
+    ot = tp.wgrad_out_table()
+    assert ot.shape[1:] == (8, 9, 64, 16) and ot[0].size == JOB_FLOATS
+    idx = ot[ot >= 0]
+    total = tp.fwd.param_offsets()[1]
+    assert total == 612740 and idx.size == total and np.array_equal(np.sort(idx), np.arange(total))
+    # the dgrad stream uses every weight that has a downstream gradient exactly once: all but layer 0, the 96
+    # skip columns of layer 5 and the 27 view columns of the view layer; no bias
+    bp = tp.bpack_table()
+    used = bp[bp >= 0]
+    assert used.size == np.unique(used).size == 557696   # 557,696 dgrad MACs per sample
+
+
+def test_emulated_dataflow_reproduces_oracle_gradients(tp, golden_dir):
+    S = 70     # 3 wave tiles, the last one ragged (clamped duplicates must not contribute)
+    params, enc, venc, view, d_raw = _case(golden_dir, S)
+    flatp = np.concatenate([v.ravel() for v in params.values()])
+    flat, seen, raw = emulate_train(tp, flatp, enc, view, d_raw)
+    assert (seen == 1).all()
+    rr, dd = orc.mlp_forward(params, enc[:, None, :], venc)
+    np.testing.assert_allclose(raw[:, :3], rr[:, 0], atol=1e-5)
+    np.testing.assert_allclose(raw[:, 3], dd[:, 0, 0], atol=1e-4)
+    og = orc.mlp_backward(params, enc[:, None, :], venc, d_raw[:, None, :3], d_raw[:, None, 3:])
+    off = 0
+    for k, v in og.items():
+        e = np.abs(flat[off:off + v.size] - v.ravel()).max() / max(1e-20, np.abs(v).max())
+        off += v.size
+        assert e < 1e-5, (k, e)
+
+
+def test_embedded_tables_equal_python_plan(tp):
+    from mipnerf_pl_amd import _lib as L
+    h = L.lib()
+    for which, ref in ((3, tp.bpack_table()), (4, tp.wgrad_out_table()), (5, tp.job_table())):
+        n = h.mipnerf_debug_table(which, None, 0)
+        buf = np.zeros(n, np.int32)
+        h.mipnerf_debug_table(which, buf.ctypes.data, n)
+        assert n == ref.size and np.array_equal(buf, ref.ravel()), which
+
+
+def test_generator_schedule_passes_hazard_check(tmp_path):
+    """gen_mlp_train.py replays both tile programs and asserts the register-set discipline (every B operand of op i
+    was written by op i-1, every transposed register by the op that stores it)."""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "mipnerf_pl_amd", "csrc", "gen_mlp_train.py"), str(tmp_path)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for f in ("mlp_bf16_trainfwd_gen.hip", "mlp_bf16_dgrad_gen.hip"):
+        gen = open(os.path.join(tmp_path, f)).read()
+        committed = open(os.path.join(REPO, "mipnerf_pl_amd", "csrc", f)).read()
+        assert gen == committed, f"{f} is stale: re-run python -m mipnerf_pl_amd.build"
