@@ -209,6 +209,15 @@ int mipnerf_mlp_forward_train(mipnerf_ctx* ctx, int64_t num_points, int32_t num_
 int mipnerf_mlp_backward(mipnerf_ctx* ctx, int64_t num_points, const float* d_raw, const void* act,
                          const void* masks, void* delta, float* partials, float* grad_flat,
                          void* stream);
+/* The two halves of mipnerf_mlp_backward, separately testable / timeable: delta chain (writes `delta`), and
+ * weight gradients (reads act + delta; grad_flat may be NULL = leave the fp32 partials unreduced). */
+int mipnerf_mlp_dgrad(mipnerf_ctx* ctx, int64_t num_points, const float* d_raw, const void* masks,
+                      void* delta, void* stream);
+int mipnerf_mlp_wgrad(mipnerf_ctx* ctx, int64_t num_points, const void* act, const void* delta,
+                      float* partials, float* grad_flat, void* stream);
+/* Tuning: workgroups per weight-gradient job (HOST array, 14 entries for the compiled MLP; 0 skips a job, for
+ * timing only).  NULL restores the default.  Changes partial_bytes of mipnerf_mlp_train_sizes; synchronises. */
+int mipnerf_set_wgrad_splits(mipnerf_ctx* ctx, const int32_t* splits_host);
 
 /* ---- instrumentation ------------------------------------------------------------------ */
 /* Times `iters` launches of the bf16 MLP kernel with hipEvents on `stream`; returns the

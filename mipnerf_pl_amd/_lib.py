@@ -62,6 +62,9 @@ SIGNATURES = {
     "mipnerf_mlp_train_sizes": (C.c_int, [_P, _I64, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ)]),
     "mipnerf_mlp_forward_train": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "mipnerf_mlp_backward": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "mipnerf_mlp_dgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P]),
+    "mipnerf_mlp_wgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
+    "mipnerf_set_wgrad_splits": (C.c_int, [_P, _P]),
     "mipnerf_time_mlp": (C.c_int, [_P, _I64, _I32, _P, _P, C.c_int, _P, C.c_int, C.POINTER(_F), _P]),
     "mipnerf_selftest": (C.c_int, [_P]),
     "mipnerf_set_option": (C.c_int, [_P, C.c_int, C.c_int]),

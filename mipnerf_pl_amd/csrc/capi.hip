@@ -205,6 +205,8 @@ struct mipnerf_ctx {
 
 extern "C" {
 
+int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host);
+
 const char* mipnerf_last_error(void) { return g_err.c_str(); }
 int mipnerf_abi_version(void) { return MIPNERF_ABI_VERSION; }
 
@@ -274,36 +276,24 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         const TrainTables& tt = c->tt;
         const std::vector<int32_t> flat(tt.bpack, tt.bpack + (size_t)tt.n_bchunks * 512);
         const std::vector<int32_t> e_dg = encode(flat, c->tab.tensor_off);
-        // workgroups per job ~ HBM bytes per wave tile (blocks loaded); every job gets at least one
-        std::vector<int> splits(tt.njobs);
-        double csum = 0;
-        for (int j = 0; j < tt.njobs; ++j) csum += tt.jobs[j * 20 + 0] + tt.jobs[j * 20 + 1];
-        std::vector<int4> wgtab;
-        std::vector<int2> slots(tt.njobs);
-        for (int j = 0; j < tt.njobs; ++j) {
-            int sp = (int)((tt.jobs[j * 20 + 0] + tt.jobs[j * 20 + 1]) / csum * c->grid_limit);
-            if (sp < 1) sp = 1;
-            slots[j] = make_int2((int)wgtab.size(), sp);
-            for (int k = 0; k < sp; ++k) wgtab.push_back(make_int4(j, k, sp, (int)wgtab.size()));
-        }
-        c->num_wgrad_wgs = (int)wgtab.size();
         chk(hipMalloc(&c->d_pack_dgrad, e_dg.size() * 4));
         chk(hipMalloc(&c->d_stream_dgrad, e_dg.size() * 2));
         chk(hipMalloc(&c->d_jobs, (size_t)tt.njobs * sizeof(mip::WgradJob)));
         chk(hipMalloc(&c->d_otab, (size_t)tt.njobs * tt.job_floats * 4));
-        chk(hipMalloc(&c->d_wgtab, wgtab.size() * sizeof(int4)));
-        chk(hipMalloc(&c->d_jobslots, slots.size() * sizeof(int2)));
+        chk(hipMalloc(&c->d_jobslots, (size_t)tt.njobs * sizeof(int2)));
         if (er == hipSuccess) {
             chk(hipMemcpy(c->d_pack_dgrad, e_dg.data(), e_dg.size() * 4, hipMemcpyHostToDevice));
             chk(hipMemcpy(c->d_jobs, tt.jobs, (size_t)tt.njobs * sizeof(mip::WgradJob), hipMemcpyHostToDevice));
             chk(hipMemcpy(c->d_otab, tt.otab, (size_t)tt.njobs * tt.job_floats * 4, hipMemcpyHostToDevice));
-            chk(hipMemcpy(c->d_wgtab, wgtab.data(), wgtab.size() * sizeof(int4), hipMemcpyHostToDevice));
-            chk(hipMemcpy(c->d_jobslots, slots.data(), slots.size() * sizeof(int2), hipMemcpyHostToDevice));
         }
         if (er != hipSuccess) {
             mipnerf_destroy(c);
             return fail(MIPNERF_E_HIP, "mipnerf_create (training tables): %s", hipGetErrorString(er));
         }
+    }
+    {
+        const int rc = mipnerf_set_wgrad_splits(c, nullptr);
+        if (rc) { mipnerf_destroy(c); return rc; }
     }
     *out = c;
     return MIPNERF_OK;
@@ -477,16 +467,63 @@ int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* 
     return MIPNERF_OK;
 }
 
-int mipnerf_mlp_backward(mipnerf_ctx* c, int64_t M, const float* d_raw, const void* act, const void* masks, void* delta,
-                         float* partials, float* grad_flat, void* stream) {
-    if (!c || M < 1 || !d_raw || !act || !masks || !delta || !partials || !grad_flat)
-        return fail(MIPNERF_E_INVALID, "mlp_backward: bad argument");
-    if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_backward: mipnerf_set_params has not been called");
-    const int64_t n_wt = ((M + 255) / 256) * 8;
+int mipnerf_mlp_dgrad(mipnerf_ctx* c, int64_t M, const float* d_raw, const void* masks, void* delta, void* stream) {
+    if (!c || M < 1 || !d_raw || !masks || !delta) return fail(MIPNERF_E_INVALID, "mlp_dgrad: bad argument");
+    if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_dgrad: mipnerf_set_params has not been called");
     HIP_TRY(mip::launch_mlp_bf16_dgrad(c->d_stream_dgrad, d_raw, masks, delta, M, c->grid_limit, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_mlp_wgrad(mipnerf_ctx* c, int64_t M, const void* act, const void* delta, float* partials, float* grad_flat,
+                      void* stream) {
+    if (!c || M < 1 || !act || !delta || !partials) return fail(MIPNERF_E_INVALID, "mlp_wgrad: bad argument");
+    const int64_t n_wt = ((M + 255) / 256) * 8;
     HIP_TRY(mip::launch_mlp_wgrad(act, delta, c->d_jobs, c->d_wgtab, c->num_wgrad_wgs, n_wt, c->tt.NH, c->tt.NG, partials,
                                   S(stream)));
-    HIP_TRY(mip::launch_wgrad_reduce(partials, c->d_otab, c->d_jobslots, c->tt.njobs, grad_flat, S(stream)));
+    if (grad_flat)
+        HIP_TRY(mip::launch_wgrad_reduce(partials, c->d_otab, c->d_jobslots, c->tt.njobs, grad_flat, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_mlp_backward(mipnerf_ctx* c, int64_t M, const float* d_raw, const void* act, const void* masks, void* delta,
+                         float* partials, float* grad_flat, void* stream) {
+    if (!grad_flat) return fail(MIPNERF_E_INVALID, "mlp_backward: grad_flat is null");
+    int rc = mipnerf_mlp_dgrad(c, M, d_raw, masks, delta, stream);
+    if (rc) return rc;
+    return mipnerf_mlp_wgrad(c, M, act, delta, partials, grad_flat, stream);
+}
+
+// Replace the wgrad work split: splits_host[njobs] workgroups per job (0 = skip the job: its gradients are then
+// NOT produced -- timing experiments only).  NULL restores the default (CUs / njobs workgroups per job).
+int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host) {
+    if (!c) return fail(MIPNERF_E_INVALID, "ctx is null");
+    const TrainTables& tt = c->tt;
+    std::vector<int> sp(tt.njobs);
+    if (splits_host) {
+        for (int j = 0; j < tt.njobs; ++j) sp[j] = splits_host[j] < 0 ? 0 : splits_host[j];
+    } else {
+        // Equal number of workgroups per job (measured on MI355X, scripts/prof_train.py: 1.00 ms vs 1.17 ms for a
+        // bytes-proportional split at 4096x128 samples): a stage has a fixed cost (barrier + DMA latency) that the
+        // small jobs cannot hide, so balancing stages, not bytes, is what equalises the finish times.
+        for (int j = 0; j < tt.njobs; ++j) {
+            sp[j] = c->grid_limit / tt.njobs;
+            if (sp[j] < 1) sp[j] = 1;
+        }
+    }
+    std::vector<int4> wgtab;
+    std::vector<int2> slots(tt.njobs);
+    for (int j = 0; j < tt.njobs; ++j) {
+        slots[j] = make_int2((int)wgtab.size(), sp[j]);
+        for (int k = 0; k < sp[j]; ++k) wgtab.push_back(make_int4(j, k, sp[j], (int)wgtab.size()));
+    }
+    if (wgtab.empty()) return fail(MIPNERF_E_INVALID, "set_wgrad_splits: no workgroups");
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(c->d_wgtab);
+    c->d_wgtab = nullptr;
+    HIP_TRY(hipMalloc(&c->d_wgtab, wgtab.size() * sizeof(int4)));
+    HIP_TRY(hipMemcpy(c->d_wgtab, wgtab.data(), wgtab.size() * sizeof(int4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_jobslots, slots.data(), slots.size() * sizeof(int2), hipMemcpyHostToDevice));
+    c->num_wgrad_wgs = (int)wgtab.size();
     return MIPNERF_OK;
 }
 

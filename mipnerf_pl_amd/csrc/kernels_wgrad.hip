@@ -6,9 +6,9 @@
 // column n for 8 samples -- directly an A (delta) or B (activation) operand of v_mfma_f32_32x32x16_bf16 with the
 // contraction running over samples.  A job = (<= 8 delta blocks) x (<= 8 activation blocks) of one weight matrix;
 // a workgroup (8 waves, wave w owns delta block w and the 8+1 accumulator tiles of its row) streams its share of
-// the wave tiles through a 4-deep LDS ring filled with global_load_lds (every wave moves its own delta block and
-// one activation block per stage: exactly four 1-KiB DMAs per wave per stage, so the ring is synchronised with one
-// counted s_waitcnt + one s_barrier per stage), accumulates in fp32 registers and writes one partial per split.
+// the wave tiles through a 4-deep LDS ring filled with global_load_lds (wave w moves delta block w and
+// activation block w when they exist: a wave-uniform number of 1-KiB DMAs per stage, so the ring is synchronised
+// with one counted s_waitcnt + one s_barrier per stage), accumulates in fp32 registers and writes one partial per split.
 // Bound: HBM (1 KiB of operands per 32 KFLOP... 128 FLOP/B at 8x8 blocks); see DESIGN.md.
 #include <hip/hip_runtime.h>
 
@@ -67,10 +67,14 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
+    // Each wave moves only blocks that exist: its delta block (wave < nA) and one activation block (wave < nB),
+    // 2 DMAs each.  The number of DMAs per stage is wave-uniform, so each wave waits with its own counted vmcnt.
+    const bool has_a = wave < nA, has_b = wave < nB;
+    const int ndma = (has_a ? 2 : 0) + (has_b ? 2 : 0);
     auto issue = [&](int64_t wt, int stage) {
         char* st = smem + stage * kStageBytes;
-        dma_block(HT + (wt * NH + b_blk) * 2048, st + wave * 2048, lane16);
-        dma_block(GT + (wt * NG + a_blk) * 2048, st + 16384 + wave * 2048, lane16);
+        if (has_b) dma_block(HT + (wt * NH + b_blk) * 2048, st + wave * 2048, lane16);
+        if (has_a) dma_block(GT + (wt * NG + a_blk) * 2048, st + 16384 + wave * 2048, lane16);
     };
 
     if (nst > 0) {
@@ -78,7 +82,8 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
         for (int s = 0; s < kStages - 1; ++s) issue(lo + (s < nst ? s : nst - 1), s);
         for (int i = 0; i < nst; ++i) {
             // own DMAs of stage i have landed (stages i+1 .. i+kStages-2 may still be in flight) ...
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kStages - 2)) : "memory");
+            if (ndma == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kStages - 2)) : "memory");
+            else if (ndma == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (kStages - 2)) : "memory");
             // ... and everybody's: stage i is readable, and the slot of stage i-1 is free for refilling
             __builtin_amdgcn_s_barrier();
             const int nxt = i + kStages - 1;
