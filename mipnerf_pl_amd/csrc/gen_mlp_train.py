@@ -315,7 +315,7 @@ def file_header(e, ns, consts):
     e("typedef __attribute__((ext_vector_type(16))) float f32x16;")
     for k, v in consts.items():
         e(f"constexpr int {k} = {v};")
-    e(KERNEL_PREAMBLE.replace("BARRIER_INSN", "s_barrier"))
+    e(KERNEL_PREAMBLE.replace("BARRIER_INSN", "s_barrier").replace("WAIT_INSN", "s_waitcnt vmcnt(0) lgkmcnt(0)"))
     e(TRAIN_PREAMBLE)
     e("constexpr bool DMA = true;")
 
