@@ -33,8 +33,11 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="inference", choices=["inference", "train"],
-                    help="inference (headline): MipNerf.forward; train: forward + loss + backward + grad all-reduce + Adam")
+    ap.add_argument("--mode", default="inference", choices=["inference", "train", "render"],
+                    help="inference (headline): MipNerf.forward; train: forward + loss + backward + grad all-reduce + Adam; "
+                         "render: BASELINE configs[4], one 800x800 frame (640k rays) in 8192-ray chunks replayed from a "
+                         "captured hipGraph, rays split over the ranks, rgb gathered")
+    ap.add_argument("--no-graph", action="store_true", help="render mode: eager chunk loop instead of the hipGraph")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,6 +87,30 @@ def main():
             opt.step()
             sch["scheduler"].step()
             return [(loss.detach().reshape(1),)]
+    elif args.mode == "render":
+        from mipnerf_pl_amd.parallel import gather_rendered, shard_bounds
+        from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+        Himg = Wimg = 800
+        lo, hi = shard_bounds(Himg * Wimg, rank, world)          # contiguous ray shard of this rank (strong scaling)
+        nloc = hi - lo
+        frame_np = orc.synthetic_rays(8192, seed=7)               # tiled: 640k distinct draws would dominate start-up
+        reps = (nloc + 8191) // 8192
+        FR = Rays(*[torch.from_numpy(np.tile(a, (reps, 1))[:nloc]).to(dev) for a in frame_np])
+        hp = dict(DEFAULT_HPARAMS)
+        hp.update({"nerf.num_samples": N, "val.chunk_size": 8192})
+        system = MipNeRFSystem(hp, precision=args.precision)
+        system.mip_nerf.load_state_dict(model.state_dict())
+        system = system.to(dev)
+        system.enable_hip_graph(not args.no_graph)
+        model = system.mip_nerf
+        img_rays = Rays(*[x.reshape(1, 1, nloc, -1) for x in FR])
+        dummy = torch.zeros(1, 1, nloc, 3, device=dev)
+
+        def step():
+            _, fine, _ = system.render_image((img_rays, dummy))
+            full = gather_rendered(fine.reshape(nloc, 3), Himg * Wimg)
+            return [(full,)]
+        B = Himg * Wimg // world      # for the samples-per-step accounting below (whole frame / world per rank)
     else:
         def step():
             with torch.no_grad():
@@ -159,10 +186,13 @@ def main():
         line = {
             "metric": "ray-samples/sec", "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.mode == "render" else "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": (f"BASELINE.json configs[1]: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) "
                                     f"samples per GPU, 8x256 MLP, random-init trained-like weights") if args.mode == "inference"
+                       else (f"BASELINE.json configs[4]: one 800x800 frame = 640,000 rays x ({N}+{N}) samples in 8192-ray chunks, "
+                             f"{'eager chunk loop' if args.no_graph else 'chunk forward replayed from a captured hipGraph'}, rays split over "
+                             f"{world} rank(s), rgb all-gathered") if args.mode == "render"
                        else (f"training step (forward randomized + loss incl. distloss + backward + grad all-reduce + Adam), "
                              f"{B} rays x ({N}+{N}) samples per GPU; MLP forward-with-save / dgrad / wgrad = native bf16 MFMA kernels"),
                        "mode": args.mode,

@@ -289,3 +289,49 @@ class MipNerf(torch.nn.Module):
             raise NotImplementedError("density_noise > 0 is not implemented (reference default 0; upstream code "
                                       "draws it on the CPU and would fail on GPU)")
         return ret
+
+
+class GraphedForward:
+    """hipGraph replay of `MipNerf.forward(rays, randomized=False, white_bkgd)` for a fixed chunk of rays
+    (BASELINE configs[4]: full-frame rendering = ~79 identical chunk launches; the ~20 kernel launches of one
+    chunk are captured once and replayed).  Inputs are copied into static buffers, outputs are static tensors
+    (valid until the next call); a ragged last chunk is padded with copies of its first ray and sliced."""
+
+    def __init__(self, model: "MipNerf", chunk: int, white_bkgd: bool, device: torch.device):
+        self.model, self.chunk, self.white_bkgd = model, int(chunk), bool(white_bkgd)
+        self.static_in = Rays(*[torch.zeros(self.chunk, k, device=device) for k in (3, 3, 3, 1, 1, 1, 1)])
+        for k in ("directions", "viewdirs"):          # valid dummy rays for the warm-up launches
+            getattr(self.static_in, k)[:, 2] = 1.0
+        self.static_in.radii.fill_(1e-3)
+        self.static_in.near.fill_(2.0)
+        self.static_in.far.fill_(6.0)
+        self.param_key = None
+        self.graph = None
+        self.static_out = None
+
+    def _capture(self):
+        m = self.model
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():     # warm-up on a side stream: lazy init, workspace, packing
+            for _ in range(2):
+                m._forward_native(self.static_in, False, self.white_bkgd)
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.static_out = m._forward_native(self.static_in, False, self.white_bkgd)
+
+    def __call__(self, rays: Rays):
+        n = rays.origins.shape[0]
+        if n > self.chunk:
+            raise ValueError(f"GraphedForward captured for {self.chunk} rays, got {n}")
+        # the packed weight streams live in the context: re-pack OUTSIDE the graph when a parameter changed
+        self.model.mlp.native(rays.origins.device)
+        if self.graph is None:
+            self._capture()
+        for dst, src in zip(self.static_in, rays):
+            dst[:n].copy_(src)
+            if n < self.chunk:
+                dst[n:].copy_(src[:1].expand(self.chunk - n, -1))
+        self.graph.replay()
+        return [tuple(t[:n] for t in lvl) for lvl in self.static_out]

@@ -165,6 +165,22 @@ class MipNeRFSystem(_Base):
         self.log('val/loss', torch.stack([x['val/loss'] for x in outputs]).mean())
         self.log('val/psnr', torch.stack([x['val/psnr'] for x in outputs]).mean(), prog_bar=True)
 
+    def enable_hip_graph(self, on: bool = True):
+        """Render chunks through a captured hipGraph (one capture per chunk size; not in the reference)."""
+        self.use_hip_graph = bool(on)
+        self._graphed = None
+        return self
+
+    def _chunk_forward(self, batch_rays):
+        if getattr(self, "use_hip_graph", False) and not self.val_randomized and batch_rays.origins.is_cuda:
+            from .model import GraphedForward
+            g = getattr(self, "_graphed", None)
+            if g is None or g.chunk != self.val_chunk_size or g.white_bkgd != bool(self.white_bkgd):
+                g = self._graphed = GraphedForward(self.mip_nerf, self.val_chunk_size, self.white_bkgd,
+                                                   batch_rays.origins.device)
+            return g(batch_rays)
+        return self(batch_rays, self.val_randomized, self.white_bkgd)
+
     def render_image(self, batch, return_distance=False):   # nerf_system.py:151-177
         rays, rgbs = batch
         _, height, width, _ = rgbs.shape
@@ -172,10 +188,10 @@ class MipNeRFSystem(_Base):
         coarse_rgb, fine_rgb, distances = [], [], []
         with torch.no_grad():
             for batch_rays in single_image_rays:
-                (c_rgb, _, _, _, _), (f_rgb, distance, _, _, _) = self(batch_rays, self.val_randomized, self.white_bkgd)
-                coarse_rgb.append(c_rgb)
-                fine_rgb.append(f_rgb)
-                distances.append(distance)
+                (c_rgb, _, _, _, _), (f_rgb, distance, _, _, _) = self._chunk_forward(batch_rays)
+                coarse_rgb.append(c_rgb.clone() if getattr(self, "use_hip_graph", False) else c_rgb)
+                fine_rgb.append(f_rgb.clone() if getattr(self, "use_hip_graph", False) else f_rgb)
+                distances.append(distance.clone() if getattr(self, "use_hip_graph", False) else distance)
         coarse_rgb = torch.cat(coarse_rgb, dim=0).reshape(1, height, width, -1)
         fine_rgb = torch.cat(fine_rgb, dim=0).reshape(1, height, width, -1)
         if return_distance:

@@ -268,3 +268,33 @@ def test_native_mlp_full_size_linearity_and_split_invariance(G):
         worst = max(worst, e_split, e_lin)
         assert np.isfinite(g_all[k]).all() and e_split <= 1e-3 and e_lin <= 1e-6, (k, e_split, e_lin)
     G.record("native_mlp_bwd_full_size", worst=worst)
+
+
+def test_render_image_hip_graph_equals_eager(G):
+    """BASELINE configs[4] plumbing: the chunk loop of render_image replayed from a captured hipGraph returns
+    bit-identical images (incl. the ragged last chunk and a parameter update between frames)."""
+    from mipnerf_pl_amd import Rays
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    H, W = 24, 37     # 888 rays; chunk 256 -> 3 full chunks + ragged tail of 120
+    rays_np = orc.synthetic_rays(H * W, seed=9)
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({'nerf.num_samples': 64, 'val.chunk_size': 256})
+    system = MipNeRFSystem(hp, precision="bf16")
+    params = orc.make_params(seed=9, density_gain=40.0)
+    system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    system = system.to(DEV)
+    R = G.to_dev(rays_np)
+    img_rays = Rays(*[x.reshape(1, H, W, -1) for x in R])
+    rgbs = torch.zeros(1, H, W, 3, device=DEV)
+    eager = system.render_image((img_rays, rgbs), return_distance=True)
+    system.enable_hip_graph(True)
+    for _ in range(2):      # second frame replays without re-capturing
+        graphed = system.render_image((img_rays, rgbs), return_distance=True)
+        for a, b in zip(eager, graphed):
+            assert torch.equal(a, b)
+    with torch.no_grad():
+        system.mip_nerf.mlp.color_layer.bias.add_(0.25)      # optimizer-step stand-in: streams must be re-packed
+    g2 = system.render_image((img_rays, rgbs))
+    system.enable_hip_graph(False)
+    e2 = system.render_image((img_rays, rgbs))
+    assert torch.equal(g2[1], e2[1]) and not torch.equal(g2[1], eager[1])
