@@ -37,6 +37,8 @@ def main():
                     help="inference (headline): MipNerf.forward; train: forward + loss + backward + grad all-reduce + Adam; "
                          "render: BASELINE configs[4], one 800x800 frame (640k rays) in 8192-ray chunks replayed from a "
                          "captured hipGraph, rays split over the ranks, rgb gathered")
+    ap.add_argument("--torch-adam", action="store_true", help="train mode: torch.optim.Adam on per-tensor gradients "
+                    "(what the reference configures) instead of the fused flat Adam kernel")
     ap.add_argument("--no-graph", action="store_true", help="render mode: eager chunk loop instead of the hipGraph")
     args = ap.parse_args()
 
@@ -75,12 +77,13 @@ def main():
         system.mip_nerf.load_state_dict(model.state_dict())
         system = system.to(dev)
         model = system.mip_nerf
+        system.fused_adam = not args.torch_adam         # FlatAdam: flat parameter / gradient buffers, one Adam kernel
         (opt,), (sch,) = system.configure_optimizers()
-        reduce_grads = FlatGradAllReduce(list(model.parameters()))
+        reduce_grads = FlatGradAllReduce(list(model.parameters()), mlp=model.mlp)
         gt = torch.rand(B, 3, device=dev)
 
         def step():
-            opt.zero_grad(set_to_none=False)
+            opt.zero_grad(set_to_none=False)              # FlatAdam: no kernel, the next backward overwrites
             loss = system.training_step((R, gt), 0)      # randomized=True, nerf_system.py:95-121
             loss.backward()
             reduce_grads()                                # one flat all-reduce over RCCL (no-op at world 1)

@@ -99,6 +99,16 @@ typedef struct mipnerf_level_out {
     float* t_samples; /* [B,N+1] */
 } mipnerf_level_out;
 
+/* Output of mipnerf_generate_rays: the same 7 fields, writable. */
+typedef struct mipnerf_rays_out {
+    float* origins; float* directions; float* viewdirs; float* radii; float* lossmult; float* near; float* far;
+} mipnerf_rays_out;
+
+/* One camera for mipnerf_generate_rays: 32 floats =
+ * c2w[3][4] | pix2cam[3][3] | width, height, near, far, lossmult, mode, focal | 4 pad.
+ * mode 0: Blender pinhole formula with `focal` (datasets.py:226-228); mode 1: pix2cam matrix (datasets.py:125-131). */
+#define MIPNERF_CAMERA_FLOATS 32
+
 typedef struct mipnerf_ctx mipnerf_ctx;
 
 const char* mipnerf_last_error(void);
@@ -177,6 +187,13 @@ int mipnerf_sorted_piecewise_constant_pdf(int64_t num_rays, int32_t num_bins, co
                                           const float* weights, int32_t num_draws,
                                           const float* u_rand, float* samples, void* stream);
 
+/* ---- device-side ray generation (Blender._generate_rays datasets.py:214-263, Multicam._generate_rays :116-168):
+ * ray i = pixel pix_idx[i] (row-major y*W + x; NULL = pixel i) of camera cam_idx[i] (NULL = camera 0) of the
+ * `cameras` table [ncam][MIPNERF_CAMERA_FLOATS] (device memory).  Radii follow the reference: distance to the
+ * neighbouring pixel along image rows, last row repeated, times 2/sqrt(12). */
+int mipnerf_generate_rays(int64_t num_rays, const float* cameras, const int32_t* cam_idx,
+                          const int32_t* pix_idx, const mipnerf_rays_out* out, void* stream);
+
 /* ---- training side ---------------------------------------------------------------------- */
 /* activations (mip_nerf.py:236-238): raw [M,4] = (raw_rgb, raw_density) -> rgb_sigma [M,4]. */
 int mipnerf_activate(int64_t num_points, const float* raw, float rgb_padding, float density_bias,
@@ -199,7 +216,7 @@ int mipnerf_distloss(int64_t num_rays, int32_t num_samples, const float* weights
  * mipnerf_mlp_forward_train = mipnerf_mlp_forward (bf16) that also saves, per 32-sample wave tile, the
  * transposed activations of every layer input (`act`) and the ReLU bit masks (`masks`).
  * mipnerf_mlp_backward: d_raw [M,4] = dL/d(raw_rgb, raw_density) -> grad_flat [612,740] fp32, the gradients
- * of the 24 parameter tensors concatenated in state_dict order (OVERWRITTEN, not accumulated).  `delta` and
+ * of the 24 parameter tensors concatenated in state_dict order (accumulate = 0: overwritten; 1: added to).  `delta` and
  * `partials` are scratch.  Buffer sizes for M samples come from mipnerf_mlp_train_sizes. */
 int mipnerf_mlp_train_sizes(const mipnerf_ctx* ctx, int64_t num_points, size_t* act_bytes,
                             size_t* mask_bytes, size_t* delta_bytes, size_t* partial_bytes);
@@ -208,13 +225,17 @@ int mipnerf_mlp_forward_train(mipnerf_ctx* ctx, int64_t num_points, int32_t num_
                               void* act, void* masks, void* stream);
 int mipnerf_mlp_backward(mipnerf_ctx* ctx, int64_t num_points, const float* d_raw, const void* act,
                          const void* masks, void* delta, float* partials, float* grad_flat,
-                         void* stream);
+                         int32_t accumulate, void* stream);
 /* The two halves of mipnerf_mlp_backward, separately testable / timeable: delta chain (writes `delta`), and
  * weight gradients (reads act + delta; grad_flat may be NULL = leave the fp32 partials unreduced). */
 int mipnerf_mlp_dgrad(mipnerf_ctx* ctx, int64_t num_points, const float* d_raw, const void* masks,
                       void* delta, void* stream);
 int mipnerf_mlp_wgrad(mipnerf_ctx* ctx, int64_t num_points, const void* act, const void* delta,
-                      float* partials, float* grad_flat, void* stream);
+                      float* partials, float* grad_flat, int32_t accumulate, void* stream);
+/* torch.optim.Adam.step() of nerf_system.py:71-72 (betas, eps as given; no weight decay / amsgrad) over ONE flat
+ * buffer of n parameters: param, grad, exp_avg, exp_avg_sq [n] fp32; `step` = 1-based step count. */
+int mipnerf_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                      float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
 /* Tuning: workgroups per weight-gradient job (HOST array, 14 entries for the compiled MLP; 0 skips a job, for
  * timing only).  NULL restores the default.  Changes partial_bytes of mipnerf_mlp_train_sizes; synchronises. */
 int mipnerf_set_wgrad_splits(mipnerf_ctx* ctx, const int32_t* splits_host);

@@ -56,14 +56,16 @@ SIGNATURES = {
     "mipnerf_volumetric_rendering": (C.c_int, [_I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "mipnerf_resample_along_rays": (C.c_int, [_I64, _I32, _P, _P, _P, _F, _P, _P]),
     "mipnerf_sorted_piecewise_constant_pdf": (C.c_int, [_I64, _I32, _P, _P, _I32, _P, _P, _P]),
+    "mipnerf_generate_rays": (C.c_int, [_I64, _P, _P, _P, C.POINTER(RaysPtrs), _P]),
     "mipnerf_activate": (C.c_int, [_I64, _P, _F, _F, _P, _P]),
     "mipnerf_volumetric_rendering_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _F, _P, _P]),
     "mipnerf_distloss": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P]),
     "mipnerf_mlp_train_sizes": (C.c_int, [_P, _I64, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ)]),
     "mipnerf_mlp_forward_train": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
-    "mipnerf_mlp_backward": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "mipnerf_mlp_backward": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _P]),
+    "mipnerf_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _F, _F, _F, _F, _I32, _P]),
     "mipnerf_mlp_dgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P]),
-    "mipnerf_mlp_wgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
+    "mipnerf_mlp_wgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P]),
     "mipnerf_set_wgrad_splits": (C.c_int, [_P, _P]),
     "mipnerf_time_mlp": (C.c_int, [_P, _I64, _I32, _P, _P, C.c_int, _P, C.c_int, C.POINTER(_F), _P]),
     "mipnerf_selftest": (C.c_int, [_P]),

@@ -98,7 +98,7 @@ class _MLPNative(torch.autograd.Function):
                                                   raw.data_ptr(), act.data_ptr(), masks.data_ptr(), ops._stream()),
                 "mlp_forward_train")
         ctx.save_for_backward(act, masks)
-        ctx.nctx, ctx.M, ctx.sizes = nctx, M, sz
+        ctx.nctx, ctx.M, ctx.sizes, ctx.mlp = nctx, M, sz, mlp
         ctx.shapes = [p.shape for p in params]
         return raw
 
@@ -111,9 +111,18 @@ class _MLPNative(torch.autograd.Function):
         delta = nctx.scratch("delta", ctx.sizes[2])
         partials = nctx.scratch("partials", ctx.sizes[3])
         total = sum(int(torch.Size(s).numel()) for s in ctx.shapes)
+        mlp = ctx.mlp
+        if mlp.grads_are_flat():
+            # flat mode (MLP.flatten_parameters): the split reduction writes / adds straight into the buffer the
+            # parameters' .grad alias -- no per-tensor gradient tensors, no autograd accumulation kernels
+            L.check(L.lib().mipnerf_mlp_backward(nctx.handle, ctx.M, d_raw.data_ptr(), act.data_ptr(), masks.data_ptr(),
+                                                 delta.data_ptr(), partials.data_ptr(), mlp._flat_grad.data_ptr(),
+                                                 1 if mlp._flat_grad_valid else 0, ops._stream()), "mlp_backward")
+            mlp._flat_grad_valid = True
+            return (None, None, None) + (None,) * len(ctx.shapes)
         grad_flat = torch.empty(total, device=dev, dtype=torch.float32)
         L.check(L.lib().mipnerf_mlp_backward(nctx.handle, ctx.M, d_raw.data_ptr(), act.data_ptr(), masks.data_ptr(),
-                                             delta.data_ptr(), partials.data_ptr(), grad_flat.data_ptr(), ops._stream()),
+                                             delta.data_ptr(), partials.data_ptr(), grad_flat.data_ptr(), 0, ops._stream()),
                 "mlp_backward")
         grads, off = [], 0
         for shp in ctx.shapes:

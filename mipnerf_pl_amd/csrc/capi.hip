@@ -420,6 +420,17 @@ int mipnerf_sorted_piecewise_constant_pdf(int64_t B, int32_t nbins, const float*
     return MIPNERF_OK;
 }
 
+// ---- device-side ray generation (datasets/datasets.py:116-168, 214-263) ---------------------------------------
+int mipnerf_generate_rays(int64_t n, const float* cameras, const int32_t* cam_idx, const int32_t* pix_idx,
+                          const mipnerf_rays_out* out, void* stream) {
+    if (n < 1 || !cameras || !out || !out->origins || !out->directions || !out->viewdirs || !out->radii ||
+        !out->lossmult || !out->near || !out->far)
+        return fail(MIPNERF_E_INVALID, "generate_rays: bad argument");
+    HIP_TRY(mip::launch_generate_rays(n, cameras, cam_idx, pix_idx, out->origins, out->directions, out->viewdirs,
+                                      out->radii, out->lossmult, out->near, out->far, S(stream)));
+    return MIPNERF_OK;
+}
+
 // ---- training-side entry points ------------------------------------------------------------------
 int mipnerf_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, float* rgb_sigma, void* stream) {
     if (M < 1 || !raw || !rgb_sigma) return fail(MIPNERF_E_INVALID, "activate: bad argument");
@@ -475,22 +486,30 @@ int mipnerf_mlp_dgrad(mipnerf_ctx* c, int64_t M, const float* d_raw, const void*
 }
 
 int mipnerf_mlp_wgrad(mipnerf_ctx* c, int64_t M, const void* act, const void* delta, float* partials, float* grad_flat,
-                      void* stream) {
+                      int32_t accumulate, void* stream) {
     if (!c || M < 1 || !act || !delta || !partials) return fail(MIPNERF_E_INVALID, "mlp_wgrad: bad argument");
     const int64_t n_wt = ((M + 255) / 256) * 8;
     HIP_TRY(mip::launch_mlp_wgrad(act, delta, c->d_jobs, c->d_wgtab, c->num_wgrad_wgs, n_wt, c->tt.NH, c->tt.NG, partials,
                                   S(stream)));
     if (grad_flat)
-        HIP_TRY(mip::launch_wgrad_reduce(partials, c->d_otab, c->d_jobslots, c->tt.njobs, grad_flat, S(stream)));
+        HIP_TRY(mip::launch_wgrad_reduce(partials, c->d_otab, c->d_jobslots, c->tt.njobs, grad_flat, accumulate != 0,
+                                         S(stream)));
     return MIPNERF_OK;
 }
 
 int mipnerf_mlp_backward(mipnerf_ctx* c, int64_t M, const float* d_raw, const void* act, const void* masks, void* delta,
-                         float* partials, float* grad_flat, void* stream) {
+                         float* partials, float* grad_flat, int32_t accumulate, void* stream) {
     if (!grad_flat) return fail(MIPNERF_E_INVALID, "mlp_backward: grad_flat is null");
     int rc = mipnerf_mlp_dgrad(c, M, d_raw, masks, delta, stream);
     if (rc) return rc;
-    return mipnerf_mlp_wgrad(c, M, act, delta, partials, grad_flat, stream);
+    return mipnerf_mlp_wgrad(c, M, act, delta, partials, grad_flat, accumulate, stream);
+}
+
+int mipnerf_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                      float beta2, float eps, int32_t step, void* stream) {
+    if (n < 1 || !param || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail(MIPNERF_E_INVALID, "adam_step: bad argument");
+    HIP_TRY(mip::launch_adam_flat(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, S(stream)));
+    return MIPNERF_OK;
 }
 
 // Replace the wgrad work split: splits_host[njobs] workgroups per job (0 = skip the job: its gradients are then

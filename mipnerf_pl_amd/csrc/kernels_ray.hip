@@ -500,3 +500,71 @@ hipError_t launch_piecewise_constant_pdf(int64_t B, int N, const float* bins, co
 }
 
 }  // namespace mip
+
+// ---- device-side ray generation ----------------------------------------------------------------
+// datasets/datasets.py:214-263 (Blender._generate_rays) and :116-168 (Multicam._generate_rays) computed per pixel
+// on the device instead of materialising 52 B/ray for every pixel of every image on the host.
+// camera record (32 floats): c2w[3][4] | pix2cam[3][3] | W, H, near, far, lossmult, mode, focal | pad
+//   mode 0 (Blender): camera_dir = ((x - W/2 + .5)/focal, -(y - H/2 + .5)/focal, -1)        datasets.py:226-228
+//   mode 1 (Multicam): camera_dir = pix2cam @ (x + .5, y + .5, 1)                             datasets.py:125-131
+// direction = c2w[:3,:3] @ camera_dir; origin = c2w[:3,3]; viewdir = direction / |direction|;
+// radius = |direction(y, x) - direction(y+1, x)| * 2/sqrt(12), last row repeats the previous one (datasets.py:246-253:
+// the neighbour is taken along axis 0 = image rows).
+namespace mip {
+namespace {
+__device__ __forceinline__ void pixel_direction(const float* __restrict__ cam, float x, float y, float d[3]) {
+    float c0, c1, c2;
+    if (cam[26] == 0.0f) {
+        const float W = cam[21], H = cam[22], f = cam[27];
+        c0 = (x - W * 0.5f + 0.5f) / f;
+        c1 = -(y - H * 0.5f + 0.5f) / f;
+        c2 = -1.0f;
+    } else {
+        const float px = x + 0.5f, py = y + 0.5f;
+        c0 = cam[12] * px + cam[13] * py + cam[14];
+        c1 = cam[15] * px + cam[16] * py + cam[17];
+        c2 = cam[18] * px + cam[19] * py + cam[20];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = cam[4 * i] * c0 + cam[4 * i + 1] * c1 + cam[4 * i + 2] * c2;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256)
+k_generate_rays(int64_t n, const float* __restrict__ cams, const int32_t* __restrict__ cam_idx,
+                const int32_t* __restrict__ pix_idx, float* __restrict__ origins, float* __restrict__ directions,
+                float* __restrict__ viewdirs, float* __restrict__ radii, float* __restrict__ lossmult,
+                float* __restrict__ nearp, float* __restrict__ farp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* cam = cams + (size_t)(cam_idx ? cam_idx[i] : 0) * 32;
+    const int W = (int)cam[21], H = (int)cam[22];
+    const int p = pix_idx ? pix_idx[i] : (int)i;
+    const int yy = p / W, xx = p - yy * W;
+    float d[3], dn[3];
+    pixel_direction(cam, (float)xx, (float)yy, d);
+    const int yn = yy + 1 < H ? yy + 1 : yy - 1;
+    pixel_direction(cam, (float)xx, (float)yn, dn);
+    const float e0 = d[0] - dn[0], e1 = d[1] - dn[1], e2 = d[2] - dn[2];
+    const float dx = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+    const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        origins[i * 3 + k] = cam[4 * k + 3];
+        directions[i * 3 + k] = d[k];
+        viewdirs[i * 3 + k] = d[k] / nrm;
+    }
+    radii[i] = dx * 2.0f / 3.4641016151377544f;
+    lossmult[i] = cam[25];
+    nearp[i] = cam[23];
+    farp[i] = cam[24];
+}
+
+hipError_t launch_generate_rays(int64_t n, const float* cams, const int32_t* cam_idx, const int32_t* pix_idx,
+                                float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
+                                float* nearp, float* farp, hipStream_t st) {
+    hipLaunchKernelGGL(k_generate_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, cams, cam_idx, pix_idx,
+                       origins, directions, viewdirs, radii, lossmult, nearp, farp);
+    return hipGetLastError();
+}
+}  // namespace mip

@@ -3,6 +3,7 @@
 // (models/mip_nerf.py:236-238), and the distortion loss (models/mip.py:8-20) forward/backward in O(N)
 // per ray (the reference builds two [B,N,N] tensors).  One wavefront per ray, scans in fp64.
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #include "kernels.hpp"
 #include "raymath.hpp"
@@ -226,4 +227,31 @@ hipError_t launch_distloss(int64_t B, int N, const float* weights, const float* 
     return hipGetLastError();
 }
 
+
+// ---- fused Adam over one flat parameter buffer -----------------------------------------------------
+// torch.optim.Adam(params, lr) as the reference configures it (nerf_system.py:71-72: betas (0.9, 0.999), eps 1e-8, no
+// weight decay, no amsgrad), same operation order as torch's single-tensor implementation:
+//   m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void __launch_bounds__(256)
+k_adam_flat(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+hipError_t launch_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
+                            float eps, int step, hipStream_t st) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(k_adam_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, lr, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2));
+    return hipGetLastError();
+}
 }  // namespace mip

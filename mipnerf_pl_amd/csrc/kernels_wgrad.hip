@@ -126,7 +126,7 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
 // grad[idx] = sum over the job's splits of the partial at `pos`, for every position that feeds a parameter
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ partials, const int32_t* __restrict__ otab, const int2* __restrict__ job_slots,
-               float* __restrict__ grad_flat) {
+               float* __restrict__ grad_flat, int accumulate) {
     const int job = blockIdx.y;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= kWgradJobFloats) return;
@@ -136,7 +136,7 @@ k_wgrad_reduce(const float* __restrict__ partials, const int32_t* __restrict__ o
     const float* p = partials + (int64_t)js.x * kWgradJobFloats + pos;
     float s = 0.0f;
     for (int k = 0; k < js.y; ++k) s += p[(int64_t)k * kWgradJobFloats];
-    grad_flat[idx] = s;
+    grad_flat[idx] = accumulate ? grad_flat[idx] + s : s;     // every parameter has exactly one source position
 }
 
 int mlp_wgrad_lds_bytes() { return kWgradLds; }
@@ -155,9 +155,9 @@ hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs
 }
 
 hipError_t launch_wgrad_reduce(const float* partials, const int32_t* otab, const void* job_slots, int njobs,
-                               float* grad_flat, hipStream_t st) {
+                               float* grad_flat, bool accumulate, hipStream_t st) {
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((kWgradJobFloats + 255) / 256, njobs), dim3(256), 0, st, partials, otab,
-                       (const int2*)job_slots, grad_flat);
+                       (const int2*)job_slots, grad_flat, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -141,6 +141,73 @@ class MLP(torch.nn.Module):
         self._cfg_extra = {}
         self.precision = L.PREC_BF16
 
+    # -- flat parameter / gradient storage (opt-in: FlatAdam, FlatGradAllReduce, zero-copy wgrad reduction) -------
+    def flatten_parameters(self):
+        """Re-home the 24 parameters (and their .grad) as views of ONE flat fp32 buffer each, in state_dict order.
+        Call after the module is on its device.  Names, shapes, leaf-ness and state_dict() are unchanged."""
+        params = self.ordered_params()
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, device=dev, dtype=torch.float32)
+        gflat = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.detach().reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = gflat[off:off + n].view(p.shape)
+            off += n
+        self._flat_param, self._flat_grad = flat, gflat
+        self._flat_grad_valid = False
+        self.invalidate_packed()
+        return self
+
+    def is_flat(self) -> bool:
+        flat = getattr(self, "_flat_param", None)
+        if flat is None:
+            return False
+        off = 0
+        for p in self.ordered_params():
+            if p.data_ptr() != flat.data_ptr() + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    def grads_are_flat(self) -> bool:
+        g = getattr(self, "_flat_grad", None)
+        if g is None or not self.is_flat():
+            return False
+        off = 0
+        for p in self.ordered_params():
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr() + 4 * off:
+                return False
+            off += p.numel()
+        return True
+
+    def gather_foreign_grads(self):
+        """If autograd / a caller replaced some p.grad (e.g. zero_grad(set_to_none=True) followed by a backward through
+        the generic path), copy those into the flat buffer and re-attach the views."""
+        g = getattr(self, "_flat_grad", None)
+        if g is None:
+            return
+        off, any_grad = 0, False
+        for p in self.ordered_params():
+            n = p.numel()
+            view = g[off:off + n].view(p.shape)
+            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                any_grad = True
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                p.grad = view
+            off += n
+        if any_grad:
+            self._flat_grad_valid = True
+
+    def invalidate_packed(self):
+        """Force a re-pack of the MFMA weight streams (parameters changed without bumping tensor versions)."""
+        if self._ctx is not None:
+            self._ctx._packed_key = None
+
     # -- native context ------------------------------------------------------------------------
     def ordered_params(self):
         """state_dict order of the reference MLP = order mipnerf_set_params expects."""

@@ -173,6 +173,46 @@ def volumetric_rendering_packed(rgb_sigma, t_samples, dirs, white_bkgd):
     return comp_rgb, distance, acc, weights
 
 
+def camera_record(c2w, width, height, near, far, focal=None, pix2cam=None, lossmult=1.0):
+    """One row of the camera table of `generate_rays` (32 floats, include/mipnerf_hip.h): Blender pinhole camera
+    when `focal` is given (datasets.py:226-228), Multicam when `pix2cam` is given (datasets.py:125-131)."""
+    rec = torch.zeros(32, dtype=torch.float32)
+    rec[0:12] = torch.as_tensor(c2w, dtype=torch.float32)[:3, :4].reshape(-1)
+    if (focal is None) == (pix2cam is None):
+        raise ValueError("give exactly one of focal (Blender) / pix2cam (Multicam)")
+    if pix2cam is not None:
+        rec[12:21] = torch.as_tensor(pix2cam, dtype=torch.float32)[:3, :3].reshape(-1)
+        rec[26] = 1.0
+    else:
+        rec[27] = float(focal)
+    rec[21], rec[22], rec[23], rec[24], rec[25] = float(width), float(height), float(near), float(far), float(lossmult)
+    return rec
+
+
+def generate_rays(cameras, num_rays=None, cam_idx=None, pix_idx=None):
+    """Rays of datasets.py:214-263 / 116-168 computed on the device: `cameras` [ncam, 32] float32 HIP tensor of
+    `camera_record` rows, ray i = pixel pix_idx[i] (y*W + x; None = i) of camera cam_idx[i] (None = 0)."""
+    from .rays import Rays
+    cameras = _f32c(cameras, "cameras").reshape(-1, 32)
+    dev = cameras.device
+    if num_rays is None:
+        num_rays = int(pix_idx.numel()) if pix_idx is not None else int(cameras[0, 21].item() * cameras[0, 22].item())
+
+    def i32(t, name):
+        if t is None:
+            return None
+        if not t.is_cuda:
+            raise RuntimeError(f"{name}: needs a HIP device tensor")
+        return t.to(torch.int32).contiguous()
+    ci, pi = i32(cam_idx, "cam_idx"), i32(pix_idx, "pix_idx")
+    out = [torch.empty(num_rays, k, device=dev, dtype=torch.float32) for k in (3, 3, 3, 1, 1, 1, 1)]
+    rp = L.RaysPtrs(*[t.data_ptr() for t in out])
+    import ctypes as C
+    L.check(L.lib().mipnerf_generate_rays(num_rays, _ptr(cameras), _ptr(ci), _ptr(pi), C.byref(rp), _stream()),
+            "generate_rays")
+    return Rays(*out)
+
+
 def selftest() -> str:
     """Run the hardware self-test (MFMA lane layouts, LDS DMA); returns the report, raises on failure."""
     rc = L.lib().mipnerf_selftest(_stream())

@@ -29,13 +29,19 @@ def shard_rays(rays, rank: int, world: int):
 class FlatGradAllReduce:
     """One-buffer gradient all-reduce (mean) for a fixed parameter list."""
 
-    def __init__(self, params: Sequence[torch.nn.Parameter]):
+    def __init__(self, params: Sequence[torch.nn.Parameter], mlp=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
+        self.mlp = mlp      # optional: an MLP in flat mode (MLP.flatten_parameters) -> its gradient buffer is reduced in place
 
     def __call__(self, group=None) -> None:
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        if self.mlp is not None and self.mlp.grads_are_flat():
+            g = self.mlp._flat_grad
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+            g.div_(dist.get_world_size(group))
             return
         p0 = self.params[0]
         if self.flat is None or self.flat.device != p0.device:

@@ -112,7 +112,12 @@ class MipNeRFSystem(_Base):
                                    batch_type=self.hparams['val.batch_type'])
 
     def configure_optimizers(self):   # nerf_system.py:70-76
-        optimizer = torch.optim.Adam(self.mip_nerf.parameters(), lr=self.hparams['optimizer.lr_init'])
+        if getattr(self, "fused_adam", False):
+            # same update rule as torch.optim.Adam below, one HIP kernel over the flat parameter buffer
+            from .optim import FlatAdam
+            optimizer = FlatAdam(self.mip_nerf.mlp, lr=self.hparams['optimizer.lr_init'])
+        else:
+            optimizer = torch.optim.Adam(self.mip_nerf.parameters(), lr=self.hparams['optimizer.lr_init'])
         scheduler = MipLRDecay(optimizer, self.hparams['optimizer.lr_init'], self.hparams['optimizer.lr_final'],
                                self.hparams['optimizer.max_steps'], self.hparams['optimizer.lr_delay_steps'],
                                self.hparams['optimizer.lr_delay_mult'])

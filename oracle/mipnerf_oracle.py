@@ -445,6 +445,35 @@ def calc_psnr(x, y):
 
 
 # ------------------------------------------------------------------ synthetic inputs
+def generate_rays_blender(c2w, width, height, focal, near, far):
+    """datasets/datasets.py:214-263 (Blender._generate_rays) for ONE camera: Rays of [H, W, k] float32."""
+    x, y = np.meshgrid(np.arange(width, dtype=F32), np.arange(height, dtype=F32), indexing="xy")
+    focal = F32(focal)
+    camera_dirs = np.stack([(x - F32(width * 0.5) + F32(0.5)) / focal,
+                            -(y - F32(height * 0.5) + F32(0.5)) / focal, -np.ones_like(x)], axis=-1).astype(F32)
+    return _finish_rays(camera_dirs, np.asarray(c2w, F32), F32(1), near, far)
+
+
+def generate_rays_multicam(c2w, pix2cam, width, height, near, far, lossmult):
+    """datasets/datasets.py:116-168 (Multicam._generate_rays) for ONE camera."""
+    x, y = np.meshgrid(np.arange(width, dtype=F32) + F32(.5), np.arange(height, dtype=F32) + F32(.5), indexing="xy")
+    pixel_dirs = np.stack([x, y, np.ones_like(x)], axis=-1)
+    camera_dirs = (pixel_dirs @ np.asarray(pix2cam, F32)[:3, :3].T).astype(F32)
+    return _finish_rays(camera_dirs, np.asarray(c2w, F32), lossmult, near, far)
+
+
+def _finish_rays(camera_dirs, c2w, lossmult, near, far):
+    directions = (camera_dirs @ c2w[:3, :3].T).astype(F32)
+    origins = np.broadcast_to(c2w[:3, -1], directions.shape).astype(F32)
+    viewdirs = (directions / np.linalg.norm(directions, axis=-1, keepdims=True)).astype(F32)
+    dx = np.sqrt(np.sum((directions[:-1] - directions[1:]) ** 2, -1))        # neighbour along axis 0 (rows)
+    dx = np.concatenate([dx, dx[-2:-1]], 0)
+    radii = (dx[..., None] * F32(2) / np.sqrt(F32(12))).astype(F32)
+    ones = np.ones_like(origins[..., :1])
+    return Rays(origins, directions, viewdirs, radii, (F32(lossmult) * ones).astype(F32),
+                (F32(near) * ones).astype(F32), (F32(far) * ones).astype(F32))
+
+
 def synthetic_rays(batch, seed=0, multiscale=False, unbounded=False):
     """Lego-like synthetic rays, SURVEY.md section 8(d): camera on a radius-4 sphere
     looking at the origin, focal 1111.11, pixel offsets U[-400,400], radii 5.2e-4,

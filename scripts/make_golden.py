@@ -225,8 +225,62 @@ def mlp_grad_case(name, batch, num_samples, param_seed, gain, seed):
     print(f"wrote {name}.npz  oracle.mlp_backward vs reference autograd rel max err {worst:.2e}")
 
 
+def raygen_case(name):
+    """Ray-generation golden: the reference's Blender._generate_rays / Multicam._generate_rays (datasets.py:214-263,
+    116-168) called unbound on stub objects (no images on disk needed)."""
+    from datasets.datasets import Blender, Multicam
+    rng = np.random.default_rng(11)
+
+    def pose():
+        a = rng.normal(size=(3, 3))
+        q, _ = np.linalg.qr(a)
+        c2w = np.eye(4, dtype=np.float32)
+        c2w[:3, :3] = q.astype(np.float32)
+        c2w[:3, 3] = (4.0 * q[:, 2]).astype(np.float32)
+        return c2w
+    W, H = 20, 14
+    focal = .5 * W / np.tan(.5 * 0.6911112070083618)
+    out = dict(width=W, height=H, focal=np.float64(focal), near=2.0, far=6.0)
+    stub = types.SimpleNamespace(w=W, h=H, focal=focal, camtoworlds=[pose(), pose()], images=[None, None], near=2., far=6.)
+    Blender._generate_rays(stub)
+    out["blender_c2w"] = np.stack(stub.camtoworlds)
+    for k in RefRays._fields:
+        out["blender_" + k] = np.stack([np.asarray(v, dtype=np.float64) for v in getattr(stub.rays, k)])
+    # Multicam: two scales of one camera, pix2cam as written by the mip-NeRF converter (inverse intrinsics, y/z flipped)
+    metas = dict(pix2cam=[], cam2world=[], width=[], height=[], lossmult=[], near=[], far=[])
+    for scale in (0, 1):
+        w, h, f = W // 2 ** scale, H // 2 ** scale, focal / 2 ** scale
+        p2c = np.array([[1 / f, 0, -.5 * w / f], [0, -1 / f, .5 * h / f], [0, 0, -1.]], np.float64)
+        metas["pix2cam"].append(p2c); metas["cam2world"].append(pose()[:3, :4]); metas["width"].append(w)
+        metas["height"].append(h); metas["lossmult"].append(4.0 ** scale); metas["near"].append(2.0); metas["far"].append(6.0)
+    stub = types.SimpleNamespace(meta={k: np.array(v) if k not in ("pix2cam", "cam2world") else np.stack(v)
+                                       for k, v in metas.items()}, images=[None, None])
+    Multicam._generate_rays(stub)
+    out["multicam_pix2cam"] = np.stack(metas["pix2cam"])
+    out["multicam_c2w"] = np.stack(metas["cam2world"])
+    for i in range(2):
+        for k in RefRays._fields:
+            out[f"multicam{i}_" + k] = np.asarray(getattr(stub.rays, k)[i], dtype=np.float64)
+    # the oracle restatement against it
+    for i in range(2):
+        o = orc.generate_rays_blender(out["blender_c2w"][i], W, H, focal, 2.0, 6.0)
+        for k in RefRays._fields:
+            d = maxdiff(getattr(o, k), out["blender_" + k][i])
+            assert d < 2e-6, ("blender", k, d)
+        w, h = metas["width"][i], metas["height"][i]
+        o = orc.generate_rays_multicam(metas["cam2world"][i], metas["pix2cam"][i], w, h, 2.0, 6.0, metas["lossmult"][i])
+        for k in RefRays._fields:
+            d = maxdiff(getattr(o, k), out[f"multicam{i}_" + k])
+            assert d < 2e-6, ("multicam", k, d)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
+    if "--only-raygen" in sys.argv:         # added after the other files were frozen
+        raygen_case("raygen_20x14")
+        sys.exit(0)
     if "--only-mlp-grad" in sys.argv:       # added after the other files were frozen
         mlp_grad_case("mlp_bwd_8x32_trained", 8, 32, param_seed=8, gain=40.0, seed=8)
         sys.exit(0)
@@ -246,4 +300,5 @@ if __name__ == "__main__":
     stage_case("stages_16x64_trained", 16, 64, param_seed=6, gain=40.0, ray_seed=6)
     grad_case("train_64x64_trained", 64, 64, param_seed=7, gain=40.0, ray_seed=7)
     mlp_grad_case("mlp_bwd_8x32_trained", 8, 32, param_seed=8, gain=40.0, seed=8)
+    raygen_case("raygen_20x14")
     print("done")

@@ -75,10 +75,10 @@ def main():
         L.check(lib.mipnerf_mlp_dgrad(h, M, d_raw.data_ptr(), masks.data_ptr(), delta.data_ptr(), st))
 
     def wgrad():
-        L.check(lib.mipnerf_mlp_wgrad(h, M, act.data_ptr(), delta.data_ptr(), part.data_ptr(), grad.data_ptr(), st))
+        L.check(lib.mipnerf_mlp_wgrad(h, M, act.data_ptr(), delta.data_ptr(), part.data_ptr(), grad.data_ptr(), 0, st))
 
     def wgrad_noreduce():
-        L.check(lib.mipnerf_mlp_wgrad(h, M, act.data_ptr(), delta.data_ptr(), part.data_ptr(), None, st))
+        L.check(lib.mipnerf_mlp_wgrad(h, M, act.data_ptr(), delta.data_ptr(), part.data_ptr(), None, 0, st))
 
     def infer():
         L.check(lib.mipnerf_mlp_forward(h, M, N, enc.data_ptr(), venc.data_ptr(), L.PREC_BF16, rgbs.data_ptr(), None, st))

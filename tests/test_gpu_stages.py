@@ -226,3 +226,35 @@ def test_sorted_piecewise_constant_pdf_edge_cases(G, stage):
     e = G.maxdiff(out, g["pdf_t"])
     G.record("pdf_edge_cases", t=e)
     assert e <= 5e-6
+
+
+def test_generate_rays_matches_reference(G):
+    """Device-side ray generation vs the reference's Blender / Multicam `_generate_rays` goldens:
+    whole images, and a random (camera, pixel) gather as a training batch would draw it."""
+    from mipnerf_pl_amd import ops
+    g = G.load_golden("raygen_20x14")
+    W, H, focal = int(g["width"]), int(g["height"]), float(g["focal"])
+    cams = [ops.camera_record(g["blender_c2w"][i], W, H, 2.0, 6.0, focal=focal) for i in range(2)]
+    cams += [ops.camera_record(g["multicam_c2w"][i], W // 2 ** i, H // 2 ** i, 2.0, 6.0, pix2cam=g["multicam_pix2cam"][i],
+                               lossmult=4.0 ** i) for i in range(2)]
+    table = torch.stack(cams).to(G.DEV)
+    worst = 0.0
+    for ci, (prefix, idx) in enumerate([("blender_", 0), ("blender_", 1), ("multicam0_", None), ("multicam1_", None)]):
+        w, h = int(cams[ci][21]), int(cams[ci][22])
+        cidx = torch.full((w * h,), ci, dtype=torch.int32, device=G.DEV)
+        rays = ops.generate_rays(table, num_rays=w * h, cam_idx=cidx)
+        for k in orc.Rays._fields:
+            ref = g[prefix + k] if idx is None else g[prefix + k][idx]
+            e = G.maxdiff(getattr(rays, k).reshape(h, w, -1), ref.astype(np.float32))
+            worst = max(worst, e)
+            assert e <= 3e-6, (prefix, k, e)
+    # random gather over cameras 0/1
+    rng = np.random.default_rng(0)
+    n = 777
+    ci = rng.integers(0, 2, n)
+    pi = rng.integers(0, W * H, n)
+    rays = ops.generate_rays(table, cam_idx=torch.from_numpy(ci).to(G.DEV), pix_idx=torch.from_numpy(pi).to(G.DEV))
+    for k in orc.Rays._fields:
+        ref = g["blender_" + k].reshape(2, W * H, -1)[ci, pi].astype(np.float32)
+        assert G.maxdiff(getattr(rays, k), ref) <= 3e-6, k
+    G.record("generate_rays", worst=worst)

@@ -298,3 +298,47 @@ def test_render_image_hip_graph_equals_eager(G):
     system.enable_hip_graph(False)
     e2 = system.render_image((img_rays, rgbs))
     assert torch.equal(g2[1], e2[1]) and not torch.equal(g2[1], eager[1])
+
+
+def _train_system(G, g, fused):
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({'nerf.num_samples': 64, 'train.randomized': False, 'optimizer.lr_delay_steps': 3, 'optimizer.max_steps': 10})
+    system = MipNeRFSystem(hp, precision="bf16")
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    system = system.to(DEV)
+    system.fused_adam = fused
+    (opt,), (sch,) = system.configure_optimizers()
+    return system, opt, sch["scheduler"]
+
+
+def test_flat_adam_equals_torch_adam(G):
+    """flat gradient buffer (written by the wgrad reduction, both levels accumulated in place) + one fused
+    Adam kernel + MipLRDecay == torch.optim.Adam on per-tensor autograd gradients, step for step."""
+    g = G.load_golden("train_64x64_trained")
+    rays, gt = G.to_dev(G.rays_of(g)), torch.from_numpy(g["gt"]).to(DEV)
+    runs = {}
+    for fused in (False, True):
+        system, opt, sch = _train_system(G, g, fused)
+        assert system.mip_nerf.mlp.is_flat() == fused
+        losses, grads = [], None
+        for it in range(4):
+            opt.zero_grad()
+            loss = system.training_step((rays, gt), it)
+            loss.backward()
+            if it == 0:
+                grads = torch.cat([p.grad.reshape(-1) for p in system.mip_nerf.parameters()]).clone()
+            opt.step()
+            sch.step()
+            losses.append(float(loss))
+        runs[fused] = (losses, grads, torch.cat([p.detach().reshape(-1) for p in system.mip_nerf.parameters()]).clone(),
+                       list(system.mip_nerf.state_dict().keys()))
+    (l0, g0, p0, k0), (l1, g1, p1, k1) = runs[False], runs[True]
+    assert k0 == k1
+    eg = G.maxdiff(g0, g1) / float(g0.abs().max())
+    ep = G.maxdiff(p0, p1)
+    G.record("flat_adam_vs_torch_adam", grad_rel=eg, param_abs=ep, loss0=l0[-1], loss1=l1[-1])
+    assert eg <= 1e-6                     # same kernels; only (a + b) association of the two levels could differ
+    assert ep <= 2e-6 and abs(l0[-1] - l1[-1]) <= 1e-5 * max(1.0, abs(l0[-1]))
+    assert l0[-1] != l0[0]                # the weights did move (re-pack after the raw-kernel update is effective)

@@ -150,3 +150,17 @@ def test_mlp_backward_matches_reference_autograd(golden_dir):
     grads = orc.mlp_backward(params, g["enc"], g["venc"], g["d_rgb"], g["d_den"])
     assert list(grads) == list(params)
     grad_check(g, grads, 1e-5, 1e-5)
+
+
+def test_ray_generation_matches_reference(golden_dir):
+    """datasets.py:214-263 (Blender) and :116-168 (Multicam) ray generation, oracle vs the reference's own output."""
+    g = load(golden_dir, "raygen_20x14")
+    W, H, focal = int(g["width"]), int(g["height"]), float(g["focal"])
+    for i in range(2):
+        o = orc.generate_rays_blender(g["blender_c2w"][i], W, H, focal, float(g["near"]), float(g["far"]))
+        for k in orc.Rays._fields:
+            np.testing.assert_allclose(getattr(o, k), g["blender_" + k][i], atol=2e-6, err_msg=f"blender {k}")
+        w, h = W // 2 ** i, H // 2 ** i
+        o = orc.generate_rays_multicam(g["multicam_c2w"][i], g["multicam_pix2cam"][i], w, h, 2.0, 6.0, 4.0 ** i)
+        for k in orc.Rays._fields:
+            np.testing.assert_allclose(getattr(o, k), g[f"multicam{i}_" + k], atol=2e-6, err_msg=f"multicam {k}")
