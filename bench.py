@@ -54,11 +54,14 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if os.environ.get("MIPNERF_BENCH_SHARE_GPU") == "1":     # plumbing test on a 1-GPU box: every rank on cuda:0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm; the override exists only for the shared-GPU plumbing test (RCCL refuses two ranks per GPU)
+        dist.init_process_group(os.environ.get("MIPNERF_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     B, N = args.rays, args.samples
     rays_np = orc.synthetic_rays(B, seed=100 + rank)
