@@ -194,6 +194,13 @@ int mipnerf_sorted_piecewise_constant_pdf(int64_t num_rays, int32_t num_bins, co
 int mipnerf_generate_rays(int64_t num_rays, const float* cameras, const int32_t* cam_idx,
                           const int32_t* pix_idx, const mipnerf_rays_out* out, void* stream);
 
+/* ---- evaluation metrics: eval_errors (utils/metrics.py:191-197) on one frame: pred, gt [H,W,3] fp32 in [0,1];
+ * out[0] = PSNR (metrics.py:182-188), out[1] = mean SSIM, 11x11 Gaussian window sigma 1.5, zero padding
+ * (metrics.py:44-126).  workspace: mipnerf_eval_workspace_floats(H, W) floats. */
+int64_t mipnerf_eval_workspace_floats(int32_t height, int32_t width);
+int mipnerf_eval_errors(int32_t height, int32_t width, const float* pred, const float* gt,
+                        float* workspace, float* out_psnr_ssim, void* stream);
+
 /* ---- training side ---------------------------------------------------------------------- */
 /* activations (mip_nerf.py:236-238): raw [M,4] = (raw_rgb, raw_density) -> rgb_sigma [M,4]. */
 int mipnerf_activate(int64_t num_points, const float* raw, float rgb_padding, float density_bias,

@@ -57,6 +57,8 @@ SIGNATURES = {
     "mipnerf_resample_along_rays": (C.c_int, [_I64, _I32, _P, _P, _P, _F, _P, _P]),
     "mipnerf_sorted_piecewise_constant_pdf": (C.c_int, [_I64, _I32, _P, _P, _I32, _P, _P, _P]),
     "mipnerf_generate_rays": (C.c_int, [_I64, _P, _P, _P, C.POINTER(RaysPtrs), _P]),
+    "mipnerf_eval_workspace_floats": (_I64, [_I32, _I32]),
+    "mipnerf_eval_errors": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P]),
     "mipnerf_activate": (C.c_int, [_I64, _P, _F, _F, _P, _P]),
     "mipnerf_volumetric_rendering_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _F, _P, _P]),
     "mipnerf_distloss": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P]),

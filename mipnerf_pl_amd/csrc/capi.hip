@@ -431,6 +431,18 @@ int mipnerf_generate_rays(int64_t n, const float* cameras, const int32_t* cam_id
     return MIPNERF_OK;
 }
 
+// ---- evaluation metrics (utils/metrics.py:191-197) ---------------------------------------------------------------
+int64_t mipnerf_eval_workspace_floats(int32_t height, int32_t width) {
+    return height > 0 && width > 0 ? mip::eval_errors_partial_floats(height, width) : 0;
+}
+
+int mipnerf_eval_errors(int32_t H, int32_t W, const float* pred, const float* gt, float* workspace, float* out_psnr_ssim,
+                        void* stream) {
+    if (H < 1 || W < 1 || !pred || !gt || !workspace || !out_psnr_ssim) return fail(MIPNERF_E_INVALID, "eval_errors: bad argument");
+    HIP_TRY(mip::launch_eval_errors(H, W, pred, gt, workspace, out_psnr_ssim, S(stream)));
+    return MIPNERF_OK;
+}
+
 // ---- training-side entry points ------------------------------------------------------------------
 int mipnerf_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, float* rgb_sigma, void* stream) {
     if (M < 1 || !raw || !rgb_sigma) return fail(MIPNERF_E_INVALID, "activate: bad argument");

@@ -213,6 +213,25 @@ def generate_rays(cameras, num_rays=None, cam_idx=None, pix_idx=None):
     return Rays(*out)
 
 
+def eval_errors(pred_color, batch_pixels):
+    """utils/metrics.py:191-197: (psnr, ssim) of one rendered frame, pred/gt [1,H,W,3] (or [H,W,3]) fp32 HIP tensors;
+    one fused kernel instead of six conv2d passes.  Returns two 0-d tensors."""
+    a = _f32c(pred_color, "pred_color")
+    b = _f32c(batch_pixels, "batch_pixels")
+    if a.dim() == 4:
+        if a.shape[0] != 1:
+            raise NotImplementedError("eval_errors: one frame at a time (eval.py evaluates image by image)")
+        a, b = a[0], b[0]
+    if a.shape != b.shape or a.dim() != 3 or a.shape[-1] != 3:
+        raise ValueError("eval_errors: expected matching [H,W,3] images")
+    H, W = int(a.shape[0]), int(a.shape[1])
+    ws = torch.empty(int(L.lib().mipnerf_eval_workspace_floats(H, W)), device=a.device, dtype=torch.float32)
+    out = torch.empty(2, device=a.device, dtype=torch.float32)
+    L.check(L.lib().mipnerf_eval_errors(H, W, _ptr(a.contiguous()), _ptr(b.contiguous()), _ptr(ws), _ptr(out), _stream()),
+            "eval_errors")
+    return out[0], out[1]
+
+
 def selftest() -> str:
     """Run the hardware self-test (MFMA lane layouts, LDS DMA); returns the report, raises on failure."""
     rc = L.lib().mipnerf_selftest(_stream())

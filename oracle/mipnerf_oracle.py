@@ -445,6 +445,30 @@ def calc_psnr(x, y):
 
 
 # ------------------------------------------------------------------ synthetic inputs
+def eval_errors(pred, gt):
+    """utils/metrics.py:191-197: (psnr, mean ssim) of [H,W,3] images; SSIM = metrics.py:44-126 with the 11x11 Gaussian
+    window of metrics.py:10-41 (sigma 1.5), zero padding 5, C1 = 0.01^2, C2 = 0.03^2."""
+    pred, gt = np.asarray(pred, np.float64), np.asarray(gt, np.float64)
+    psnr = -10.0 * np.log10(np.mean((pred - gt) ** 2))
+    g = np.exp(-((np.arange(11) - 5) ** 2) / (2 * 1.5 ** 2)).astype(F32)
+    g = (g / g.sum()).astype(np.float64)
+    win = np.outer(g, g)
+
+    def filt(img):
+        H, W, _ = img.shape
+        p = np.pad(img, ((5, 5), (5, 5), (0, 0)))
+        out = np.zeros_like(img)
+        for dy in range(11):
+            for dx in range(11):
+                out += win[dy, dx] * p[dy:dy + H, dx:dx + W]
+        return out
+    mu1, mu2 = filt(pred), filt(gt)
+    s1, s2, s12 = filt(pred * pred) - mu1 ** 2, filt(gt * gt) - mu2 ** 2, filt(pred * gt) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))
+    return F32(psnr), F32(ssim_map.mean())
+
+
 def generate_rays_blender(c2w, width, height, focal, near, far):
     """datasets/datasets.py:214-263 (Blender._generate_rays) for ONE camera: Rays of [H, W, k] float32."""
     x, y = np.meshgrid(np.arange(width, dtype=F32), np.arange(height, dtype=F32), indexing="xy")

@@ -276,8 +276,27 @@ def raygen_case(name):
     print(f"wrote {name}.npz")
 
 
+def metrics_case(name):
+    """eval_errors golden (utils/metrics.py:191-197) on a smooth synthetic frame + noise, sizes not multiples of 16."""
+    from utils.metrics import eval_errors as ref_eval_errors
+    rng = np.random.default_rng(21)
+    H, W = 45, 70
+    yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+    gt = np.stack([0.5 + 0.5 * np.sin(6 * xx + 3 * yy), yy * xx, 0.5 + 0.5 * np.cos(9 * yy)], -1).astype(np.float32)
+    pred = np.clip(gt + rng.normal(0, 0.03, gt.shape) + 0.02 * np.sin(40 * xx)[..., None], 0, 1).astype(np.float32)
+    psnr, ssim = ref_eval_errors(torch.from_numpy(pred)[None], torch.from_numpy(gt)[None])
+    op, os_ = orc.eval_errors(pred, gt)
+    assert abs(float(op) - float(psnr)) < 1e-4 and abs(float(os_) - float(ssim)) < 1e-5, (op, psnr, os_, ssim)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), pred=pred, gt=gt, psnr=np.float32(psnr.item()),
+                        ssim=np.float32(ssim.item()))
+    print(f"wrote {name}.npz psnr={psnr.item():.4f} ssim={ssim.item():.6f}")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
+    if "--only-metrics" in sys.argv:
+        metrics_case("metrics_45x70")
+        sys.exit(0)
     if "--only-raygen" in sys.argv:         # added after the other files were frozen
         raygen_case("raygen_20x14")
         sys.exit(0)
@@ -301,4 +320,5 @@ if __name__ == "__main__":
     grad_case("train_64x64_trained", 64, 64, param_seed=7, gain=40.0, ray_seed=7)
     mlp_grad_case("mlp_bwd_8x32_trained", 8, 32, param_seed=8, gain=40.0, seed=8)
     raygen_case("raygen_20x14")
+    metrics_case("metrics_45x70")
     print("done")

@@ -258,3 +258,22 @@ def test_generate_rays_matches_reference(G):
         ref = g["blender_" + k].reshape(2, W * H, -1)[ci, pi].astype(np.float32)
         assert G.maxdiff(getattr(rays, k), ref) <= 3e-6, k
     G.record("generate_rays", worst=worst)
+
+
+def test_eval_errors_matches_reference(G):
+    """fused PSNR + 11x11-Gaussian SSIM kernel vs the reference's eval_errors (golden) and the oracle
+    on an 800x800 frame (size-independent check: identical images -> ssim 1, psnr = +inf)."""
+    from mipnerf_pl_amd import ops
+    g = G.load_golden("metrics_45x70")
+    pred, gt = torch.from_numpy(g["pred"]).to(G.DEV), torch.from_numpy(g["gt"]).to(G.DEV)
+    psnr, ssim = ops.eval_errors(pred[None], gt[None])
+    e1, e2 = abs(float(psnr) - float(g["psnr"])), abs(float(ssim) - float(g["ssim"]))
+    G.record("eval_errors", psnr_abs=e1, ssim_abs=e2)
+    assert e1 <= 1e-4 and e2 <= 1e-5
+    big = torch.rand(800, 800, 3, device=G.DEV)
+    p2, s2 = ops.eval_errors(big, big)
+    assert abs(float(s2) - 1.0) <= 1e-6 and float(p2) == float("inf")
+    noisy = (big + 0.05 * torch.randn_like(big)).clamp(0, 1)
+    p3, s3 = ops.eval_errors(noisy, big)
+    op, os_ = orc.eval_errors(noisy.cpu().numpy(), big.cpu().numpy())
+    assert abs(float(p3) - float(op)) <= 1e-3 and abs(float(s3) - float(os_)) <= 2e-5

@@ -164,3 +164,9 @@ def test_ray_generation_matches_reference(golden_dir):
         o = orc.generate_rays_multicam(g["multicam_c2w"][i], g["multicam_pix2cam"][i], w, h, 2.0, 6.0, 4.0 ** i)
         for k in orc.Rays._fields:
             np.testing.assert_allclose(getattr(o, k), g[f"multicam{i}_" + k], atol=2e-6, err_msg=f"multicam {k}")
+
+
+def test_eval_errors_matches_reference(golden_dir):
+    g = load(golden_dir, "metrics_45x70")
+    psnr, ssim = orc.eval_errors(g["pred"], g["gt"])
+    assert abs(float(psnr) - float(g["psnr"])) <= 1e-4 and abs(float(ssim) - float(g["ssim"])) <= 1e-5
