@@ -158,7 +158,8 @@ std::vector<int32_t> encode(const std::vector<int32_t>& flat, const std::vector<
 
 // ---- training tables: binary blob produced by mlp_train_plan.TrainPlan.blob(), linked in by train_tables.c ------
 struct TrainTables {
-    int n_bchunks, njobs, NH, NG, NMASK, job_floats, nparams;
+    int n_bchunks, njobs, NH, NG, NMASK, job_floats, nparams, n_scratch;
+    int off_extra_w, off_extra_b, off_view_w, off_view_b;
     const int32_t* bpack;    // [n_bchunks * 512] flat parameter index or -1
     const int32_t* jobs;     // [njobs * 20]
     const int32_t* otab;     // [njobs * job_floats] flat parameter index or -1
@@ -168,6 +169,7 @@ bool train_tables(TrainTables& T) {
     const int32_t* h = reinterpret_cast<const int32_t*>(mip_train_tables);
     if (h[0] != 0x54524E31) return false;
     T.n_bchunks = h[1]; T.njobs = h[2]; T.NH = h[3]; T.NG = h[4]; T.NMASK = h[5]; T.job_floats = h[6]; T.nparams = h[7];
+    T.n_scratch = h[11]; T.off_extra_w = h[12]; T.off_extra_b = h[13]; T.off_view_w = h[14]; T.off_view_b = h[15];
     T.bpack = h + 16;
     T.jobs = T.bpack + h[8];
     T.otab = T.jobs + h[9];
@@ -193,7 +195,10 @@ struct mipnerf_ctx {
     int32_t* d_otab = nullptr;
     int4* d_wgtab = nullptr;
     int2* d_jobslots = nullptr;
+    float* d_scratch = nullptr;      // fp32 scratch behind the parameters (M, db_view of one backward call)
+    float* d_extra_wT = nullptr;     // W_extra^T (fp32), refreshed by mipnerf_set_params
     int num_wgrad_wgs = 0;
+    mip::ParamPtrs pp;               // device pointers of the fp32 master parameters (last mipnerf_set_params)
     bool params_set = false;
     int mlp_dma = 1;                 // 1: global_load_lds ring, 0: register-staged ring (debug)
     int grid_limit = 256;            // persistent workgroups of the bf16 MLP kernel (= CUs)
@@ -281,6 +286,8 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         chk(hipMalloc(&c->d_jobs, (size_t)tt.njobs * sizeof(mip::WgradJob)));
         chk(hipMalloc(&c->d_otab, (size_t)tt.njobs * tt.job_floats * 4));
         chk(hipMalloc(&c->d_jobslots, (size_t)tt.njobs * sizeof(int2)));
+        chk(hipMalloc(&c->d_scratch, (size_t)(tt.n_scratch > 0 ? tt.n_scratch : 1) * 4));
+        chk(hipMalloc(&c->d_extra_wT, (size_t)kNetWidth * kNetWidth * 4));
         if (er == hipSuccess) {
             chk(hipMemcpy(c->d_pack_dgrad, e_dg.data(), e_dg.size() * 4, hipMemcpyHostToDevice));
             chk(hipMemcpy(c->d_jobs, tt.jobs, (size_t)tt.njobs * sizeof(mip::WgradJob), hipMemcpyHostToDevice));
@@ -304,7 +311,7 @@ int mipnerf_destroy(mipnerf_ctx* c) {
     (void)hipFree(c->d_pack_bf16); (void)hipFree(c->d_pack_f32); (void)hipFree(c->d_bias_idx);
     (void)hipFree(c->d_stream_bf16); (void)hipFree(c->d_stream_f32); (void)hipFree(c->d_bias);
     (void)hipFree(c->d_pack_dgrad); (void)hipFree(c->d_stream_dgrad); (void)hipFree(c->d_jobs); (void)hipFree(c->d_otab);
-    (void)hipFree(c->d_wgtab); (void)hipFree(c->d_jobslots);
+    (void)hipFree(c->d_wgtab); (void)hipFree(c->d_jobslots); (void)hipFree(c->d_scratch); (void)hipFree(c->d_extra_wT);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
     return MIPNERF_OK;
@@ -334,6 +341,8 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
     HIP_TRY(mip::launch_pack(c->d_pack_f32, nst, pp, c->d_stream_f32, false, S(stream)));
     HIP_TRY(mip::launch_pack(c->d_bias_idx, (int64_t)kNumTiles * 32, pp, c->d_bias, false, S(stream)));
     HIP_TRY(mip::launch_pack(c->d_pack_dgrad, (int64_t)c->tt.n_bchunks * 512, pp, c->d_stream_dgrad, true, S(stream)));
+    HIP_TRY(mip::launch_transpose_sq(kNetWidth, pp.p[2 * kNetDepth + 2], c->d_extra_wT, S(stream)));
+    c->pp = pp;
     c->params_set = true;
     return MIPNERF_OK;
 }
@@ -503,9 +512,20 @@ int mipnerf_mlp_wgrad(mipnerf_ctx* c, int64_t M, const void* act, const void* de
     const int64_t n_wt = ((M + 255) / 256) * 8;
     HIP_TRY(mip::launch_mlp_wgrad(act, delta, c->d_jobs, c->d_wgtab, c->num_wgrad_wgs, n_wt, c->tt.NH, c->tt.NG, partials,
                                   S(stream)));
-    if (grad_flat)
-        HIP_TRY(mip::launch_wgrad_reduce(partials, c->d_otab, c->d_jobslots, c->tt.njobs, grad_flat, accumulate != 0,
-                                         S(stream)));
+    if (grad_flat) {
+        if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_wgrad: mipnerf_set_params has not been called");
+        using namespace mip::plan;
+        mip::WgradPost post;
+        post.W = kNetWidth; post.Wc = kNetWidthCond; post.ldv = kNetWidth + kViewDim;
+        post.off_extra_w = c->tt.off_extra_w; post.off_extra_b = c->tt.off_extra_b;
+        post.off_view_w = c->tt.off_view_w; post.off_view_b = c->tt.off_view_b;
+        // state_dict order: ... density (2*D, 2*D+1), extra (2*D+2, +3), view (2*D+4, +5), colour
+        post.extra_wT = c->d_extra_wT;
+        post.extra_w = c->pp.p[2 * kNetDepth + 2]; post.extra_b = c->pp.p[2 * kNetDepth + 3];
+        post.view_w = c->pp.p[2 * kNetDepth + 4];
+        HIP_TRY(mip::launch_wgrad_reduce(partials, c->d_otab, c->d_jobslots, c->tt.njobs, grad_flat, c->d_scratch,
+                                         c->tt.nparams, post, accumulate != 0, S(stream)));
+    }
     return MIPNERF_OK;
 }
 

@@ -486,10 +486,11 @@ def build_dgrad_prog(tp: TrainPlan):
                 else:
                     post.append(f"depilogue_half<false, 0, 0>({acc}, 0u, {op.out}[{2 * t}]);  /*op{oi}*/")
                     post.append(f"depilogue_half<false, 8, 0>({acc}, 0u, {op.out}[{2 * t + 1}]);  /*op{oi}*/")
-                post_t.append(f"TMFMA0({acc}, {op.out}[{2 * t}], P1);  /*op{oi}*/")
-                post_t.append(f"MFMA({acc}, {op.out}[{2 * t + 1}], P2);  /*op{oi}*/")
-                post_late.append(f"store_tfrag<0>({acc}, gt_wave + {(op.gblock + t) * 2048}, lane16);")
-                post_late.append(f"store_tfrag<8>({acc}, gt_wave + {(op.gblock + t) * 2048}, lane16);")
+                if op.gblock is not None:      # (the bottleneck delta is consumed in registers only)
+                    post_t.append(f"TMFMA0({acc}, {op.out}[{2 * t}], P1);  /*op{oi}*/")
+                    post_t.append(f"MFMA({acc}, {op.out}[{2 * t + 1}], P2);  /*op{oi}*/")
+                    post_late.append(f"store_tfrag<0>({acc}, gt_wave + {(op.gblock + t) * 2048}, lane16);")
+                    post_late.append(f"store_tfrag<8>({acc}, gt_wave + {(op.gblock + t) * 2048}, lane16);")
             pre = []
             if first_panel_of_op and op.mask is not None:
                 # the mask dwords of this op, read from the wave-private LDS copy while the previous op finishes

@@ -124,9 +124,10 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
 }
 
 // grad[idx] = sum over the job's splits of the partial at `pos`, for every position that feeds a parameter
+// (idx < nparams: assign or accumulate) or the fp32 scratch region behind them (idx >= nparams: always assigned)
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ partials, const int32_t* __restrict__ otab, const int2* __restrict__ job_slots,
-               float* __restrict__ grad_flat, int accumulate) {
+               float* __restrict__ grad_flat, float* __restrict__ scratch, int nparams, int accumulate) {
     const int job = blockIdx.y;
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= kWgradJobFloats) return;
@@ -136,7 +137,73 @@ k_wgrad_reduce(const float* __restrict__ partials, const int32_t* __restrict__ o
     const float* p = partials + (int64_t)js.x * kWgradJobFloats + pos;
     float s = 0.0f;
     for (int k = 0; k < js.y; ++k) s += p[(int64_t)k * kWgradJobFloats];
-    grad_flat[idx] = accumulate ? grad_flat[idx] + s : s;     // every parameter has exactly one source position
+    if (idx >= nparams) scratch[idx - nparams] = s;
+    else grad_flat[idx] = accumulate ? grad_flat[idx] + s : s;     // every parameter has exactly one source position
+}
+
+// The bottleneck (extra_layer, mip_nerf.py:102) has no activation, so its T-blocks are never stored; with
+// M = sum_s delta_view x8^T [Wc, W] and dbv = sum_s delta_view [Wc] (scratch, from the "M" job):
+//   dW_view[:, :W] = M W_extra^T + dbv b_extra^T ;  db_view = dbv ;  dW_extra = W_view[:, :W]^T M ;  db_extra = W_view[:, :W]^T dbv
+// fp32 on the master parameters, 25 MFLOP.
+__global__ void __launch_bounds__(256)
+k_wgrad_post(WgradPost P, const float* __restrict__ scratch, float* __restrict__ grad_flat, int accumulate) {
+    const int W = P.W, Wc = P.Wc, ldv = P.ldv;
+    const float* M = scratch;
+    const float* dbv = scratch + Wc * W;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float val;
+    float* dst;
+    if (i < W * W) {                                   // dW_extra[o][c] = sum_r W_view[r][o] M[r][c]
+        const int o = i / W, c = i - o * W;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;      // 4 independent chains: 16 loads in flight per lane
+#pragma unroll 2
+        for (int r = 0; r < Wc; r += 4) {
+            s0 += P.view_w[(r + 0) * ldv + o] * M[(r + 0) * W + c];
+            s1 += P.view_w[(r + 1) * ldv + o] * M[(r + 1) * W + c];
+            s2 += P.view_w[(r + 2) * ldv + o] * M[(r + 2) * W + c];
+            s3 += P.view_w[(r + 3) * ldv + o] * M[(r + 3) * W + c];
+        }
+        val = (s0 + s1) + (s2 + s3);
+        dst = grad_flat + P.off_extra_w + i;
+    } else if ((i -= W * W) < Wc * W) {                // dW_view[r][c] = sum_k M[r][k] W_extra[c][k] + dbv[r] b_extra[c]
+        const int r = i / W, c = i - r * W;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll 2
+        for (int k = 0; k < W; k += 4) {                   // transposed copy of W_extra: coalesced over c
+            s0 += M[r * W + k + 0] * P.extra_wT[(k + 0) * W + c];
+            s1 += M[r * W + k + 1] * P.extra_wT[(k + 1) * W + c];
+            s2 += M[r * W + k + 2] * P.extra_wT[(k + 2) * W + c];
+            s3 += M[r * W + k + 3] * P.extra_wT[(k + 3) * W + c];
+        }
+        val = (s0 + s1) + (s2 + s3) + dbv[r] * P.extra_b[c];
+        dst = grad_flat + P.off_view_w + r * ldv + c;
+    } else if ((i -= Wc * W) < W) {                    // db_extra[o] = sum_r W_view[r][o] dbv[r]
+        float s = 0.0f;
+        for (int r = 0; r < Wc; ++r) s += P.view_w[r * ldv + i] * dbv[r];
+        val = s;
+        dst = grad_flat + P.off_extra_b + i;
+    } else if ((i -= W) < Wc) {                        // db_view
+        val = dbv[i];
+        dst = grad_flat + P.off_view_b + i;
+    } else {
+        return;
+    }
+    *dst = accumulate ? *dst + val : val;
+}
+
+__global__ void __launch_bounds__(256) k_transpose_sq(int n, const float* __restrict__ in, float* __restrict__ out) {
+    __shared__ float t[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int x = blockIdx.x * 16 + tx, y = blockIdx.y * 16 + ty;
+    if (x < n && y < n) t[ty][tx] = in[(size_t)y * n + x];
+    __syncthreads();
+    const int ox = blockIdx.y * 16 + tx, oy = blockIdx.x * 16 + ty;
+    if (ox < n && oy < n) out[(size_t)oy * n + ox] = t[tx][ty];
+}
+
+hipError_t launch_transpose_sq(int n, const float* in, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_transpose_sq, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, st, n, in, out);
+    return hipGetLastError();
 }
 
 int mlp_wgrad_lds_bytes() { return kWgradLds; }
@@ -155,9 +222,12 @@ hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs
 }
 
 hipError_t launch_wgrad_reduce(const float* partials, const int32_t* otab, const void* job_slots, int njobs,
-                               float* grad_flat, bool accumulate, hipStream_t st) {
+                               float* grad_flat, float* scratch, int nparams, const WgradPost& post, bool accumulate,
+                               hipStream_t st) {
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((kWgradJobFloats + 255) / 256, njobs), dim3(256), 0, st, partials, otab,
-                       (const int2*)job_slots, grad_flat, accumulate ? 1 : 0);
+                       (const int2*)job_slots, grad_flat, scratch, nparams, accumulate ? 1 : 0);
+    const int n = post.W * post.W + post.Wc * post.W + post.W + post.Wc;
+    hipLaunchKernelGGL(k_wgrad_post, dim3((n + 255) / 256), dim3(256), 0, st, post, scratch, grad_flat, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 
