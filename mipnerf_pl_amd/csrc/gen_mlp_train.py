@@ -41,6 +41,9 @@ __device__ __forceinline__ void store_tfrag(const f32x16& acc, char* blk, unsign
     bf16x8 o;
 #pragma unroll
     for (int r = 0; r < 8; ++r) o[r] = (__bf16)acc[R0 + r];
+#ifdef MLP_TRAIN_ABLATE_STORES      // timing experiment: everything but the store itself (results are wrong)
+    if (lane16 != 0xFFFFFFFFu) { asm volatile("" :: "v"(o)); return; }
+#endif
     // streamed once, read back by another kernel after >2 GB of other traffic: keep it out of the L2's way
     // (measured on MI355X: -5 % forward-with-save, -7 % dgrad vs plain stores)
     __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(blk + (R0 / 8) * 1024 + lane16));
@@ -48,18 +51,16 @@ __device__ __forceinline__ void store_tfrag(const f32x16& acc, char* blk, unsign
 
 // 16 ReLU bits of one output tile from its two (post-ReLU, bf16) k-step registers: bit p = reg 2p > 0,
 // bit 16+p = reg 2p+1 > 0 (mlp_train_plan.pack_mask).
-__device__ __forceinline__ unsigned pk_nonzero(unsigned x, unsigned one2) {
-    unsigned r;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "s"(one2));
-    return r;
-}
+// Plain 32-bit integer VALU on the packed pairs (never inline asm next to MFMAs: see relu1 in gen_mlp_bf16.py).  The
+// halves are non-negative bf16 (v_max_f32 returns +0 for max(-0, +0)), so h + 0x7FFF has bit 15 set iff h != 0 and
+// never carries into the neighbouring half.
 __device__ __forceinline__ unsigned tile_mask(const bf16x8& a, const bf16x8& b) {
     const u32x4 da = __builtin_bit_cast(u32x4, a), db = __builtin_bit_cast(u32x4, b);
     unsigned m = 0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) m |= pk_nonzero(da[p], 0x00010001u) << p;
+    for (int p = 0; p < 4; ++p) m |= ((da[p] + 0x7FFF7FFFu) >> (15 - p)) & (0x00010001u << p);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) m |= pk_nonzero(db[p], 0x00010001u) << (4 + p);
+    for (int p = 0; p < 4; ++p) m |= ((db[p] + 0x7FFF7FFFu) >> (11 - p)) & (0x00010001u << (4 + p));
     return m;
 }
 
@@ -117,19 +118,41 @@ class Prog:
         self.panels = []      # dict(first, n, pair, spk, post (list of stmts run during the next panel), pre)
 
 
-def place_sides(prog, nchunks):
-    """Spread each panel's `post` statements (and the next-next panel's `pre`) over the next panel's slots."""
+def place_sides(prog, nchunks, which=""):
+    """Spread each panel's `post` statements (and the next-next panel's `pre`) over the next panel's slots: the
+    register work (epilogue, transposing MFMAs, masks) right away, one statement per slot; the T-block STORES evenly
+    over the rest of the panel (all 8 waves of a workgroup run in lockstep, so back-to-back stores reach the CU's store
+    path as one 32-KiB burst); then `pre` (accumulator re-initialisation of the panel after next, which must follow
+    the stores that read those accumulators).  Measured on MI355X (scripts/prof_train.py): removing the store
+    instructions altogether saves 0.18 ms of a 0.77 ms launch, but neither spreading them, nor counted vmcnt waits,
+    nor the block layout (scripts/micro/wpattern.hip: the pattern alone sustains 4.9 TB/s) changes the launch time --
+    the kernel sits on the power envelope and 3.5 TB/s of HBM writes take their share of it."""
+    spread = os.environ.get("MLP_TRAIN_SPREAD_STORES", "1") in ("1", which)
     side = {c: [] for c in range(nchunks)}
     for pi, pn in enumerate(prog.panels):
-        work = []
-        if pi > 0:
-            work += prog.panels[pi - 1]["post"]
-        if pi + 1 < len(prog.panels):
-            work += prog.panels[pi + 1]["pre"]
+        post = prog.panels[pi - 1]["post"] if pi > 0 else []
+        pre = prog.panels[pi + 1]["pre"] if pi + 1 < len(prog.panels) else []
         n = pn["n"]
-        for wi, stmt in enumerate(work):
-            at = min(2 + wi, n - 1)
-            side[pn["first"] + at].append(stmt)
+        first = pn["first"]
+        if not spread:
+            for wi, stmt in enumerate(post + pre):
+                side[first + min(2 + wi, n - 1)].append(stmt)
+            continue
+        compute = [st for st in post if count_stores(st) == 0]
+        stores = [st for st in post if count_stores(st) > 0]
+        pos = 2
+        for st in compute:
+            side[first + min(pos, n - 1)].append(st)
+            pos += 1
+        lo = min(pos + 1, n - 1)                 # >= 2 slots after the last transposing MFMA
+        hi = max(lo, n - 2)
+        last = lo
+        for i, st in enumerate(stores):
+            at = lo if len(stores) == 1 else lo + (hi - lo) * i // (len(stores) - 1)
+            side[first + at].append(st)
+            last = at
+        for wi, st in enumerate(pre):
+            side[first + min(max(last, pos) + wi, n - 1)].append(st)
     return side
 
 
@@ -138,7 +161,8 @@ def count_stores(stmt: str) -> int:
     return stmt.count("store_tfrag<") + stmt.count("reinterpret_cast<u32x4*>(mask_wave")
 
 
-def emit_tile_body(e, prog, side, nchunks_total, prologue_lines, final_lines, lda, counted=True):
+def emit_tile_body(e, prog, side, nchunks_total, prologue_lines, final_lines, lda,
+                   counted=os.environ.get("MLP_TRAIN_COUNTED_VMCNT", "0") == "1"):
     """MFMA slots with A prefetch PREFETCH chunks ahead and ring-group boundaries where the load cursor
     enters a new group.  nchunks_total >= len(slots): trailing (padding) groups are still cycled through so
     that the ring phase is tile-invariant.  Group boundaries g >= 1 wait with vmcnt(K), K = stores this wave
@@ -346,7 +370,7 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     prog = build_fwd_prog(tp)
     assert len(prog.slots) == nchunks
     side_e, prologue_e = assign_lds_b(prog, nchunks)
-    side = place_sides(prog, nchunks)
+    side = place_sides(prog, nchunks, "fwd")
     for c in range(nchunks):
         side[c] = side_e[c] + side[c]
     check_hazards(prog, side)
@@ -512,7 +536,7 @@ def gen_dgrad(tp: TrainPlan) -> str:
     assert lds_bytes <= 160 * 1024
     prog = build_dgrad_prog(tp)
     assert len(prog.slots) == nreal
-    side = place_sides(prog, nreal)
+    side = place_sides(prog, nreal, "dgrad")
     check_hazards(prog, side)
     lines = []
     e = lines.append
