@@ -35,6 +35,22 @@ except Exception:  # noqa: BLE001
         def log(self, name, value, **kw):
             self.logged[name] = value.detach() if torch.is_tensor(value) else value
 
+        # Lightning checkpoint format (what the reference's train.py writes and eval.py / render_video.py read with
+        # MipNeRFSystem.load_from_checkpoint): {'state_dict': {'mip_nerf.mlp...': tensor}, 'hyper_parameters': {...}}
+        def save_checkpoint(self, path):
+            torch.save({"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
+                        "hyper_parameters": dict(self.hparams), "global_step": self.global_step}, path)
+
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
+            ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+            hp = dict(ckpt.get("hyper_parameters", {}))
+            hp.update(kwargs.pop("hparams", {}) or {})
+            system = cls(hp, **kwargs)
+            system.load_state_dict(ckpt["state_dict"], strict=True)
+            system.global_step = int(ckpt.get("global_step", 0))
+            return system
+
 
 def calc_psnr(x: torch.Tensor, y: torch.Tensor):
     """utils/metrics.py:182-188."""
