@@ -37,6 +37,8 @@ def main():
                     help="inference (headline): MipNerf.forward; train: forward + loss + backward + grad all-reduce + Adam; "
                          "render: BASELINE configs[4], one 800x800 frame (640k rays) in 8192-ray chunks replayed from a "
                          "captured hipGraph, rays split over the ranks, rgb gathered")
+    ap.add_argument("--autograd", action="store_true", help="train mode: training_step + loss.backward() through the custom "
+                    "autograd Functions (what a Lightning loop does) instead of the single native mipnerf_train_step call")
     ap.add_argument("--torch-adam", action="store_true", help="train mode: torch.optim.Adam on per-tensor gradients "
                     "(what the reference configures) instead of the fused flat Adam kernel")
     ap.add_argument("--no-graph", action="store_true", help="render mode: eager chunk loop instead of the hipGraph")
@@ -87,8 +89,11 @@ def main():
 
         def step():
             opt.zero_grad(set_to_none=False)              # FlatAdam: no kernel, the next backward overwrites
-            loss = system.training_step((R, gt), 0)      # randomized=True, nerf_system.py:95-121
-            loss.backward()
+            if args.autograd:
+                loss = system.training_step((R, gt), 0)      # randomized=True, nerf_system.py:95-121
+                loss.backward()
+            else:
+                loss = system.training_step_native((R, gt), 0)     # the same, one native call (mipnerf_train_step)
             reduce_grads()                                # one flat all-reduce over RCCL (no-op at world 1)
             opt.step()
             sch["scheduler"].step()

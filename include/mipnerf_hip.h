@@ -247,6 +247,19 @@ int mipnerf_adam_step(int64_t n, float* param, const float* grad, float* exp_avg
  * timing only).  NULL restores the default.  Changes partial_bytes of mipnerf_mlp_train_sizes; synchronises. */
 int mipnerf_set_wgrad_splits(mipnerf_ctx* ctx, const int32_t* splits_host);
 
+/* ---- the whole training step (bf16): MipNeRFSystem.training_step (nerf_system.py:95-111) + loss.backward() --------
+ * forward of all levels with saved activations, loss = cm (mse_c + dm dl_c) + mse_f + dm dl_f (cm = loss.coarse_loss_mult,
+ * dm = 0.01, mse masked by rays.lossmult unless disable_multiscale_loss), backward of compositing / activations / MLP.
+ * grad_flat [612,740] = d loss / d parameters in state_dict order (accumulate = 0 overwrites).  out_scalars [6] =
+ * loss, mse_coarse, mse_fine, distloss_coarse, distloss_fine, psnr_fine.  `out` (may be NULL, or hold NULL fields)
+ * receives copies of what MipNerf.forward returns.  No autograd graph, no allocation, one stream: graph-capturable. */
+size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* ctx, int64_t num_rays);
+int mipnerf_train_step(mipnerf_ctx* ctx, int64_t num_rays, const mipnerf_rays* rays, const float* gt_rgb,
+                       const float* t_rand, const float* u_rand, uint32_t flags, float coarse_loss_mult,
+                       float distloss_mult, int32_t disable_multiscale_loss, void* workspace,
+                       size_t workspace_bytes, float* grad_flat, int32_t accumulate, float* out_scalars,
+                       const mipnerf_level_out* out, void* stream);
+
 /* ---- instrumentation ------------------------------------------------------------------ */
 /* Times `iters` launches of the bf16 MLP kernel with hipEvents on `stream`; returns the
  * average milliseconds per launch in *ms (used by bench.py for roofline.achieved). */

@@ -208,6 +208,18 @@ struct mipnerf_ctx {
     size_t ev_used = 0;
 };
 
+namespace {
+struct TrainWs {                   // carve-up of the caller's workspace (all 256-byte aligned)
+    char* base;
+    size_t off = 0;
+    template <typename T> T* take(size_t bytes) {
+        T* p = reinterpret_cast<T*>(base + off);
+        off += align256(bytes);
+        return p;
+    }
+};
+}  // namespace
+
 extern "C" {
 
 int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host);
@@ -473,7 +485,7 @@ int mipnerf_distloss(int64_t B, int32_t N, const float* weights, const float* t,
                      float* d_w, void* stream) {
     if (B < 1 || N < 1 || N > MIPNERF_MAX_SAMPLES || !weights || !t || (!ray_loss && !d_w) || ((g_ray == nullptr) != (d_w == nullptr)))
         return fail(MIPNERF_E_INVALID, "distloss: bad argument");
-    HIP_TRY(mip::launch_distloss(B, N, weights, t, ray_loss, g_ray, d_w, S(stream)));
+    HIP_TRY(mip::launch_distloss(B, N, weights, t, ray_loss, g_ray, 0.0f, d_w, S(stream)));
     return MIPNERF_OK;
 }
 
@@ -575,6 +587,99 @@ int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host) {
     HIP_TRY(hipMemcpy(c->d_wgtab, wgtab.data(), wgtab.size() * sizeof(int4), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_jobslots, slots.data(), slots.size() * sizeof(int2), hipMemcpyHostToDevice));
     c->num_wgrad_wgs = (int)wgtab.size();
+    return MIPNERF_OK;
+}
+
+
+// ---- the whole training step of the hot path in one call ---------------------------------------------------------
+// MipNeRFSystem.training_step (nerf_system.py:95-111) = MipNerf.forward(randomized) + loss, followed by what
+// loss.backward() does to the 24 MLP parameters -- native kernels only, no autograd graph, graph-capturable.
+size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
+    if (!c || B < 1) return 0;
+    const size_t N = c->cfg.num_samples, M = (size_t)B * N, L = c->cfg.num_levels;
+    size_t act, masks, delta, partials;
+    if (mipnerf_mlp_train_sizes(c, (int64_t)M, &act, &masks, &delta, &partials)) return 0;
+    size_t per_level = align256(B * (N + 1) * 4) + align256(B * N * 4) + align256(B * 3 * 4) + 2 * align256(B * 4) +   // t, w, rgb, dist, acc
+                       align256(M * mip::plan::kXyzDim * 2) + 2 * align256(M * 16) +                                    // enc, rgb_sigma, raw
+                       align256(act) + align256(masks) + align256(B * 4) + align256(B * N * 4) + align256(B * 3 * 4);   // act, masks, ray_loss, d_w, g_rgb
+    return 256 + L * per_level + align256(B * 32 * 2) + align256(delta) + align256(partials) + align256(M * 16) + 256;
+}
+
+int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* gt_rgb, const float* t_rand,
+                       const float* u_rand, uint32_t flags, float coarse_loss_mult, float distloss_mult,
+                       int32_t disable_multiscale_loss, void* workspace, size_t workspace_bytes, float* grad_flat,
+                       int32_t accumulate, float* out_scalars, const mipnerf_level_out* out, void* stream) {
+    if (!c || !rays || !gt_rgb || !workspace || !grad_flat || !out_scalars || B < 1)
+        return fail(MIPNERF_E_INVALID, "train_step: bad argument");
+    if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->radii || !rays->near || !rays->far || !rays->lossmult)
+        return fail(MIPNERF_E_INVALID, "train_step: a Rays field is null");
+    if (!c->params_set) return fail(MIPNERF_E_INVALID, "train_step: mipnerf_set_params has not been called");
+    if ((t_rand == nullptr) != (u_rand == nullptr) && c->cfg.num_levels > 1)
+        return fail(MIPNERF_E_INVALID, "train_step: t_rand and u_rand must both be given (randomized) or both null");
+    if (workspace_bytes < mipnerf_train_workspace_bytes(c, B)) return fail(MIPNERF_E_WORKSPACE, "train_step: workspace too small");
+    const mipnerf_config& cfg = c->cfg;
+    const int N = cfg.num_samples, L = cfg.num_levels;
+    const size_t M = (size_t)B * N;
+    size_t act_b, mask_b, delta_b, part_b;
+    int rc = mipnerf_mlp_train_sizes(c, (int64_t)M, &act_b, &mask_b, &delta_b, &part_b);
+    if (rc) return rc;
+    TrainWs ws;
+    ws.base = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+    struct Lvl { float *t, *w, *rgb, *dist, *acc, *rgb_sigma, *raw, *ray_loss, *d_w, *g_rgb; void *enc, *act, *masks; } lv[2];
+    for (int l = 0; l < L; ++l) {
+        lv[l].t = ws.take<float>(B * (N + 1) * 4); lv[l].w = ws.take<float>(B * N * 4); lv[l].rgb = ws.take<float>(B * 3 * 4);
+        lv[l].dist = ws.take<float>(B * 4); lv[l].acc = ws.take<float>(B * 4);
+        lv[l].enc = ws.take<char>(M * mip::plan::kXyzDim * 2);
+        lv[l].rgb_sigma = ws.take<float>(M * 16); lv[l].raw = ws.take<float>(M * 16);
+        lv[l].act = ws.take<char>(act_b); lv[l].masks = ws.take<char>(mask_b);
+        lv[l].ray_loss = ws.take<float>(B * 4); lv[l].d_w = ws.take<float>(B * N * 4); lv[l].g_rgb = ws.take<float>(B * 3 * 4);
+    }
+    void* viewenc = ws.take<char>(B * 32 * 2);
+    void* delta = ws.take<char>(delta_b);
+    float* partials = ws.take<float>(part_b);
+    float* d_raw = ws.take<float>(M * 16);
+    const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
+    const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
+    // ---- forward (mip_nerf.py:182-246), activations saved for the backward -------------------------------------------
+    if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, MIPNERF_PREC_BF16, stream))) return rc;
+    for (int l = 0; l < L; ++l) {
+        if (l == 0) {
+            if ((rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, lv[0].t, stream))) return rc;
+        } else {
+            if ((rc = mipnerf_resample_along_rays(B, N, lv[l - 1].t, lv[l - 1].w, u_rand, cfg.resample_padding, lv[l].t, stream))) return rc;
+        }
+        if ((rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, lv[l].t, rays->origins,
+                                   rays->directions, rays->radii, lv[l].enc, MIPNERF_PREC_BF16, stream))) return rc;
+        if ((rc = mipnerf_mlp_forward_train(c, (int64_t)M, N, lv[l].enc, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act,
+                                            lv[l].masks, stream))) return rc;
+        if ((rc = mipnerf_volumetric_rendering(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].rgb, lv[l].dist,
+                                               lv[l].acc, lv[l].w, stream))) return rc;
+        // distloss (mip.py:8-20) forward AND backward in one pass: d loss / d ray_loss is the constant k_l * dm / B
+        const float k = (L > 1 && l == 0) ? coarse_loss_mult : 1.0f;
+        HIP_TRY(mip::launch_distloss(B, N, lv[l].w, lv[l].t, lv[l].ray_loss, nullptr, k * distloss_mult / (float)B, lv[l].d_w,
+                                     S(stream)));
+    }
+    // ---- loss (nerf_system.py:99-111) and d loss / d comp_rgb ------------------------------------------------------------
+    HIP_TRY(mip::launch_loss_fused(B, L, lv[0].rgb, L > 1 ? lv[1].rgb : nullptr, gt_rgb, disable_multiscale_loss ? nullptr : rays->lossmult,
+                                   lv[0].ray_loss, L > 1 ? lv[1].ray_loss : nullptr, coarse_loss_mult, distloss_mult, lv[0].g_rgb,
+                                   L > 1 ? lv[1].g_rgb : lv[0].g_rgb, out_scalars, S(stream)));
+    // ---- backward: compositing + activations, then the MLP, level by level (resampling carries no gradient,
+    //      mip_nerf.py:187-196 stop_resample_grad) ----------------------------------------------------------------------------
+    for (int l = L - 1; l >= 0; --l) {
+        if ((rc = mipnerf_volumetric_rendering_bwd(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].g_rgb, nullptr,
+                                                   nullptr, lv[l].d_w, cfg.rgb_padding, d_raw, stream))) return rc;
+        const int acc = (l == L - 1) ? (accumulate ? 1 : 0) : 1;
+        if ((rc = mipnerf_mlp_backward(c, (int64_t)M, d_raw, lv[l].act, lv[l].masks, delta, partials, grad_flat, acc, stream))) return rc;
+    }
+    if (out)      // optional copies of what MipNerf.forward returns (async device-to-device)
+        for (int l = 0; l < L; ++l) {
+            const mipnerf_level_out& o = out[l];
+            if (o.comp_rgb) HIP_TRY(hipMemcpyAsync(o.comp_rgb, lv[l].rgb, B * 3 * 4, hipMemcpyDeviceToDevice, S(stream)));
+            if (o.distance) HIP_TRY(hipMemcpyAsync(o.distance, lv[l].dist, B * 4, hipMemcpyDeviceToDevice, S(stream)));
+            if (o.acc) HIP_TRY(hipMemcpyAsync(o.acc, lv[l].acc, B * 4, hipMemcpyDeviceToDevice, S(stream)));
+            if (o.weights) HIP_TRY(hipMemcpyAsync(o.weights, lv[l].w, B * N * 4, hipMemcpyDeviceToDevice, S(stream)));
+            if (o.t_samples) HIP_TRY(hipMemcpyAsync(o.t_samples, lv[l].t, B * (N + 1) * 4, hipMemcpyDeviceToDevice, S(stream)));
+        }
     return MIPNERF_OK;
 }
 

@@ -140,7 +140,7 @@ k_volumetric_rendering_bwd(int64_t B, int N, const float4* __restrict__ rgb_sigm
 template <int K>
 __global__ void __launch_bounds__(256)
 k_distloss(int64_t B, int N, const float* __restrict__ weights, const float* __restrict__ t,
-           float* __restrict__ ray_loss, const float* __restrict__ g_ray, float* __restrict__ d_w) {
+           float* __restrict__ ray_loss, const float* __restrict__ g_ray, float g_const, float* __restrict__ d_w) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -169,8 +169,8 @@ k_distloss(int64_t B, int N, const float* __restrict__ weights, const float* __r
     for (int k = 0; k < K; ++k) bi += (double)w[k] * ((double)m[k] * (oP + pP[k]) - (oQ + pQ[k]));
     const double tot = wsum64(uni) / 3.0 + 2.0 * wsum64(bi);
     if (lane == 0 && ray_loss) ray_loss[b] = (float)tot;
-    if (g_ray && d_w) {
-        const float g = g_ray[b];
+    if (d_w) {
+        const float g = g_ray ? g_ray[b] : g_const;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (i0 + k < N) {
@@ -212,10 +212,10 @@ hipError_t launch_volumetric_rendering_bwd(int64_t B, int N, const float* rgb_si
 }
 
 hipError_t launch_distloss(int64_t B, int N, const float* weights, const float* t, float* ray_loss, const float* g_ray,
-                           float* d_w, hipStream_t st) {
+                           float g_const, float* d_w, hipStream_t st) {
     const dim3 grid(gridf(B, 4)), block(256);
     const int K = (N + 63) / 64;
-#define MIP_DL(KK) hipLaunchKernelGGL((k_distloss<KK>), grid, block, 0, st, B, N, weights, t, ray_loss, g_ray, d_w)
+#define MIP_DL(KK) hipLaunchKernelGGL((k_distloss<KK>), grid, block, 0, st, B, N, weights, t, ray_loss, g_ray, g_const, d_w)
     switch (K) {
         case 1: MIP_DL(1); break;
         case 2: MIP_DL(2); break;
@@ -227,6 +227,81 @@ hipError_t launch_distloss(int64_t B, int N, const float* weights, const float* 
     return hipGetLastError();
 }
 
+
+// ---- loss of nerf_system.py:99-111 and its gradient w.r.t. the rendered colours, one launch --------------------------
+//   mse_l = sum_b mask_b sum_c (rgb_l[b,c] - gt[b,c])^2 / sum_b mask_b       (mask = lossmult, or ones)
+//   loss  = cm (mse_c + dm dl_c) + mse_f + dm dl_f,   dl_l = mean_b ray_loss_l[b]
+//   d loss / d rgb_l[b,c] = k_l 2 mask_b (rgb_l - gt) / sum mask,  k_c = cm, k_f = 1
+// One workgroup (the inputs are B x 3 floats per level): fp64 tree reductions, deterministic.
+// out[0..5] = loss, mse_c, mse_f, dl_c, dl_f, psnr_f (= -10 log10 mean((rgb_f - gt)^2), nerf_system.py:113).
+__global__ void __launch_bounds__(1024)
+k_loss_fused(int64_t B, int nlevels, const float* __restrict__ rgb0, const float* __restrict__ rgb1,
+             const float* __restrict__ gt, const float* __restrict__ lossmult, const float* __restrict__ ray_loss0,
+             const float* __restrict__ ray_loss1, float coarse_mult, float dist_mult, float* __restrict__ g_rgb0,
+             float* __restrict__ g_rgb1, float* __restrict__ out) {
+    __shared__ double red[6][16];
+    __shared__ double tot[6];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double acc[6] = {0, 0, 0, 0, 0, 0};     // sum mask, sum mask se0, sum mask se1, sum dl0, sum dl1, sum se_fine (unmasked)
+    const float* rgbf = nlevels > 1 ? rgb1 : rgb0;
+    for (int64_t b = tid; b < B; b += blockDim.x) {
+        const float m = lossmult ? lossmult[b] : 1.0f;
+        float se0 = 0.f, se1 = 0.f, sef = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float g = gt[b * 3 + c];
+            const float d0 = rgb0[b * 3 + c] - g;
+            se0 += d0 * d0;
+            if (nlevels > 1) { const float d1 = rgb1[b * 3 + c] - g; se1 += d1 * d1; }
+            const float df = rgbf[b * 3 + c] - g;
+            sef += df * df;
+        }
+        acc[0] += m; acc[1] += (double)m * se0; acc[2] += (double)m * se1;
+        acc[3] += ray_loss0 ? ray_loss0[b] : 0.f; acc[4] += (nlevels > 1 && ray_loss1) ? ray_loss1[b] : 0.f;
+        acc[5] += sef;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[k][w] = v;
+    }
+    __syncthreads();
+    if (tid < 6) {
+        double v = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) v += red[tid][i];
+        tot[tid] = v;
+    }
+    __syncthreads();
+    const double sm = tot[0];
+    if (tid == 0) {
+        const double mse0 = tot[1] / sm, mse1 = tot[2] / sm, dl0 = tot[3] / (double)B, dl1 = tot[4] / (double)B;
+        double loss;
+        if (nlevels > 1) loss = coarse_mult * (mse0 + dist_mult * dl0) + mse1 + dist_mult * dl1;
+        else loss = mse0 + dist_mult * dl0;                     // single level: it is the fine one
+        out[0] = (float)loss; out[1] = (float)mse0; out[2] = (float)(nlevels > 1 ? mse1 : mse0);
+        out[3] = (float)dl0; out[4] = (float)dl1;
+        out[5] = (float)(-10.0 * log10(tot[5] / (3.0 * (double)B)));
+    }
+    const float k0 = nlevels > 1 ? coarse_mult : 1.0f;
+    const float inv = (float)(2.0 / sm);
+    for (int64_t i = tid; i < B * 3; i += blockDim.x) {
+        const int64_t b = i / 3;
+        const float m = lossmult ? lossmult[b] : 1.0f;
+        const float g = gt[i];
+        g_rgb0[i] = k0 * inv * m * (rgb0[i] - g);
+        if (nlevels > 1) g_rgb1[i] = inv * m * (rgb1[i] - g);
+    }
+}
+
+hipError_t launch_loss_fused(int64_t B, int nlevels, const float* rgb0, const float* rgb1, const float* gt, const float* lossmult,
+                             const float* ray_loss0, const float* ray_loss1, float coarse_mult, float dist_mult, float* g_rgb0,
+                             float* g_rgb1, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_loss_fused, dim3(1), dim3(1024), 0, st, B, nlevels, rgb0, rgb1, gt, lossmult, ray_loss0, ray_loss1,
+                       coarse_mult, dist_mult, g_rgb0, g_rgb1, out);
+    return hipGetLastError();
+}
 
 // ---- fused Adam over one flat parameter buffer -----------------------------------------------------
 // torch.optim.Adam(params, lr) as the reference configures it (nerf_system.py:71-72: betas (0.9, 0.999), eps 1e-8, no

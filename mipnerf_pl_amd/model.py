@@ -325,6 +325,63 @@ class MipNerf(torch.nn.Module):
             return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand)
         return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand)
 
+    def train_step_native(self, rays: Rays, gt_rgb, randomized: bool, white_bkgd: bool, coarse_loss_mult: float = 0.1,
+                          distloss_mult: float = 0.01, disable_multiscale_loss: bool = False, t_rand=None, u_rand=None,
+                          return_outputs: bool = False):
+        """forward + loss (nerf_system.py:99-111) + backward of the whole hot path in ONE native call
+        (mipnerf_train_step): no autograd graph.  The gradient of the loss lands in the parameters' .grad (zero-copy
+        when the MLP is in flat mode, `mlp.flatten_parameters()`).  Returns (scalars [6] tensor = loss, mse_c, mse_f,
+        distloss_c, distloss_f, psnr_fine, outputs or None).  bf16 precision only."""
+        if self.precision != L.PREC_BF16:
+            raise NotImplementedError("train_step_native is the bf16 path; fp32 parity mode trains through autograd")
+        dev = rays.origins.device
+        if not rays.origins.is_cuda:
+            raise RuntimeError("train_step_native needs rays on a HIP device; there is no CPU fallback")
+        B, N = rays.origins.shape[0], self.num_samples
+        mlp = self.mlp
+        ctx = mlp.native(dev)
+        f = [ops._f32c(getattr(rays, k), k) for k in Rays._fields]
+        rp = L.RaysPtrs(*[t.data_ptr() for t in f])
+        gt = ops._f32c(gt_rgb[..., :3], "gt_rgb")
+        if randomized:
+            t_rand = torch.rand(B, N + 1, device=dev) if t_rand is None else ops._f32c(t_rand, "t_rand")
+            u_rand = torch.rand(B, N + 1, device=dev) if u_rand is None else ops._f32c(u_rand, "u_rand")
+        if randomized and self.density_noise > 0:
+            raise NotImplementedError("density_noise > 0 is not implemented (reference default 0)")
+        need = int(L.lib().mipnerf_train_workspace_bytes(ctx.handle, B))
+        ws = ctx.scratch("train_step", need)
+        flat_mode = mlp.grads_are_flat() or (mlp.is_flat() and all(p.grad is None for p in mlp.ordered_params()))
+        if flat_mode:
+            mlp.gather_foreign_grads()          # re-attaches the .grad views if zero_grad(set_to_none=True) dropped them
+            grad, accumulate = mlp._flat_grad, 1 if mlp._flat_grad_valid else 0
+        else:
+            total = sum(p.numel() for p in mlp.ordered_params())
+            grad, accumulate = torch.empty(total, device=dev, dtype=torch.float32), 0
+        scalars = torch.empty(6, device=dev, dtype=torch.float32)
+        outs, ret = None, None
+        if return_outputs:
+            outs = (L.LevelOut * self.num_levels)()
+            ret = []
+            for lvl in range(self.num_levels):
+                tens = (torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev),
+                        torch.empty(B, N, device=dev), torch.empty(B, N + 1, device=dev))
+                outs[lvl] = L.LevelOut(*[t.data_ptr() for t in tens])
+                ret.append(tens)
+        flags = L.FLAG_WHITE_BKGD if white_bkgd else 0
+        L.check(L.lib().mipnerf_train_step(ctx.handle, B, C.byref(rp), gt.data_ptr(), t_rand.data_ptr() if randomized else None,
+                                           u_rand.data_ptr() if randomized else None, flags, float(coarse_loss_mult),
+                                           float(distloss_mult), int(bool(disable_multiscale_loss)), ws.data_ptr(), ws.numel(),
+                                           grad.data_ptr(), accumulate, scalars.data_ptr(), outs, ops._stream()), "train_step")
+        if flat_mode:
+            mlp._flat_grad_valid = True
+        else:
+            off = 0
+            for p in mlp.ordered_params():
+                g = grad[off:off + p.numel()].view(p.shape)
+                p.grad = g if p.grad is None else p.grad.add_(g)
+                off += p.numel()
+        return scalars, ret
+
     def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None):
         dev = rays.origins.device
         B, N = rays.origins.shape[0], self.num_samples

@@ -173,6 +173,17 @@ class MipNeRFSystem(_Base):
         self.log('train/psnr', psnr_fine, prog_bar=True)
         return loss
 
+    def training_step_native(self, batch, batch_nb=0):
+        """training_step + loss.backward() in one native call (no autograd graph; bf16): the gradients are in
+        `.grad` when it returns.  Returns the detached loss; logs like training_step."""
+        rays, rgbs = batch
+        scalars, _ = self.mip_nerf.train_step_native(
+            rays, rgbs, self.train_randomized, self.white_bkgd, coarse_loss_mult=self.hparams['loss.coarse_loss_mult'],
+            disable_multiscale_loss=self.hparams['loss.disable_multiscale_loss'])
+        self.log('train/loss', scalars[0])
+        self.log('train/psnr', scalars[5], prog_bar=True)
+        return scalars[0]
+
     def validation_step(self, batch, batch_nb):   # nerf_system.py:123-142 (TensorBoard images left to the caller)
         _, rgbs = batch
         rgb_gt = rgbs[..., :3]

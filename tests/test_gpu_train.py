@@ -362,3 +362,42 @@ def test_end_to_end_training_bf16_tracks_fp32(G):
     G.record("train_synthetic_160", bf16_psnr0=b[0][2], bf16_psnr=b[-1][2], fp32_psnr=f[-1][2])
     assert b[-1][2] > b[0][2] + 4.0 and f[-1][2] > f[0][2] + 4.0
     assert abs(b[-1][2] - f[-1][2]) <= 1.0
+
+
+@pytest.mark.parametrize("flat", [True, False])
+def test_native_train_step_equals_autograd_path(G, flat):
+    """mipnerf_train_step (forward + loss + backward in one native call, no autograd graph) against
+    training_step + loss.backward() through the custom autograd Functions: same kernels underneath, so loss and every
+    gradient must agree to fp32 round-off (the loss reduction runs in fp64 instead of torch's fp32)."""
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    g = G.load_golden("train_64x64_trained")
+    rays, gt = G.to_dev(G.rays_of(g)), torch.from_numpy(g["gt"]).to(DEV)
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    res = {}
+    for native in (False, True):
+        hp = dict(DEFAULT_HPARAMS)
+        hp.update({'nerf.num_samples': 64, 'train.randomized': False})
+        system = MipNeRFSystem(hp, precision="bf16")
+        system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        system = system.to(DEV)
+        if flat:
+            system.mip_nerf.mlp.flatten_parameters()
+        if native:
+            loss = system.training_step_native((rays, gt), 0)
+            loss2 = system.training_step_native((rays, gt), 1)          # second call accumulates like a second backward()
+            grads2 = torch.cat([p.grad.reshape(-1) for p in system.mip_nerf.parameters()]).clone()
+        else:
+            loss = system.training_step((rays, gt), 0)
+            loss.backward()
+        grads = torch.cat([p.grad.reshape(-1) for p in system.mip_nerf.parameters()]).clone()
+        res[native] = (float(loss), grads, float(system.logged['train/psnr']))
+        if native:
+            assert abs(float(loss2) - float(loss)) < 1e-7
+            assert G.maxdiff(grads2, 2.0 * res[False][1]) <= 2e-5 * float(res[False][1].abs().max())
+            grads = grads2 / 2.0
+            res[native] = (float(loss), grads, res[native][2])
+    (l0, g0, p0), (l1, g1, p1) = res[False], res[True]
+    eg = G.maxdiff(g0, g1) / float(g0.abs().max())
+    G.record(f"native_train_step flat={flat}", loss_autograd=l0, loss_native=l1, grad_rel=eg, psnr_autograd=p0, psnr_native=p1)
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)) and abs(p0 - p1) <= 1e-3 and eg <= 2e-5
+    assert abs(l1 - float(g["loss"])) <= 5e-3      # and the bf16 loss is the reference's loss (fp32) to bf16 accuracy
