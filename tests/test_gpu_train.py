@@ -401,3 +401,17 @@ def test_native_train_step_equals_autograd_path(G, flat):
     G.record(f"native_train_step flat={flat}", loss_autograd=l0, loss_native=l1, grad_rel=eg, psnr_autograd=p0, psnr_native=p1)
     assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)) and abs(p0 - p1) <= 1e-3 and eg <= 2e-5
     assert abs(l1 - float(g["loss"])) <= 5e-3      # and the bf16 loss is the reference's loss (fp32) to bf16 accuracy
+
+
+def test_mlp_module_forward_is_differentiable(G):
+    """The standalone MLP module (models/mip_nerf.py:14-111 contract) must produce gradients when called under
+    autograd, like the reference's nn.Module."""
+    params, enc, venc, d_raw = _mlp_case(4, 32, seed=3)
+    model = G.make_model(params, 32, "bf16")
+    rgb, den = model.mlp(torch.from_numpy(enc).to(DEV), torch.from_numpy(venc).to(DEV))
+    assert rgb.shape == (4, 32, 3) and den.shape == (4, 32, 1) and rgb.requires_grad
+    (rgb.sum() + den.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.mlp.parameters())
+    with torch.no_grad():
+        rgb2, den2 = model.mlp(torch.from_numpy(enc).to(DEV), torch.from_numpy(venc).to(DEV))
+    assert G.maxdiff(rgb, rgb2) <= 1e-6 and not rgb2.requires_grad     # same forward numbers with or without the graph
