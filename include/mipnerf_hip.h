@@ -247,6 +247,18 @@ int mipnerf_adam_step(int64_t n, float* param, const float* grad, float* exp_avg
  * timing only).  NULL restores the default.  Changes partial_bytes of mipnerf_mlp_train_sizes; synchronises. */
 int mipnerf_set_wgrad_splits(mipnerf_ctx* ctx, const int32_t* splits_host);
 
+/* ---- parity-mode (fp32) MLP training: the fused fp32 forward also writes every layer output into `save`
+ * (mipnerf_mlp_train_f32_bytes), the backward is dgrad / wgrad GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32
+ * products, fp32 accumulation).  enc [M,96] and viewenc [B,32] are fp32.  Correctness-first. */
+size_t mipnerf_mlp_train_f32_bytes(const mipnerf_ctx* ctx, int64_t num_points, size_t* save_bytes,
+                                   size_t* workspace_bytes);
+int mipnerf_mlp_forward_train_f32(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples, const float* enc,
+                                  const float* viewenc, float* rgb_sigma, float* raw, float* save,
+                                  void* stream);
+int mipnerf_mlp_backward_f32(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples, const float* d_raw,
+                             const float* enc, const float* viewenc, const float* save, void* workspace,
+                             float* grad_flat, int32_t accumulate, void* stream);
+
 /* ---- the whole training step (bf16): MipNeRFSystem.training_step (nerf_system.py:95-111) + loss.backward() --------
  * forward of all levels with saved activations, loss = cm (mse_c + dm dl_c) + mse_f + dm dl_f (cm = loss.coarse_loss_mult,
  * dm = 0.01, mse masked by rays.lossmult unless disable_multiscale_loss), backward of compositing / activations / MLP.

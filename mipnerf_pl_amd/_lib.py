@@ -69,6 +69,9 @@ SIGNATURES = {
     "mipnerf_mlp_dgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P]),
     "mipnerf_mlp_wgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P]),
     "mipnerf_set_wgrad_splits": (C.c_int, [_P, _P]),
+    "mipnerf_mlp_train_f32_bytes": (_SZ, [_P, _I64, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "mipnerf_mlp_forward_train_f32": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "mipnerf_mlp_backward_f32": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "mipnerf_train_workspace_bytes": (_SZ, [_P, _I64]),
     "mipnerf_train_step": (C.c_int, [_P, _I64, C.POINTER(RaysPtrs), _P, _P, _P, C.c_uint32, _F, _F, _I32, _P, _SZ, _P, _I32, _P,
                                      C.POINTER(LevelOut), _P]),

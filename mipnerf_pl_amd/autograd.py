@@ -4,8 +4,9 @@ Native (HIP) in both directions: sampling, conical-frustum + IPE, view encoding,
 forward-with-save, dgrad and wgrad MFMA kernels, see mlp_train_plan.py), activations, volumetric rendering and
 its backward (fused with the activation derivatives), resampling, distloss.  torch.autograd only chains the
 native pieces (custom Functions) and owns the buffers.
-fp32 ("parity") mode: the MLP runs through torch's Linear ops in fp32 so that autograd supplies exact-fp32
-dgrad/wgrad for the gradient-parity tests against the reference; every other stage is the same native kernel.
+fp32 ("parity") mode: fused exact-fp32 MFMA forward that saves the layer outputs + GEMM-based dgrad / wgrad on the
+fp32 matrix instruction (kernels_gemm_f32.hip) -- the instrument of the gradient-parity tests against the reference.
+`mlp_torch` below is a plain-PyTorch restatement of the same op, kept as a test reference only.
 """
 from __future__ import annotations
 
@@ -132,6 +133,56 @@ class _MLPNative(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+class _MLPNativeF32(torch.autograd.Function):
+    """Parity-mode (fp32) MLP under autograd: fused exact-fp32 MFMA forward that saves every layer output, backward =
+    dgrad / wgrad GEMMs on v_mfma_f32_32x32x2_f32 (kernels_gemm_f32.hip).  No library GEMM."""
+
+    @staticmethod
+    def forward(ctx, mlp, enc, venc, *params):
+        dev = enc.device
+        nctx = mlp.native(dev)
+        B, N = enc.shape[0], enc.shape[1]
+        M = B * N
+        if enc.dtype != torch.float32 or venc.dtype != torch.float32 or venc.shape[-1] != 32:
+            raise TypeError("fp32 MLP training path: enc [B,N,96] and viewenc [B,32] must be float32")
+        enc, venc = enc.contiguous(), venc.contiguous()
+        import ctypes as C
+        sb, wb = C.c_size_t(), C.c_size_t()
+        L.lib().mipnerf_mlp_train_f32_bytes(nctx.handle, M, C.byref(sb), C.byref(wb))
+        save = torch.empty(int(sb.value), dtype=torch.uint8, device=dev)
+        raw = torch.empty(B, N, 4, device=dev, dtype=torch.float32)
+        rgb_sigma = torch.empty_like(raw)
+        L.check(L.lib().mipnerf_mlp_forward_train_f32(nctx.handle, M, N, enc.data_ptr(), venc.data_ptr(), rgb_sigma.data_ptr(),
+                                                      raw.data_ptr(), save.data_ptr(), ops._stream()), "mlp_forward_train_f32")
+        ctx.save_for_backward(save, enc, venc)
+        ctx.nctx, ctx.M, ctx.N, ctx.ws_bytes = nctx, M, N, int(wb.value)
+        ctx.shapes = [p.shape for p in params]
+        return raw
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        save, enc, venc = ctx.saved_tensors
+        nctx = ctx.nctx
+        d_raw = d_raw.contiguous().float()
+        ws = nctx.scratch("f32_bwd", ctx.ws_bytes)
+        total = sum(int(torch.Size(s).numel()) for s in ctx.shapes)
+        grad_flat = torch.empty(total, device=save.device, dtype=torch.float32)
+        L.check(L.lib().mipnerf_mlp_backward_f32(nctx.handle, ctx.M, ctx.N, d_raw.data_ptr(), enc.data_ptr(), venc.data_ptr(),
+                                                 save.data_ptr(), ws.data_ptr(), grad_flat.data_ptr(), 0, ops._stream()),
+                "mlp_backward_f32")
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = int(torch.Size(shp).numel())
+            grads.append(grad_flat[off:off + n].view(shp))
+            off += n
+        return (None, None, None, *grads)
+
+
+def mlp_native_f32(mlp, samples_enc, viewdirs_enc):
+    """Differentiable fp32 MLP: samples_enc [B,N,96] fp32, viewdirs_enc [B,32] fp32 (27 + zero pad) -> raw [B,N,4]."""
+    return _MLPNativeF32.apply(mlp, samples_enc, viewdirs_enc, *mlp.ordered_params())
+
+
 def mlp_native(mlp, samples_enc, viewdirs_enc):
     """Differentiable bf16 MLP: samples_enc [B,N,96] bf16, viewdirs_enc [B,32] bf16 -> raw [B,N,4] fp32."""
     return _MLPNative.apply(mlp, samples_enc, viewdirs_enc, *mlp.ordered_params())
@@ -175,10 +226,7 @@ def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_ra
     N = model.num_samples
     model.mlp.native(dev)      # raises NotImplementedError for an MLP shape the kernels were not generated for
     with torch.no_grad():
-        if native:
-            venc = ops.pos_enc(rays.viewdirs, 0, model.deg_view, True, precision=L.PREC_BF16, ld=32)
-        else:
-            venc = ops.pos_enc(rays.viewdirs, 0, model.deg_view, True)
+        venc = ops.pos_enc(rays.viewdirs, 0, model.deg_view, True, precision=model.precision, ld=32)
     ret = []
     t_samples, weights = None, None
     for lvl in range(model.num_levels):
@@ -189,7 +237,7 @@ def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_ra
                 t_samples = ops.resample_t(t_samples, weights.detach(), randomized, model.resample_padding, u_rand)
             enc = ops.cast_ipe(t_samples, rays.origins, rays.directions, rays.radii, model.min_deg_point,
                                model.max_deg_point, model.disable_integration, precision=model.precision)
-        raw = mlp_native(model.mlp, enc, venc) if native else mlp_torch(model.mlp, enc, venc, dtype)
+        raw = mlp_native(model.mlp, enc, venc) if native else mlp_native_f32(model.mlp, enc, venc)
         comp_rgb, distance, acc, weights = render_from_raw(raw, t_samples, rays.directions, white_bkgd,
                                                            model.rgb_padding, model.density_bias)
         ret.append((comp_rgb, distance, acc, weights, t_samples))

@@ -408,7 +408,7 @@ int mipnerf_mlp_forward(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, c
                                      c->cfg.rgb_padding, c->grid_limit, c->mlp_dma != 0, S(stream)));
     } else if (precision == MIPNERF_PREC_FP32) {
         HIP_TRY(mip::launch_mlp_f32(c->tab.net, c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
-                                    rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, S(stream)));
+                                    rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, S(stream)));
     } else {
         return fail(MIPNERF_E_INVALID, "unknown precision %d", precision);
     }
@@ -590,6 +590,98 @@ int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host) {
     return MIPNERF_OK;
 }
 
+
+
+// ---- parity-mode (fp32) MLP training: fused forward that saves every layer output + GEMM-based backward ------------
+// `save` = 10 slots of [M, 256] fp32 (layers 0..7 outputs, bottleneck, view-layer output [M,128] in slot 9).
+size_t mipnerf_mlp_train_f32_bytes(const mipnerf_ctx* c, int64_t M, size_t* save_bytes, size_t* workspace_bytes) {
+    using namespace mip::plan;
+    if (!c || M < 1) return 0;
+    const size_t save = (size_t)(kNetDepth + 2) * M * kNetWidth * 4;
+    const int splits = 64;
+    const size_t ws = 2 * (size_t)M * kNetWidth * 4 + (size_t)splits * kNetWidth * (kNetWidth + kXyzDim) * 4 + 1024;
+    if (save_bytes) *save_bytes = save;
+    if (workspace_bytes) *workspace_bytes = ws;
+    return save + ws;
+}
+
+int mipnerf_mlp_forward_train_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* enc, const float* viewenc, float* rgb_sigma,
+                                  float* raw, float* save, void* stream) {
+    if (!c || M < 1 || N < 1 || !enc || !viewenc || !rgb_sigma || !raw || !save)
+        return fail(MIPNERF_E_INVALID, "mlp_forward_train_f32: bad argument");
+    if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train_f32: mipnerf_set_params has not been called");
+    HIP_TRY(mip::launch_mlp_f32(c->tab.net, c->d_stream_f32, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias,
+                                c->cfg.rgb_padding, save, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* d_raw, const float* enc, const float* viewenc,
+                             const float* save, void* workspace, float* grad_flat, int32_t accumulate, void* stream) {
+    using namespace mip::plan;
+    if (!c || M < 1 || N < 1 || !d_raw || !enc || !viewenc || !save || !workspace || !grad_flat)
+        return fail(MIPNERF_E_INVALID, "mlp_backward_f32: bad argument");
+    if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_backward_f32: mipnerf_set_params has not been called");
+    if (M > 0x7fffffff) return fail(MIPNERF_E_INVALID, "mlp_backward_f32: too many samples");
+    const int W = kNetWidth, Wc = kNetWidthCond, E = kXyzDim, D = kNetDepth, V = kViewDim;
+    const int splits = 64, Mi = (int)M;
+    hipStream_t st = S(stream);
+    float* g0 = reinterpret_cast<float*>(workspace);
+    float* g1 = g0 + (size_t)M * W;
+    float* part = g1 + (size_t)M * W;
+    const bool acc = accumulate != 0;
+    auto slot = [&](int L) { return save + (size_t)L * M * W; };
+    auto P = [&](int t) { return c->pp.p[t]; };                       // fp32 master parameter t (state_dict order)
+    auto G = [&](int t) { return grad_flat + c->tab.tensor_off[t]; }; // its gradient
+    const int tDensW = 2 * D, tDensB = 2 * D + 1, tExW = 2 * D + 2, tExB = 2 * D + 3, tVW = 2 * D + 4, tVB = 2 * D + 5,
+              tCW = 2 * D + 6, tCB = 2 * D + 7;
+    const float* hv = slot(D + 1);     // [M, Wc]
+    const float* bott = slot(D);       // [M, W]
+    const float* x8 = slot(D - 1);
+    // wgrad / bias helpers: dW[out, ldw] (cols [col0, col0+n)) (+)= dY[M, out]^T X[M, n];  db[out] (+)= dY^T 1
+    auto wgrad = [&](const float* dY, int64_t ldy, int nout, const float* X, int64_t ldx, int rowdiv, int ncols, float* dW, int64_t ldw) {
+        return mip::launch_gemm_f32(true, nout, ncols, M, dY, ldy, X, ldx, rowdiv, false, dW, ldw, acc, splits, part, st);
+    };
+    auto bgrad = [&](const float* dY, int64_t ldy, int nout, float* db) {
+        return mip::launch_gemm_f32(true, nout, 1, M, dY, ldy, nullptr, 0, 1, true, db, 1, acc, splits, part, st);
+    };
+    // colour layer (mip_nerf.py:110): d_rgb = d_raw[:, 0:3]
+    HIP_TRY(wgrad(d_raw, 4, kNumRgb, hv, Wc, 1, Wc, G(tCW), Wc));
+    HIP_TRY(bgrad(d_raw, 4, kNumRgb, G(tCB)));
+    // g_hv = (d_rgb Wc) * relu'   [M, Wc] in g0
+    HIP_TRY(mip::launch_gemm_f32(false, Mi, Wc, kNumRgb, d_raw, 4, P(tCW), Wc, 1, false, g0, Wc, false, 1, nullptr, st));
+    HIP_TRY(mip::launch_relu_mask((int64_t)M * Wc, hv, g0, st));
+    // view layer (mip_nerf.py:106-109): input [bottleneck | view encoding of the sample's ray]
+    HIP_TRY(wgrad(g0, Wc, Wc, bott, W, 1, W, G(tVW), W + V));
+    HIP_TRY(wgrad(g0, Wc, Wc, viewenc, 32, N, V, G(tVW) + W, W + V));
+    HIP_TRY(bgrad(g0, Wc, Wc, G(tVB)));
+    // g_bott = g_hv Wv[:, :W]   [M, W] in g1
+    HIP_TRY(mip::launch_gemm_f32(false, Mi, W, Wc, g0, Wc, P(tVW), W + V, 1, false, g1, W, false, 1, nullptr, st));
+    // bottleneck (extra_layer, :102) and density head (:100)
+    HIP_TRY(wgrad(g1, W, W, x8, W, 1, W, G(tExW), W));
+    HIP_TRY(bgrad(g1, W, W, G(tExB)));
+    HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W));
+    HIP_TRY(bgrad(d_raw + 3, 4, 1, G(tDensB)));
+    // g8 = (g_bott We + d_den Wd) * relu'(x8)   in g0
+    HIP_TRY(mip::launch_gemm_f32(false, Mi, W, W, g1, W, P(tExW), W, 1, false, g0, W, false, 1, nullptr, st));
+    HIP_TRY(mip::launch_gemm_f32(false, Mi, W, 1, d_raw + 3, 4, P(tDensW), W, 1, false, g0, W, true, 1, nullptr, st));
+    HIP_TRY(mip::launch_relu_mask((int64_t)M * W, x8, g0, st));
+    float* g = g0;          // delta of layer i (gradient w.r.t. its pre-activation)
+    float* gn = g1;
+    for (int i = D - 1; i >= 0; --i) {
+        const int ld = kParamNumel[2 * i] / W;                       // in_features of layer i
+        const float* xin = i == 0 ? enc : slot(i - 1);
+        const int nin = i == 0 ? E : W;
+        HIP_TRY(wgrad(g, W, W, xin, nin, 1, nin, G(2 * i), ld));
+        if (ld > nin) HIP_TRY(wgrad(g, W, W, enc, E, 1, E, G(2 * i) + W, ld));      // skip concat (:96-97)
+        HIP_TRY(bgrad(g, W, W, G(2 * i + 1)));
+        if (i > 0) {
+            HIP_TRY(mip::launch_gemm_f32(false, Mi, W, W, g, W, P(2 * i), ld, 1, false, gn, W, false, 1, nullptr, st));
+            HIP_TRY(mip::launch_relu_mask((int64_t)M * W, slot(i - 1), gn, st));
+            float* t = g; g = gn; gn = t;
+        }
+    }
+    return MIPNERF_OK;
+}
 
 // ---- the whole training step of the hot path in one call ---------------------------------------------------------
 // MipNeRFSystem.training_step (nerf_system.py:95-111) = MipNerf.forward(randomized) + loss, followed by what

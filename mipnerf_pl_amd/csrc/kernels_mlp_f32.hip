@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256)
 k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __restrict__ bias_tab,
           const float* __restrict__ enc, const float* __restrict__ viewenc, float4* __restrict__ rgb_sigma,
           float4* __restrict__ raw_out, int64_t M, int num_samples, int ntiles_total, float density_bias,
-          float rgb_padding) {
+          float rgb_padding, float* __restrict__ save) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* X = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x;
@@ -148,13 +148,27 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                 }
             }
             __syncthreads();
+            if (save && ly.kind != 2) {
+                // training (parity mode): keep this layer's output -- slot L of `save` is [M, width] fp32, width =
+                // 32 x (hidden tiles); the density tile of the head is not part of the bottleneck.  The next write
+                // to X happens behind the next layer's barrier, i.e. after every thread finished this copy.
+                const int width = 32 * (ly.ntiles - (ly.kind == 1 ? 1 : 0));
+                float* dst = save + (int64_t)L * M * W;
+                const int vpr = width / 4;
+                for (int i = tid; i < kF32TileSamples * vpr; i += blockDim.x) {
+                    const int r = i / vpr, c4 = i - r * vpr;
+                    const int64_t s = s0 + r;
+                    if (s < M)
+                        *reinterpret_cast<float4*>(dst + s * width + c4 * 4) = *reinterpret_cast<const float4*>(X + r * ldx + c4 * 4);
+                }
+            }
         }
     }
 }
 
 hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float* bias_tab, const float* enc,
                           const float* viewenc, float* rgb_sigma, float* raw_out, int64_t M, int num_samples,
-                          float density_bias, float rgb_padding, hipStream_t st) {
+                          float density_bias, float rgb_padding, float* save, hipStream_t st) {
     const int ntiles = (int)((M + kF32TileSamples - 1) / kF32TileSamples);
     const int lds = kF32TileSamples * net.ldx * (int)sizeof(float);
     static int attr_lds = 0;
@@ -166,7 +180,7 @@ hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float*
     int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_mlp_f32, dim3(grid), dim3(256), lds, st, net, stream_w, bias_tab, enc, viewenc,
-                       (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding);
+                       (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save);
     return hipGetLastError();
 }
 

@@ -245,14 +245,10 @@ class MLP(torch.nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and not return_activated:
             # differentiable w.r.t. the parameters (like the reference module under autograd): native bf16 training
             # kernels, or torch's fp32 Linear ops in parity mode (autograd.py)
-            from .autograd import mlp_native, mlp_torch
-            if prec == L.PREC_BF16:
-                venc = torch.zeros(B, 32, device=x.device, dtype=dt)
-                venc[:, :view_direction.shape[-1]] = view_direction.to(dt)
-                raw = mlp_native(self, x.to(dt), venc)
-            else:
-                self.native(x.device)
-                raw = mlp_torch(self, x, view_direction, torch.float32)
+            from .autograd import mlp_native, mlp_native_f32
+            venc = torch.zeros(B, 32, device=x.device, dtype=dt)
+            venc[:, :view_direction.shape[-1]] = view_direction.to(dt)
+            raw = mlp_native(self, x.to(dt), venc) if prec == L.PREC_BF16 else mlp_native_f32(self, x.to(dt), venc)
             return raw[..., :3], raw[..., 3:4]
         ctx = self.native(x.device)
         enc = x.to(dt).contiguous()

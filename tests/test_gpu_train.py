@@ -415,3 +415,36 @@ def test_mlp_module_forward_is_differentiable(G):
     with torch.no_grad():
         rgb2, den2 = model.mlp(torch.from_numpy(enc).to(DEV), torch.from_numpy(venc).to(DEV))
     assert G.maxdiff(rgb, rgb2) <= 1e-6 and not rgb2.requires_grad     # same forward numbers with or without the graph
+
+
+def test_fp32_native_mlp_backward_matches_reference_golden(G):
+    """Parity mode: fused fp32 forward-with-save + fp32-MFMA GEMM backward against the reference's autograd gradients
+    (golden, full fp32 tolerance) and against a plain-PyTorch fp32 restatement of the same op."""
+    from mipnerf_pl_amd.autograd import mlp_native_f32, mlp_torch
+    g = G.load_golden("mlp_bwd_8x32_trained")
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    d_raw = torch.from_numpy(np.concatenate([g["d_rgb"], g["d_den"]], -1)).to(DEV)
+    enc = torch.from_numpy(g["enc"]).to(DEV)
+    v32 = torch.zeros(8, 32, device=DEV)
+    v32[:, :27] = torch.from_numpy(g["venc"]).to(DEV)
+    res = {}
+    for name, fn in (("native", lambda m: mlp_native_f32(m.mlp, enc, v32)),
+                     ("torch", lambda m: mlp_torch(m.mlp, enc, v32[:, :27], torch.float32))):
+        model = G.make_model(params, 32, "fp32")
+        raw = fn(model)
+        (raw * d_raw).sum().backward()
+        res[name] = (raw.detach(), {k: p.grad.detach().cpu().numpy() for k, p in model.mlp.named_parameters()})
+    raw = res["native"][0].cpu().numpy()
+    assert G.maxdiff(raw[..., :3], g["raw_rgb"]) <= 2e-5 and G.maxdiff(raw[..., 3:], g["raw_density"]) <= 2e-4
+    worst = 0.0
+    for k, gr in res["native"][1].items():
+        flat, ref = gr.ravel(), g["g_smp_" + k]
+        stride = max(1, flat.size // ref.size)
+        smp = flat[::stride][:ref.size]
+        l2 = float(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        rel_l2 = abs(l2 - float(g["g_l2_" + k])) / float(g["g_l2_" + k])
+        es = float(np.max(np.abs(smp - ref))) / max(float(np.max(np.abs(ref))), 1e-20)
+        et = float(np.max(np.abs(gr - res["torch"][1][k]))) / max(float(np.max(np.abs(res["torch"][1][k]))), 1e-20)
+        worst = max(worst, rel_l2, es, et)
+        assert rel_l2 <= 1e-4 and es <= 1e-4 and et <= 1e-4, (k, rel_l2, es, et)
+    G.record("fp32_native_mlp_bwd_vs_reference_golden", worst=worst)
