@@ -86,6 +86,11 @@ void build_tables(Tables& T) {
         for (int s = 0; s < op.nsegs; ++s) nk += op.segs[s].nk;
         for (int t = 0; t < op.ntiles; t += 2) {
             const bool pair = t + 1 < op.ntiles;
+            if (kChainOrder) {
+                for (int ks = 0; ks < nk; ++ks) fill_chunk(op, t, ks);
+                if (pair) for (int ks = 0; ks < nk; ++ks) fill_chunk(op, t + 1, ks);
+                continue;
+            }
             for (int ks = 0; ks < nk; ++ks) {
                 fill_chunk(op, t, ks);
                 if (pair) fill_chunk(op, t + 1, ks);

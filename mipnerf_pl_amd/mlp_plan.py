@@ -35,6 +35,9 @@ from typing import List, Tuple
 
 import numpy as np
 
+import os
+
+CHAIN = os.environ.get("MLP_CHAIN", "0") == "1"   # weight-stream order knob (inference kernel experiments)
 TILE = 32          # MFMA M/N
 KSTEP = 16         # MFMA K (bf16 32x32x16)
 NATURAL, DLAYOUT = 0, 1
@@ -174,12 +177,19 @@ class Plan:
         p.ops.append(Op("color", [Seg(cur, DLAYOUT, Wc // KSTEP, 0, Wc)],
                         [TileSrc(pid["color_layer.weight"], pid["color_layer.bias"], 0, a.num_rgb, Wc)],
                         False, "rgb"))
-        # chunk order: panels of two tiles interleaved per k-step, odd tile alone
+        # chunk order: panels of two tiles interleaved per k-step, odd tile alone (CHAIN: tile after tile, i.e.
+        # back-to-back MFMAs on the SAME accumulator -- an experiment knob of the inference kernel, see gen_mlp_bf16.py)
         gt = 0
         for oi, op in enumerate(p.ops):
             op.first_tile = gt
             gt += len(op.tiles)
             for (t0, t1) in p.panels(op):
+                if CHAIN:
+                    for t in (t0, t1):
+                        if t is not None:
+                            for ks in range(op.nk):
+                                p.chunks.append((oi, t, ks))
+                    continue
                 for ks in range(op.nk):
                     p.chunks.append((oi, t0, ks))
                     if t1 is not None:
