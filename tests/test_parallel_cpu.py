@@ -36,6 +36,17 @@ def _worker(rank, world, port, out):
         mean01 = (1 + 2) / 2.0
         ok = all(torch.allclose(p.grad, torch.full_like(p, mean01 * (i + 1))) for i, p in enumerate(params[:2]))
         ok = ok and torch.count_nonzero(params[2].grad) == 0
+        # flat mode (MLP.flatten_parameters): the gradient buffer the wgrad reduction writes is all-reduced IN PLACE
+        from mipnerf_pl_amd import MipNerf
+        model = MipNerf(num_samples=8)
+        mlp = model.mlp.flatten_parameters()
+        assert mlp.is_flat() and mlp.grads_are_flat() and list(model.state_dict().keys())[0] == "mlp.layers.0.0.weight"
+        mlp._flat_grad.copy_(torch.arange(mlp._flat_grad.numel(), dtype=torch.float32) * (rank + 1))
+        ptr = mlp._flat_grad.data_ptr()
+        FlatGradAllReduce(list(model.parameters()), mlp=mlp)()
+        want = torch.arange(mlp._flat_grad.numel(), dtype=torch.float32) * 1.5
+        ok = ok and mlp._flat_grad.data_ptr() == ptr and torch.allclose(mlp._flat_grad, want)
+        ok = ok and torch.allclose(model.mlp.color_layer.bias.grad, want[-3:])     # .grad are views of the reduced buffer
         # rendering: shard 11 rays, "render" = 2*origin, gather
         n = 11
         rays = Rays(*[torch.arange(n * k, dtype=torch.float32).reshape(n, k) for k in (3, 3, 3, 1, 1, 1, 1)])
