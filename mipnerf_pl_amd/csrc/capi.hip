@@ -144,6 +144,8 @@ void build_tables(Tables& T) {
     }
 }
 
+bool max_deg_span_is_16(const mipnerf_config& cfg) { return cfg.max_deg_point - cfg.min_deg_point == 16 && cfg.min_deg_point >= 0 && cfg.max_deg_point <= 31; }
+
 int off_total(const Tables& T) {
     return T.tensor_off.back() + mip::plan::kParamNumel[mip::plan::kNumParamTensors - 1];
 }
@@ -206,6 +208,7 @@ struct mipnerf_ctx {
     mip::ParamPtrs pp;               // device pointers of the fp32 master parameters (last mipnerf_set_params)
     bool params_set = false;
     int mlp_dma = 1;                 // 1: global_load_lds ring, 0: register-staged ring (debug)
+    int fused_ipe = 1;               // bf16 mipnerf_forward: IPE computed inside the MLP kernel (0: k_cast_ipe + enc buffer)
     int grid_limit = 256;            // persistent workgroups of the bf16 MLP kernel (= CUs)
     // optional instrumentation: HIP events around every MLP launch made by mipnerf_forward
     int time_mlp = 0;
@@ -340,6 +343,7 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
         case 0: c->mlp_dma = value ? 1 : 0; return MIPNERF_OK;
         case 1: if (value < 1) return fail(MIPNERF_E_INVALID, "grid_limit < 1"); c->grid_limit = value; return MIPNERF_OK;
         case 2: c->time_mlp = value ? 1 : 0; c->ev_used = 0; return MIPNERF_OK;
+        case 3: c->fused_ipe = value ? 1 : 0; return MIPNERF_OK;
         default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
     }
 }
@@ -410,7 +414,7 @@ int mipnerf_mlp_forward(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, c
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward: mipnerf_set_params has not been called");
     if (precision == MIPNERF_PREC_BF16) {
         HIP_TRY(mip::launch_mlp_bf16(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias,
-                                     c->cfg.rgb_padding, c->grid_limit, c->mlp_dma != 0, S(stream)));
+                                     c->cfg.rgb_padding, c->grid_limit, c->mlp_dma != 0, nullptr, S(stream)));
     } else if (precision == MIPNERF_PREC_FP32) {
         HIP_TRY(mip::launch_mlp_f32(c->tab.net, c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
                                     rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, S(stream)));
@@ -512,7 +516,7 @@ int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* 
         return fail(MIPNERF_E_INVALID, "mlp_forward_train: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train: mipnerf_set_params has not been called");
     HIP_TRY(mip::launch_mlp_bf16_trainfwd(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, act, masks, M, N,
-                                          c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, S(stream)));
+                                          c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, nullptr, S(stream)));
     return MIPNERF_OK;
 }
 
@@ -745,10 +749,18 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
         } else {
             if ((rc = mipnerf_resample_along_rays(B, N, lv[l - 1].t, lv[l - 1].w, u_rand, cfg.resample_padding, lv[l].t, stream))) return rc;
         }
-        if ((rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, lv[l].t, rays->origins,
-                                   rays->directions, rays->radii, lv[l].enc, MIPNERF_PREC_BF16, stream))) return rc;
-        if ((rc = mipnerf_mlp_forward_train(c, (int64_t)M, N, lv[l].enc, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act,
-                                            lv[l].masks, stream))) return rc;
+        if (c->fused_ipe && max_deg_span_is_16(cfg)) {      // encoding computed inside the forward-with-save kernel
+            const mip::RayInputs ri = {lv[l].t, rays->origins, rays->directions, rays->radii, cfg.min_deg_point,
+                                       cfg.disable_integration};
+            HIP_TRY(mip::launch_mlp_bf16_trainfwd(c->d_stream_bf16, c->d_bias, nullptr, viewenc, lv[l].rgb_sigma, lv[l].raw,
+                                                  lv[l].act, lv[l].masks, (int64_t)M, N, cfg.density_bias, cfg.rgb_padding,
+                                                  c->grid_limit, &ri, S(stream)));
+        } else {
+            if ((rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, lv[l].t, rays->origins,
+                                       rays->directions, rays->radii, lv[l].enc, MIPNERF_PREC_BF16, stream))) return rc;
+            if ((rc = mipnerf_mlp_forward_train(c, (int64_t)M, N, lv[l].enc, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act,
+                                                lv[l].masks, stream))) return rc;
+        }
         if ((rc = mipnerf_volumetric_rendering(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].rgb, lv[l].dist,
                                                lv[l].acc, lv[l].w, stream))) return rc;
         // distloss (mip.py:8-20) forward AND backward in one pass: d loss / d ray_loss is the constant k_l * dm / B
@@ -821,7 +833,9 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
             if ((rc = mipnerf_resample_along_rays(B, N, out[lvl - 1].t_samples, out[lvl - 1].weights, u_rand,
                                                   cfg.resample_padding, o.t_samples, stream))) return rc;
         }
-        if ((rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, o.t_samples,
+        const bool fused = precision == MIPNERF_PREC_BF16 && c->fused_ipe && c->mlp_dma;
+        if (!fused &&
+            (rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, o.t_samples,
                                    rays->origins, rays->directions, rays->radii, enc, precision, stream))) return rc;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (c->time_mlp) {
@@ -831,7 +845,16 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
             e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1]; c->ev_used += 2;
             HIP_TRY(hipEventRecord(e0, S(stream)));
         }
-        if ((rc = mipnerf_mlp_forward(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream))) return rc;
+        if (fused) {
+            if (max_deg_span_is_16(cfg) == false)
+                return fail(MIPNERF_E_UNSUPPORTED, "fused IPE is generated for max_deg-min_deg == 16");
+            const mip::RayInputs ri = {o.t_samples, rays->origins, rays->directions, rays->radii, cfg.min_deg_point,
+                                       cfg.disable_integration};
+            HIP_TRY(mip::launch_mlp_bf16(c->d_stream_bf16, c->d_bias, nullptr, viewenc, rgb_sigma, nullptr, (int64_t)M, N,
+                                         cfg.density_bias, cfg.rgb_padding, c->grid_limit, true, &ri, S(stream)));
+        } else if ((rc = mipnerf_mlp_forward(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream))) {
+            return rc;
+        }
         if (c->time_mlp) HIP_TRY(hipEventRecord(e1, S(stream)));
         if ((rc = mipnerf_volumetric_rendering(B, N, rgb_sigma, o.t_samples, rays->directions, white, o.comp_rgb,
                                                o.distance, o.acc, o.weights, stream))) return rc;

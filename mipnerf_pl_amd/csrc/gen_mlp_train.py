@@ -380,11 +380,12 @@ def gen_trainfwd(tp: TrainPlan) -> str:
                                     kEncWaveBytes=enc_wave_bytes, kLdsBytes=lds_bytes,
                                     kGroupBytes=GROUP * CHUNK_BYTES, kNumGroups=nchunks // GROUP,
                                     kTileSamples=WAVES * 32, kNH=tp.NH, kNMask=tp.NMASK))
+    e("template <bool IPE>")
     e(f"__global__ void __launch_bounds__({WAVES * 64})")
     e("k_mlp_bf16_trainfwd(const char* __restrict__ stream, const float* __restrict__ bias_tab,")
     e("                    const __bf16* __restrict__ enc, const __bf16* __restrict__ viewenc, float4* __restrict__ rgb_sigma,")
     e("                    float4* __restrict__ raw_out, char* __restrict__ HT, char* __restrict__ masks, int64_t M,")
-    e("                    int num_samples, int ntiles, float density_bias, float rgb_padding) {")
+    e("                    int num_samples, int ntiles, float density_bias, float rgb_padding, RayIn rin) {")
     e("    extern __shared__ __attribute__((aligned(16))) char smem[];")
     e("    const int tid = threadIdx.x;")
     e("    const int lane = tid & 63;")
@@ -409,7 +410,12 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     e("        const int64_t ray = sc / num_samples;")
     e("        char* ht_wave = HT + wt * (int64_t)(kNH * 2048);")
     e("        char* mask_wave = masks + wt * (int64_t)(kNMask * 1024);")
-    e(f"        issue_encodings<DMA, {nenc}>(enc + sc * {a.xyz_dim} + hi * 8, viewenc + ray * 32 + hi * 8, encw, lane16);")
+    e("        if (IPE) {      // encoding computed here (registers -> LDS), see ipe_to_lds in gen_mlp_bf16.py")
+    e(f"            issue_encodings<DMA, {nenc}, {nenc}>(nullptr, viewenc + ray * 32 + hi * 8, encw, lane16);")
+    e(f"            ipe_to_lds<{nenc}>(rin, sc, num_samples, hi, encw + lane16);")
+    e("        } else {")
+    e(f"            issue_encodings<DMA, {nenc}, 0>(enc + sc * {a.xyz_dim} + hi * 8, viewenc + ray * 32 + hi * 8, encw, lane16);")
+    e("        }")
     e("        bf16x8 X[16], Y[16], " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ", E0, E1, E2;")
     e("        f32x16 acc00, acc01, acc10, acc11;")
     e("        unsigned mq0 = 0, mq1 = 0, mq2 = 0, mq3 = 0;")
@@ -453,20 +459,27 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     e("int mlp_trainfwd_lds_bytes() { return trainfwd::kLdsBytes; }")
     e("hipError_t launch_mlp_bf16_trainfwd(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,")
     e("                                    float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,")
-    e("                                    float density_bias, float rgb_padding, int grid_limit, hipStream_t st) {")
+    e("                                    float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,")
+    e("                                    hipStream_t st) {")
     e("    using namespace trainfwd;")
     e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
     e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
     e("    if (grid < 1) grid = 1;")
     e("    static bool attr_done = false;")
     e("    if (!attr_done) {")
-    e("        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_bf16_trainfwd, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
+    e("        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_bf16_trainfwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
+    e("        if (er != hipSuccess) return er;")
+    e("        er = hipFuncSetAttribute((const void*)k_mlp_bf16_trainfwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
     e("        if (er != hipSuccess) return er;")
     e("        attr_done = true;")
     e("    }")
-    e(f"    hipLaunchKernelGGL(k_mlp_bf16_trainfwd, dim3(grid), dim3({WAVES * 64}), kLdsBytes, st, (const char*)stream_w, bias_tab,")
-    e("                       (const __bf16*)enc, (const __bf16*)viewenc, (float4*)rgb_sigma, (float4*)raw_out, (char*)HT,")
-    e("                       (char*)masks, M, num_samples, ntiles, density_bias, rgb_padding);")
+    e("    RayIn rin = {nullptr, nullptr, nullptr, nullptr, 0, 0};")
+    e("    if (rays) rin = RayIn{rays->t, rays->origins, rays->dirs, rays->radii, rays->min_deg, rays->disable_integration};")
+    e("#define MIP_LAUNCH(I) hipLaunchKernelGGL((k_mlp_bf16_trainfwd<I>), dim3(grid), dim3(%d), kLdsBytes, st, (const char*)stream_w, \\" % (WAVES * 64))
+    e("        bias_tab, (const __bf16*)enc, (const __bf16*)viewenc, (float4*)rgb_sigma, (float4*)raw_out, (char*)HT, (char*)masks, M, \\")
+    e("        num_samples, ntiles, density_bias, rgb_padding, rin)")
+    e("    if (rays) MIP_LAUNCH(true); else MIP_LAUNCH(false);")
+    e("#undef MIP_LAUNCH")
     e("    return hipGetLastError();")
     e("}")
     e("}  // namespace mip")

@@ -123,3 +123,24 @@ def test_full_size_properties(G, precision):
     G.record(f"full_size {precision} B={B}", **errs)
     for k, e in errs.items():
         assert e <= tol[k.split("_", 1)[1]], (k, e)
+
+
+@pytest.mark.parametrize("case", ["fwd_c1_256x64_trained", "fwd_ragged_100x128_trained", "fwd_unbounded_24x256_trained"])
+def test_fused_ipe_equals_separate_kernel(G, case):
+    """bf16 mipnerf_forward computes the integrated positional encoding inside the MLP kernel (registers -> LDS, no
+    [M,96] buffer); with option 3 = 0 it goes through k_cast_ipe + the encoding buffer.  Same device functions, same
+    rounding flags: the two paths must agree bit for bit on every output."""
+    g = G.load_golden(case)
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    model = G.make_model(params, int(g["num_samples"]), "bf16")
+    R = G.to_dev(G.rays_of(g))
+    ctx = model.mlp.native(torch.device(G.DEV))
+    outs = {}
+    for fused in (1, 0):
+        ctx.set_option(3, fused)
+        with torch.no_grad():
+            outs[fused] = [[t.clone() for t in lvl] for lvl in model(R, False, True)]
+    ctx.set_option(3, 1)
+    for la, lb in zip(outs[1], outs[0]):
+        for a, b in zip(la, lb):
+            assert torch.equal(a, b)
