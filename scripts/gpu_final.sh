@@ -17,6 +17,14 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof inference rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_$TAG -o bench -- python $ROOT/bench.py --mode train --steps 7 --warmup 2 > $OUT/rocprof_train_$TAG.log 2>&1; echo "rocprof train rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
+  # the headline kernel (fused-IPE k_mlp_bf16 launched by mipnerf_forward) as bench.py runs it
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcb_${TAG}_$c -o pmc -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmcb_${TAG}_$c.log 2>&1; echo "pmc bench $c rc=$?"
+  f=$(find $OUT/pmcb_${TAG}_$c -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python - "$f" <<'PY'
+import csv, sys
+v = [float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[1])) if "k_mlp_bf16" in r["Kernel_Name"]]
+print(f"  bench k_mlp_bf16 {sys.argv[1].split('_')[-3] if False else ''} mean per dispatch {sum(v)/max(1,len(v)):.6g} KB (n={len(v)})")
+PY
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_$c -o pmc -- python $ROOT/scripts/prof_train.py --iters 3 > $OUT/pmc_${TAG}_$c.log 2>&1; echo "pmc $c rc=$?"
   f=$(find $OUT/pmc_${TAG}_$c -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" <<'PY'
