@@ -222,7 +222,6 @@ def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_ra
     """Differentiable MipNerf.forward (mip_nerf.py:172-248): list of (comp_rgb, distance, acc, weights, t_samples)."""
     dev = rays.origins.device
     native = model.precision == L.PREC_BF16
-    dtype = torch.bfloat16 if native else torch.float32
     N = model.num_samples
     model.mlp.native(dev)      # raises NotImplementedError for an MLP shape the kernels were not generated for
     with torch.no_grad():

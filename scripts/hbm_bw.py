@@ -1,4 +1,4 @@
-import torch, time
+import torch
 dev='cuda'
 def t(fn, it=10):
     fn(); torch.cuda.synchronize()
