@@ -74,9 +74,14 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                     const float* wp = wstream + ((size_t)ly.chunk0 + (size_t)t * ly.kb) * 512 + lane * 8;
                     const float* x0 = X + n * ldx + ly.x_in + hi * 8;
                     const float* x1 = x0 + 32 * ldx;
+                    // software pipeline: the weight chunk of k-block kb+1 is in flight (L2 latency ~ 500 cycles) while the
+                    // 16 MFMAs of k-block kb (1024 cycles) run -- one wave per SIMD, nothing else hides that latency
+                    float4 a0 = *reinterpret_cast<const float4*>(wp);
+                    float4 a1 = *reinterpret_cast<const float4*>(wp + 4);
                     for (int kb = 0; kb < ly.kb; ++kb) {
-                        const float4 a0 = *reinterpret_cast<const float4*>(wp + (size_t)kb * 512);
-                        const float4 a1 = *reinterpret_cast<const float4*>(wp + (size_t)kb * 512 + 4);
+                        const int kn = kb + 1 < ly.kb ? kb + 1 : kb;
+                        const float4 n0 = *reinterpret_cast<const float4*>(wp + (size_t)kn * 512);
+                        const float4 n1 = *reinterpret_cast<const float4*>(wp + (size_t)kn * 512 + 4);
                         const float4 b00 = *reinterpret_cast<const float4*>(x0 + kb * 16);
                         const float4 b01 = *reinterpret_cast<const float4*>(x0 + kb * 16 + 4);
                         const float4 b10 = *reinterpret_cast<const float4*>(x1 + kb * 16);
@@ -89,6 +94,8 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                             acc[rd][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[j], acc[rd][0], 0, 0, 0);
                             acc[rd][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc[rd][1], 0, 0, 0);
                         }
+                        a0 = n0;
+                        a1 = n1;
                     }
                 }
             }
