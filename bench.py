@@ -137,6 +137,8 @@ def main():
     ctx = model.mlp.native(dev)
     if args.mode == "inference":
         ctx.set_option(2, 1)      # HIP events around every MLP launch of the timed region (launch stream)
+    elif args.mode == "train" and args.precision == "bf16":
+        ctx.set_option(2, 2)      # ... around every weight-gradient launch (the dominant, HBM-bound kernel of the step)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -160,7 +162,21 @@ def main():
     tot_ms, nl = C.c_double(), C.c_int64()
     L.check(L.lib().mipnerf_mlp_launch_stats(ctx.handle, C.byref(tot_ms), C.byref(nl)), "mlp_launch_stats")
     ctx.set_option(2, 0)
-    if rank == 0 and nl.value > 0:
+    if rank == 0 and nl.value > 0 and args.mode == "train":
+        # dominant kernel of the training step: k_mlp_wgrad, HBM-bound; algorithmic bytes = the T-blocks it reads
+        # (157 x 2 KiB per 32-sample wave tile, mlp_train_plan.py) + the fp32 partials it writes
+        from mipnerf_pl_amd.mlp_train_plan import JOB_FLOATS, TrainPlan
+        tp = TrainPlan.build()
+        M = B * N
+        blocks = sum(len(j.a_blocks) + len(j.b_blocks) for j in tp.jobs)
+        nbytes = ((M + 255) // 256) * 8 * blocks * 2048 + (256 // len(tp.jobs)) * len(tp.jobs) * JOB_FLOATS * 4
+        launch_ms = tot_ms.value / nl.value
+        gbs = nbytes / (launch_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_mlp_wgrad", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(gbs / 8000.0, 4), "traffic": 5321000000 if M == 524288 else None,
+                    "launch_ms": round(launch_ms, 4), "launches_timed": int(nl.value), "samples_per_launch": M,
+                    "bytes_per_sample": round(nbytes / M, 1)}
+    elif rank == 0 and nl.value > 0:
         prec = model.precision
         M = B * N
         launch_ms = tot_ms.value / max(1, nl.value)

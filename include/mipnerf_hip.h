@@ -285,7 +285,8 @@ int mipnerf_selftest(void* stream);
 /* Tuning / debug knobs.  option 0: bf16 MLP weight staging (1 = global_load_lds ring
  * [default], 0 = register-staged ring, same schedule); option 1: persistent grid size of the
  * bf16 MLP kernel (default = number of CUs); option 2: 1 = record a HIP event pair around
- * every MLP launch issued by mipnerf_forward (read with mipnerf_mlp_launch_stats); option 3: 1 [default] = the bf16
+ * every MLP launch issued by mipnerf_forward, 2 = around every weight-gradient launch (read with
+ * mipnerf_mlp_launch_stats); option 3: 1 [default] = the bf16
  * MLP kernel of mipnerf_forward computes the integrated positional encoding itself (no [M,96] buffer, no k_cast_ipe
  * launch), 0 = separate mipnerf_cast_ipe + encoding buffer (same bits). */
 int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);

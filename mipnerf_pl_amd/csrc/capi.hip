@@ -342,7 +342,7 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
     switch (option) {
         case 0: c->mlp_dma = value ? 1 : 0; return MIPNERF_OK;
         case 1: if (value < 1) return fail(MIPNERF_E_INVALID, "grid_limit < 1"); c->grid_limit = value; return MIPNERF_OK;
-        case 2: c->time_mlp = value ? 1 : 0; c->ev_used = 0; return MIPNERF_OK;
+        case 2: c->time_mlp = value < 0 ? 0 : (value > 2 ? 2 : value); c->ev_used = 0; return MIPNERF_OK;
         case 3: c->fused_ipe = value ? 1 : 0; return MIPNERF_OK;
         default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
     }
@@ -531,8 +531,16 @@ int mipnerf_mlp_wgrad(mipnerf_ctx* c, int64_t M, const void* act, const void* de
                       int32_t accumulate, void* stream) {
     if (!c || M < 1 || !act || !delta || !partials) return fail(MIPNERF_E_INVALID, "mlp_wgrad: bad argument");
     const int64_t n_wt = ((M + 255) / 256) * 8;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->time_mlp == 2) {          // option 2 = 2: time the weight-gradient launches (bench.py --mode train roofline)
+        if (c->ev_used + 2 > c->ev.size())
+            for (int i = 0; i < 64; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->ev.push_back(e); }
+        e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1]; c->ev_used += 2;
+        HIP_TRY(hipEventRecord(e0, S(stream)));
+    }
     HIP_TRY(mip::launch_mlp_wgrad(act, delta, c->d_jobs, c->d_wgtab, c->num_wgrad_wgs, n_wt, c->tt.NH, c->tt.NG, partials,
                                   S(stream)));
+    if (e1) HIP_TRY(hipEventRecord(e1, S(stream)));
     if (grad_flat) {
         if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_wgrad: mipnerf_set_params has not been called");
         using namespace mip::plan;
@@ -838,7 +846,7 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
             (rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, o.t_samples,
                                    rays->origins, rays->directions, rays->radii, enc, precision, stream))) return rc;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (c->time_mlp) {
+        if (c->time_mlp == 1) {
             if (c->ev_used + 2 > c->ev.size()) {
                 for (int i = 0; i < 64; ++i) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->ev.push_back(e); }
             }
@@ -855,7 +863,7 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
         } else if ((rc = mipnerf_mlp_forward(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream))) {
             return rc;
         }
-        if (c->time_mlp) HIP_TRY(hipEventRecord(e1, S(stream)));
+        if (c->time_mlp == 1) HIP_TRY(hipEventRecord(e1, S(stream)));
         if ((rc = mipnerf_volumetric_rendering(B, N, rgb_sigma, o.t_samples, rays->directions, white, o.comp_rgb,
                                                o.distance, o.acc, o.weights, stream))) return rc;
     }
