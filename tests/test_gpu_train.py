@@ -448,3 +448,34 @@ def test_fp32_native_mlp_backward_matches_reference_golden(G):
         worst = max(worst, rel_l2, es, et)
         assert rel_l2 <= 1e-4 and es <= 1e-4 and et <= 1e-4, (k, rel_l2, es, et)
     G.record("fp32_native_mlp_bwd_vs_reference_golden", worst=worst)
+
+
+@pytest.mark.parametrize("B,N,white", [(37, 100, False), (300, 32, True)])
+def test_native_train_step_ragged_shapes_randomized(G, B, N, white):
+    """mipnerf_train_step vs the autograd path on ragged sizes (rays not a multiple of the 256-sample tile, N not a
+    multiple of 32) with the SAME stratified / resampling draws injected into both."""
+    from mipnerf_pl_amd import MipNerf
+    from mipnerf_pl_amd.autograd import distloss
+    rays = G.to_dev(orc.synthetic_rays(B, seed=B, multiscale=True))
+    params = orc.make_params(seed=B, density_gain=40.0)
+    gt = torch.rand(B, 3, device=DEV)
+    t_rand, u_rand = torch.rand(B, N + 1, device=DEV), torch.rand(B, N + 1, device=DEV)
+    res = {}
+    for native in (False, True):
+        model = G.make_model(params, N, "bf16")
+        if native:
+            scal, _ = model.train_step_native(rays, gt, True, white, t_rand=t_rand, u_rand=u_rand)
+            loss = float(scal[0])
+        else:
+            ret = model(rays, True, white, t_rand=t_rand, u_rand=u_rand)
+            mask = rays.lossmult
+            mse = [(mask * (r[0] - gt) ** 2).sum() / mask.sum() for r in ret]
+            dl = [distloss(r[3], r[4]) for r in ret]
+            tot = 0.1 * (mse[0] + 0.01 * dl[0]) + mse[1] + 0.01 * dl[1]
+            tot.backward()
+            loss = float(tot)
+        res[native] = (loss, torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone())
+    (l0, g0), (l1, g1) = res[False], res[True]
+    eg = G.maxdiff(g0, g1) / float(g0.abs().max())
+    G.record(f"native_train_step_ragged B={B} N={N}", loss_autograd=l0, loss_native=l1, grad_rel=eg)
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)) and eg <= 2e-5
