@@ -358,9 +358,12 @@ class MipNerf(torch.nn.Module):
             raise NotImplementedError("density_noise > 0 is not implemented (reference default 0)")
         need = int(L.lib().mipnerf_train_workspace_bytes(ctx.handle, B))
         ws = ctx.scratch("train_step", need)
-        flat_mode = mlp.grads_are_flat() or (mlp.is_flat() and all(p.grad is None for p in mlp.ordered_params()))
+        dropped = all(p.grad is None for p in mlp.ordered_params())
+        flat_mode = mlp.grads_are_flat() or (mlp.is_flat() and dropped)
         if flat_mode:
-            mlp.gather_foreign_grads()          # re-attaches the .grad views if zero_grad(set_to_none=True) dropped them
+            if dropped:                         # zero_grad(set_to_none=True) of a foreign optimizer: start from zero
+                mlp._flat_grad_valid = False
+            mlp.gather_foreign_grads()          # re-attaches the .grad views
             grad, accumulate = mlp._flat_grad, 1 if mlp._flat_grad_valid else 0
         else:
             total = sum(p.numel() for p in mlp.ordered_params())
