@@ -190,6 +190,8 @@ class MLP(torch.nn.Module):
         g = getattr(self, "_flat_grad", None)
         if g is None:
             return
+        if all(p.grad is None for p in self.ordered_params()):
+            self._flat_grad_valid = False       # somebody reset the gradients (zero_grad(set_to_none=True)): nothing accumulated
         off, any_grad = 0, False
         for p in self.ordered_params():
             n = p.numel()

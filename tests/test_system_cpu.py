@@ -66,3 +66,26 @@ def test_checkpoint_roundtrip_in_lightning_format(tmp_path):
     assert again.hparams["nerf.num_samples"] == 64
     for (k1, v1), (k2, v2) in zip(system.state_dict().items(), again.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_flat_mode_bookkeeping_survives_foreign_zero_grad():
+    """MLP.flatten_parameters keeps names / shapes / leaf-ness; gradients reset by nn.Module.zero_grad() (set_to_none)
+    must not leave a stale 'accumulated' flag behind; foreign .grad tensors are folded back into the flat buffer."""
+    import torch
+    from mipnerf_pl_amd import MipNerf
+    m = MipNerf(num_samples=8)
+    keys = list(m.state_dict().keys())
+    mlp = m.mlp.flatten_parameters()
+    assert list(m.state_dict().keys()) == keys and all(p.is_leaf and p.requires_grad for p in m.parameters())
+    assert mlp.is_flat() and mlp.grads_are_flat()
+    mlp._flat_grad.fill_(1.0)
+    mlp._flat_grad_valid = True
+    m.zero_grad()                                   # torch default: set_to_none=True
+    assert not mlp.grads_are_flat()
+    mlp.gather_foreign_grads()
+    assert mlp.grads_are_flat() and mlp._flat_grad_valid is False
+    w = m.mlp.color_layer.weight
+    w.grad = torch.full_like(w, 3.0)                # a foreign gradient tensor (e.g. written by a generic autograd path)
+    mlp.gather_foreign_grads()
+    assert mlp.grads_are_flat() and mlp._flat_grad_valid is True and float(w.grad.mean()) == 3.0
+    assert w.grad.data_ptr() != 0 and w.grad.data_ptr() >= mlp._flat_grad.data_ptr()
