@@ -2,29 +2,41 @@
 """Benchmark of the Mip-NeRF hot path on MI355X (contract: see the task statement).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 8                       # re-executes itself under torch.distributed.run, one rank per GPU (RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one MipNerf.forward (coarse + fine level) over one batch of synthetic lego-like rays
-resident in HBM: BASELINE.json configs[1] = 4096 rays x (128 + 128) samples, bf16 MLP.
-metric = ray-samples/sec (whole job, all ranks), ray-samples per step = B x N x num_levels.
-Ranks shard rays (independent, no data-path collective): weak scaling.
-Also reported: the roofline of the dominant kernel (the bf16 MFMA MLP), timed live with HIP events
-through mipnerf_time_mlp, and the CPU baseline = the numpy oracle on a bounded sample (rank 0, N=1).
+Headline (top level of the JSON line): a "step" is one MipNerf.forward (coarse + fine level) over one batch of synthetic
+lego-like rays resident in HBM: BASELINE.json configs[1] = 4096 rays x (128 + 128) samples, bf16 MLP.
+metric = ray-samples/sec (whole job, all ranks), ray-samples per step = B x N x num_levels.  Ranks shard rays
+(independent, no data-path collective): weak scaling.  The default run (`--mode all`) also carries two sub-records,
+each with its own timed region (same barrier + synchronize bracketing, max over ranks) and its own roofline:
+
+  "train":  one training step = randomized forward + loss (incl. distloss) + backward + gradient all-reduce (RCCL, one
+            flat 2.45 MB buffer) + Adam + LR schedule, 4096 rays x (128+128) per GPU (weak scaling);
+  "render": BASELINE.json configs[4], one 800x800 frame (640k rays) in 8192-ray chunks, rays split over the ranks
+            (strong scaling), rgb all-gathered.
+
+Also reported: the roofline of the dominant kernel (bf16 MFMA MLP), timed live with HIP events on the launch stream,
+a sustained figure (>= 2 s of steps after the timed region: the chip's clock settles on its power budget), and the CPU
+baseline = the reference's own MipNerf.forward (staged under oracle/_ref by oracle/build_ref.py) on the host cores,
+rank 0, N=1 only (the numpy port when nothing is staged).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-FLOP_PER_SAMPLE = 1_220_608          # SURVEY.md 8(d): 2 x 610,304 MAC of the MLP per ray-sample
+FLOP_PER_SAMPLE = 1_220_608          # SURVEY.md 8(d): 2 x 610,304 MAC of the MLP per ray-sample (forward)
+FLOP_PER_SAMPLE_TRAIN = 3_556_608    # SURVEY.md 8(d): forward + dgrad + wgrad
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -33,203 +45,355 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="inference", choices=["inference", "train", "render"],
-                    help="inference (headline): MipNerf.forward; train: forward + loss + backward + grad all-reduce + Adam; "
-                         "render: BASELINE configs[4], one 800x800 frame (640k rays) in 8192-ray chunks replayed from a "
-                         "captured hipGraph, rays split over the ranks, rgb gathered")
-    ap.add_argument("--autograd", action="store_true", help="train mode: training_step + loss.backward() through the custom "
+    ap.add_argument("--mode", default="all", choices=["all", "inference", "train", "render"],
+                    help="all (default): headline inference + train and render sub-records; inference / train / render: "
+                         "only that workload, reported at the top level")
+    ap.add_argument("--autograd", action="store_true", help="train: training_step + loss.backward() through the custom "
                     "autograd Functions (what a Lightning loop does) instead of the single native mipnerf_train_step call")
-    ap.add_argument("--torch-adam", action="store_true", help="train mode: torch.optim.Adam on per-tensor gradients "
+    ap.add_argument("--torch-adam", action="store_true", help="train: torch.optim.Adam on per-tensor gradients "
                     "(what the reference configures) instead of the fused flat Adam kernel")
-    ap.add_argument("--no-graph", action="store_true", help="render mode: eager chunk loop instead of the hipGraph")
-    args = ap.parse_args()
+    ap.add_argument("--no-graph", action="store_true", help="render / train: eager launches instead of the captured hipGraph")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="inference: extra steps after the timed region")
+    return ap.parse_args()
 
-    import numpy as np
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: become N ranks, one per GPU, under
+    torch.distributed.run on this node (what the reference's train.py does with devices=num_gpus + DDPPlugin,
+    train.py:56-60)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+class Env:
+    pass
+
+
+def setup(args):
     import torch
     import torch.distributed as dist
-    from mipnerf_pl_amd import MipNerf, Rays, _lib as L
-    from oracle import mipnerf_oracle as orc       # cpu_baseline leg + synthetic inputs only
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    if os.environ.get("MIPNERF_BENCH_SHARE_GPU") == "1":     # plumbing test on a 1-GPU box: every rank on cuda:0
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
+    e = Env()
+    e.rank = int(os.environ.get("RANK", "0"))
+    e.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    e.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if e.world != args.gpus:
+        raise SystemExit(f"[bench] WORLD_SIZE={e.world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` without a launcher: it starts the ranks itself)")
+    e.share = os.environ.get("MIPNERF_BENCH_SHARE_GPU") == "1"     # plumbing test on a 1-GPU box: every rank on cuda:0
+    if not e.share and torch.cuda.device_count() < e.world:
+        raise SystemExit(f"[bench] --gpus {args.gpus} needs {e.world} visible GPUs, found {torch.cuda.device_count()}")
+    if e.share:
+        e.local_rank = 0
+    torch.cuda.set_device(e.local_rank)
+    e.dev = torch.device("cuda", e.local_rank)
+    if e.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm; the override exists only for the shared-GPU plumbing test (RCCL refuses two ranks per GPU)
-        dist.init_process_group(os.environ.get("MIPNERF_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("MIPNERF_BENCH_BACKEND", "nccl"), rank=e.rank, world_size=e.world)
+        assert dist.get_world_size() == args.gpus
+    return e
 
-    B, N = args.rays, args.samples
-    rays_np = orc.synthetic_rays(B, seed=100 + rank)
-    params = orc.make_params(seed=0, density_gain=40.0)
-    model = MipNerf(num_samples=N, precision=args.precision)
-    model.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
-    model = model.to(dev)
-    R = Rays(*[torch.from_numpy(a).to(dev) for a in rays_np])
 
-    if args.mode == "train":
-        from mipnerf_pl_amd.parallel import FlatGradAllReduce
-        from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
-        hp = dict(DEFAULT_HPARAMS)
-        hp.update({"nerf.num_samples": N})
-        system = MipNeRFSystem(hp, precision=args.precision)
-        system.mip_nerf.load_state_dict(model.state_dict())
-        system = system.to(dev)
-        model = system.mip_nerf
-        system.fused_adam = not args.torch_adam         # FlatAdam: flat parameter / gradient buffers, one Adam kernel
-        (opt,), (sch,) = system.configure_optimizers()
-        reduce_grads = FlatGradAllReduce(list(model.parameters()), mlp=model.mlp)
-        gt = torch.rand(B, 3, device=dev)
-
-        def step():
-            opt.zero_grad(set_to_none=False)              # FlatAdam: no kernel, the next backward overwrites
-            if args.autograd:
-                loss = system.training_step((R, gt), 0)      # randomized=True, nerf_system.py:95-121
-                loss.backward()
-            else:
-                loss = system.training_step_native((R, gt), 0)     # the same, one native call (mipnerf_train_step)
-            reduce_grads()                                # one flat all-reduce over RCCL (no-op at world 1)
-            opt.step()
-            sch["scheduler"].step()
-            return [(loss.detach().reshape(1),)]
-    elif args.mode == "render":
-        from mipnerf_pl_amd.parallel import gather_rendered, shard_bounds
-        from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
-        Himg = Wimg = 800
-        lo, hi = shard_bounds(Himg * Wimg, rank, world)          # contiguous ray shard of this rank (strong scaling)
-        nloc = hi - lo
-        frame_np = orc.synthetic_rays(8192, seed=7)               # tiled: 640k distinct draws would dominate start-up
-        reps = (nloc + 8191) // 8192
-        FR = Rays(*[torch.from_numpy(np.tile(a, (reps, 1))[:nloc]).to(dev) for a in frame_np])
-        hp = dict(DEFAULT_HPARAMS)
-        hp.update({"nerf.num_samples": N, "val.chunk_size": 8192})
-        system = MipNeRFSystem(hp, precision=args.precision)
-        system.mip_nerf.load_state_dict(model.state_dict())
-        system = system.to(dev)
-        system.enable_hip_graph(not args.no_graph)
-        model = system.mip_nerf
-        img_rays = Rays(*[x.reshape(1, 1, nloc, -1) for x in FR])
-        dummy = torch.zeros(1, 1, nloc, 3, device=dev)
-
-        def step():
-            _, fine, _ = system.render_image((img_rays, dummy))
-            full = gather_rendered(fine.reshape(nloc, 3), Himg * Wimg)
-            return [(full,)]
-        B = Himg * Wimg // world      # for the samples-per-step accounting below (whole frame / world per rank)
-    else:
-        def step():
-            with torch.no_grad():
-                return model(R, False, True)
+def timed(e, step, warmup, steps):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks (seconds)."""
+    import torch
+    import torch.distributed as dist
 
     def barrier():
-        if world > 1:
+        if e.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ctx = model.mlp.native(dev)
-    if args.mode == "inference":
-        ctx.set_option(2, 1)      # HIP events around every MLP launch of the timed region (launch stream)
-    elif args.mode == "train" and args.precision == "bf16":
-        ctx.set_option(2, 2)      # ... around every weight-gradient launch (the dominant, HBM-bound kernel of the step)
+    out = None
+    for _ in range(warmup):
+        out = step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if e.world > 1:
+        tt = torch.tensor([dt], device=e.dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert bool(torch.isfinite(out[-1][0]).all())
+    return dt, out
 
-    samples_per_step = B * N * model.num_levels
-    value = samples_per_step * world * args.steps / dt
 
-    # ---- roofline of the dominant kernel (bf16 / fp32 MFMA MLP): average duration of the MLP launches made
-    # INSIDE the timed region, from HIP events recorded on the launch stream by the library ----
-    roofline = None
-    cpu_baseline = None
+def launch_stats(ctx):
     import ctypes as C
+    from mipnerf_pl_amd import _lib as L
     tot_ms, nl = C.c_double(), C.c_int64()
     L.check(L.lib().mipnerf_mlp_launch_stats(ctx.handle, C.byref(tot_ms), C.byref(nl)), "mlp_launch_stats")
+    return tot_ms.value, int(nl.value)
+
+
+def make_model(args, e, N):
+    import torch
+    import synthetic_inputs as syn
+    from mipnerf_pl_amd import MipNerf
+    params = syn.make_params(seed=0, density_gain=40.0)
+    model = MipNerf(num_samples=N, precision=args.precision)
+    model.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    return model.to(e.dev), params
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_inference(args, e):
+    import torch
+    import synthetic_inputs as syn
+    from mipnerf_pl_amd import Rays, _lib as L
+    B, N = args.rays, args.samples
+    rays_np = syn.synthetic_rays(B, seed=100 + e.rank)
+    model, params = make_model(args, e, N)
+    R = Rays(*[torch.from_numpy(a).to(e.dev) for a in rays_np])
+
+    def step():
+        with torch.no_grad():
+            return model(R, False, True)
+    step()
+    ctx = model.mlp.native(e.dev)
+    for _ in range(args.warmup):
+        step()
+    ctx.set_option(2, 1)      # HIP events around every MLP launch of the timed region (on the launch stream)
+    dt, out = timed(e, step, 0, args.steps)
+    tot_ms, nl = launch_stats(ctx)
     ctx.set_option(2, 0)
-    if rank == 0 and nl.value > 0 and args.mode == "train":
-        # dominant kernel of the training step: k_mlp_wgrad, HBM-bound; algorithmic bytes = the T-blocks it reads
-        # (157 x 2 KiB per 32-sample wave tile, mlp_train_plan.py) + the fp32 partials it writes
-        from mipnerf_pl_amd.mlp_train_plan import JOB_FLOATS, TrainPlan
-        tp = TrainPlan.build()
-        M = B * N
-        blocks = sum(len(j.a_blocks) + len(j.b_blocks) for j in tp.jobs)
-        nbytes = ((M + 255) // 256) * 8 * blocks * 2048 + (256 // len(tp.jobs)) * len(tp.jobs) * JOB_FLOATS * 4
-        launch_ms = tot_ms.value / nl.value
-        gbs = nbytes / (launch_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_mlp_wgrad", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(gbs / 8000.0, 4), "traffic": 5321000000 if M == 524288 else None,
-                    "launch_ms": round(launch_ms, 4), "launches_timed": int(nl.value), "samples_per_launch": M,
-                    "bytes_per_sample": round(nbytes / M, 1)}
-    elif rank == 0 and nl.value > 0:
-        prec = model.precision
-        M = B * N
-        launch_ms = tot_ms.value / max(1, nl.value)
+    assert bool(torch.isfinite(out[-1][0]).all())
+    M = B * N
+    samples_per_step = B * N * model.num_levels
+    value = samples_per_step * e.world * args.steps / dt
+    peak = PEAK_TFLOPS[args.precision]
+    kname = "k_mlp_bf16" if model.precision == L.PREC_BF16 else "k_mlp_f32"
+    roofline = None
+    if nl > 0:
+        launch_ms = tot_ms / nl
         tflops = FLOP_PER_SAMPLE * M / (launch_ms * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[args.precision]
-        traffic = None
-        pmc = os.path.join(REPO, "profiles", "mlp_pmc.json")     # HBM bytes/launch from rocprofv3 --pmc passes
+        traffic, tsrc = None, None
+        pmc = os.path.join(REPO, "profiles", "mlp_pmc.json")     # HBM bytes/launch from separate rocprofv3 --pmc passes
         if os.path.exists(pmc):
             pj = json.load(open(pmc))
             if pj.get("precision") == args.precision and pj.get("samples_per_launch") == M:
-                traffic = pj.get("hbm_bytes_per_launch")
-        roofline = {"bound": "mfma", "kernel": "k_mlp_bf16" if prec == L.PREC_BF16 else "k_mlp_f32",
-                    "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
-                    "traffic": traffic, "launch_ms": round(launch_ms, 4), "launches_timed": int(nl.value),
-                    "samples_per_launch": M, "flop_per_sample": FLOP_PER_SAMPLE}
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and args.mode == "inference":
-            # bounded sample of the same workload: 256 rays x N x 2 levels through the numpy oracle
-            nb = 256
-            sub = orc.Rays(*[a[:nb] for a in rays_np])
-            orc.mipnerf_forward(params, orc.Rays(*[a[:32] for a in rays_np]), False, True, num_samples=N)  # warm BLAS
-            reps, tcpu = 0, 0.0
-            while tcpu < 10.0 and reps < 20:
-                c0 = time.perf_counter()
-                orc.mipnerf_forward(params, sub, False, True, num_samples=N)
-                tcpu += time.perf_counter() - c0
-                reps += 1
-            cpu_baseline = {"value": round(nb * N * 2 * reps / tcpu, 1), "unit": "ray-samples/s",
-                            "cores": os.cpu_count(), "kind": "port",
-                            "sample": f"{reps} x oracle.mipnerf_forward on {nb} rays x {N} samples x 2 levels (numpy fp32, "
-                                      f"BLAS threads = all cores)"}
+                traffic, tsrc = pj.get("hbm_bytes_per_launch"), "profiles/mlp_pmc.json (rocprofv3 --pmc passes, not this run)"
+        roofline = {"bound": "mfma", "kernel": kname, "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(tflops / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                    "launch_ms": round(launch_ms, 4), "launches_timed": nl, "samples_per_launch": M,
+                    "flop_per_sample": FLOP_PER_SAMPLE}
+    # sustained: keep stepping for >= sustain-seconds; the package settles on its power budget (DVFS)
+    sustained = None
+    if args.sustain_seconds > 0:
+        per = max(1, int(0.25 / max(dt / args.steps, 1e-5)))
+        t_end = time.perf_counter() + args.sustain_seconds
+        while time.perf_counter() < t_end:          # un-instrumented heat-up
+            for _ in range(per):
+                step()
+            torch.cuda.synchronize()
+        ctx.set_option(2, 1)
+        ks = max(args.steps, 20)
+        dts, _ = timed(e, step, 0, ks)
+        tot2, nl2 = launch_stats(ctx)
+        sustained = {"after_seconds": args.sustain_seconds, "steps": ks, "ms_per_step": round(dts / ks * 1e3, 4),
+                     "value": round(samples_per_step * e.world * ks / dts, 1)}
+        if nl2 > 0:
+            tf2 = FLOP_PER_SAMPLE * M / (tot2 / nl2 * 1e-3) / 1e12
+            sustained.update({"launch_ms": round(tot2 / nl2, 4), "achieved": round(tf2, 2), "frac": round(tf2 / peak, 4)})
+    ctx.set_option(2, 0)
+    rec = {"value": round(value, 1), "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps, "warmup": args.warmup,
+           "scaling": "weak", "roofline": roofline, "sustained": sustained,
+           "config": {"workload": (f"BASELINE.json configs[1]: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) "
+                                   f"samples per GPU, 8x256 MLP, random-init trained-like weights"),
+                      "mode": "inference", "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
+                      "parallelism": f"ray-split x{e.world} (no data-path collective)"}}
+    return rec, (rays_np, params)
 
-    if rank == 0:
-        line = {
-            "metric": "ray-samples/sec", "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong" if args.mode == "render" else "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": (f"BASELINE.json configs[1]: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) "
-                                    f"samples per GPU, 8x256 MLP, random-init trained-like weights") if args.mode == "inference"
-                       else (f"BASELINE.json configs[4]: one 800x800 frame = 640,000 rays x ({N}+{N}) samples in 8192-ray chunks, "
-                             f"{'eager chunk loop' if args.no_graph else 'chunk forward replayed from a captured hipGraph'}, rays split over "
-                             f"{world} rank(s), rgb all-gathered") if args.mode == "render"
-                       else (f"training step (forward randomized + loss incl. distloss + backward + grad all-reduce + Adam), "
-                             f"{B} rays x ({N}+{N}) samples per GPU; MLP forward-with-save / dgrad / wgrad = native bf16 MFMA kernels"),
-                       "mode": args.mode,
-                       "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
-                       "parallelism": f"ray-split x{world} (no data-path collective)"},
-            "per_gpu": round(value / world, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
-        }
+
+def run_train(args, e):
+    import torch
+    import synthetic_inputs as syn
+    from mipnerf_pl_amd import Rays
+    from mipnerf_pl_amd.parallel import FlatGradAllReduce
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    B, N = args.rays, args.samples
+    rays_np = syn.synthetic_rays(B, seed=100 + e.rank)
+    R = Rays(*[torch.from_numpy(a).to(e.dev) for a in rays_np])
+    model0, _ = make_model(args, e, N)
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({"nerf.num_samples": N})
+    system = MipNeRFSystem(hp, precision=args.precision)
+    system.mip_nerf.load_state_dict(model0.state_dict())
+    system = system.to(e.dev)
+    model = system.mip_nerf
+    system.fused_adam = not args.torch_adam         # FlatAdam: flat parameter / gradient buffers, one Adam kernel
+    (opt,), (sch,) = system.configure_optimizers()
+    reduce_grads = FlatGradAllReduce(list(model.parameters()), mlp=model.mlp)
+    gt = torch.rand(B, 3, device=e.dev)
+    native = not args.autograd and args.precision == "bf16"
+
+    def step():
+        opt.zero_grad(set_to_none=False)              # FlatAdam: no kernel, the next backward overwrites
+        if native:
+            loss = system.training_step_native((R, gt), 0)     # forward + loss + backward, one native call
+        else:
+            loss = system.training_step((R, gt), 0)            # randomized=True, nerf_system.py:95-121
+            loss.backward()
+        reduce_grads()                                # one flat all-reduce over RCCL (no-op at world 1)
+        opt.step()
+        sch["scheduler"].step()
+        return [(loss.detach().reshape(1),)]
+    step()
+    dt, out = timed(e, step, args.warmup, args.steps)
+    assert bool(torch.isfinite(out[-1][0]).all())
+    samples_per_step = B * N * model.num_levels
+    value = samples_per_step * e.world * args.steps / dt
+    ms = dt / args.steps * 1e3
+    peak = PEAK_TFLOPS[args.precision]
+    tflops = FLOP_PER_SAMPLE_TRAIN * samples_per_step / (ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "whole step (forward-with-save + dgrad + wgrad MFMA kernels and everything around them)",
+                "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": None,
+                "flop_per_sample": FLOP_PER_SAMPLE_TRAIN, "samples_per_step": samples_per_step}
+    rec = {"value": round(value, 1), "ms_per_step": round(ms, 4), "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+           "roofline": roofline,
+           "config": {"workload": (f"training step (randomized forward + loss incl. distloss + backward + one flat gradient all-reduce + "
+                                   f"Adam + MipLRDecay), {B} rays x ({N}+{N}) samples per GPU"),
+                      "mode": "train", "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
+                      "native_step": native, "fused_adam": not args.torch_adam,
+                      "parallelism": f"data-parallel x{e.world}, one {4 * sum(p.numel() for p in model.parameters())} B all-reduce per step"}}
+    return rec
+
+
+def run_render(args, e):
+    import numpy as np
+    import torch
+    import synthetic_inputs as syn
+    from mipnerf_pl_amd import Rays
+    from mipnerf_pl_amd.parallel import gather_rendered, shard_bounds
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    N = args.samples
+    Himg = Wimg = 800
+    lo, hi = shard_bounds(Himg * Wimg, e.rank, e.world)          # contiguous ray shard of this rank (strong scaling)
+    nloc = hi - lo
+    frame_np = syn.synthetic_rays(8192, seed=7)               # tiled: 640k distinct draws would dominate start-up
+    reps = (nloc + 8191) // 8192
+    FR = Rays(*[torch.from_numpy(np.tile(a, (reps, 1))[:nloc]).to(e.dev) for a in frame_np])
+    model0, _ = make_model(args, e, N)
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({"nerf.num_samples": N, "val.chunk_size": 8192})
+    system = MipNeRFSystem(hp, precision=args.precision)
+    system.mip_nerf.load_state_dict(model0.state_dict())
+    system = system.to(e.dev)
+    system.enable_hip_graph(not args.no_graph)
+    img_rays = Rays(*[x.reshape(1, 1, nloc, -1) for x in FR])
+    dummy = torch.zeros(1, 1, nloc, 3, device=e.dev)
+
+    def step():
+        _, fine, _ = system.render_image((img_rays, dummy))
+        full = gather_rendered(fine.reshape(nloc, 3), Himg * Wimg)
+        return [(full,)]
+    frames = args.steps if args.mode == "render" else max(2, args.steps // 10)
+    warm = args.warmup if args.mode == "render" else 1
+    step()
+    dt, out = timed(e, step, warm, frames)
+    assert bool(torch.isfinite(out[-1][0]).all())
+    samples_per_frame = Himg * Wimg * N * system.mip_nerf.num_levels
+    ms = dt / frames * 1e3
+    peak = PEAK_TFLOPS[args.precision]
+    tflops = FLOP_PER_SAMPLE * samples_per_frame / (ms * 1e-3) / 1e12 / e.world
+    rec = {"value": round(samples_per_frame * frames / dt, 1), "ms_per_step": round(ms, 4), "steps": frames, "warmup": warm,
+           "scaling": "strong",
+           "roofline": {"bound": "mfma", "kernel": "whole frame (k_mlp_bf16 >= 95 % of it)", "achieved": round(tflops, 2), "peak": peak,
+                        "unit": "TFLOP/s per GPU", "frac": round(tflops / peak, 4), "traffic": None},
+           "config": {"workload": (f"BASELINE.json configs[4]: one 800x800 frame = 640,000 rays x ({N}+{N}) samples in 8192-ray chunks, "
+                                   f"{'eager chunk loop' if args.no_graph else 'chunk forward replayed from a captured hipGraph'}, rays split "
+                                   f"over {e.world} rank(s), rgb all-gathered"),
+                      "mode": "render", "samples_per_level": N, "parallelism": f"ray-split x{e.world}, all_gather of 12 B/ray"}}
+    return rec
+
+
+def cpu_baseline(args, rays_np, params):
+    """The reference's own CPU path on this host (rank 0, N=1): MipNerf.forward of the staged reference (oracle/_ref) under
+    no_grad, fp32, all host cores, on the FULL headline batch; falls back to the numpy port on a 256-ray sample."""
+    import numpy as np
+    import torch
+    B, N = args.rays, args.samples
+    cpu = "?"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    from oracle import ref as oref
+    r = oref.load()
+    if r is not None:
+        torch.set_num_threads(os.cpu_count())
+        model = r.MipNerf(num_samples=N)
+        model.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+        model.eval()
+        RR = r.Rays(*[torch.from_numpy(np.asarray(a)) for a in rays_np])
+        ts = []
+        with torch.no_grad():
+            model(r.Rays(*[x[:256] for x in RR]), False, True)      # warm-up (thread pool, allocator)
+            model(RR, False, True)
+            for _ in range(3):
+                c0 = time.perf_counter()
+                model(RR, False, True)
+                ts.append(time.perf_counter() - c0)
+        med = sorted(ts)[1]
+        return {"value": round(B * N * 2 / med, 1), "unit": "ray-samples/s", "cores": os.cpu_count(), "kind": "reference",
+                "cpu": cpu, "seconds_per_forward": round(med, 3),
+                "sample": f"median of 3 x the reference's MipNerf.forward (oracle/_ref, torch {torch.__version__} CPU, fp32, no_grad, "
+                          f"{torch.get_num_threads()} threads) on the full {B} rays x {N} samples x 2 levels batch"}
+    from oracle import mipnerf_oracle as orc
+    nb = 256
+    sub = orc.Rays(*[a[:nb] for a in rays_np])
+    orc.mipnerf_forward(params, orc.Rays(*[a[:32] for a in rays_np]), False, True, num_samples=N)  # warm BLAS
+    reps, tcpu = 0, 0.0
+    while tcpu < 10.0 and reps < 20:
+        c0 = time.perf_counter()
+        orc.mipnerf_forward(params, sub, False, True, num_samples=N)
+        tcpu += time.perf_counter() - c0
+        reps += 1
+    return {"value": round(nb * N * 2 * reps / tcpu, 1), "unit": "ray-samples/s", "cores": os.cpu_count(), "kind": "port", "cpu": cpu,
+            "sample": f"oracle/_ref not staged: {reps} x oracle.mipnerf_forward on {nb} rays x {N} samples x 2 levels (numpy fp32, "
+                      f"BLAS threads = all cores)"}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    e = setup(args)
+    import torch.distributed as dist
+    recs, inputs = {}, None
+    if args.mode in ("all", "inference"):
+        recs["inference"], inputs = run_inference(args, e)
+    if args.mode in ("all", "train"):
+        recs["train"] = run_train(args, e)
+    if args.mode in ("all", "render"):
+        recs["render"] = run_render(args, e)
+    head_mode = "inference" if "inference" in recs else args.mode
+    head = recs.pop(head_mode)
+    cpu = None
+    if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline and inputs is not None:
+        cpu = cpu_baseline(args, *inputs)
+    if e.rank == 0:
+        line = {"metric": "ray-samples/sec", "value": head["value"], "unit": "ray-samples/s", "n_gpus": e.world,
+                "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+                "scaling": head["scaling"], "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+                "config": head["config"], "per_gpu": round(head["value"] / e.world, 1), "roofline": head["roofline"],
+                "cpu_baseline": cpu}
+        if head.get("sustained") is not None:
+            line["sustained"] = head["sustained"]
+        for k, r in recs.items():
+            r.update({"metric": "ray-samples/sec", "unit": "ray-samples/s", "n_gpus": e.world, "per_gpu": round(r["value"] / e.world, 1)})
+            line[k] = r
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if e.world > 1:
         dist.destroy_process_group()
 
 

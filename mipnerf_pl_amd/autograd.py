@@ -6,12 +6,10 @@ its backward (fused with the activation derivatives), resampling, distloss.  tor
 native pieces (custom Functions) and owns the buffers.
 fp32 ("parity") mode: fused exact-fp32 MFMA forward that saves the layer outputs + GEMM-based dgrad / wgrad on the
 fp32 matrix instruction (kernels_gemm_f32.hip) -- the instrument of the gradient-parity tests against the reference.
-`mlp_torch` below is a plain-PyTorch restatement of the same op, kept as a test reference only.
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib as L
 from . import ops
@@ -195,27 +193,6 @@ def distloss(weight, samples):
 
 def render_from_raw(raw, t_samples, dirs, white_bkgd, rgb_padding=0.001, density_bias=-1.0):
     return _RenderFromRaw.apply(raw, t_samples, dirs, white_bkgd, rgb_padding, density_bias)
-
-
-def mlp_torch(mlp, samples_enc, viewdirs_enc, dtype):
-    """models/mip_nerf.py:75-111 through torch ops (library GEMMs) -- interim differentiable path."""
-    def lin(layer, x):
-        return F.linear(x, layer.weight.to(dtype), layer.bias.to(dtype))
-    num_samples = samples_enc.shape[1]
-    inputs = samples_enc.to(dtype)
-    x = inputs
-    for i, layer in enumerate(mlp.layers):
-        x = torch.relu(lin(layer[0], x))
-        if i % mlp.skip_index == 0 and i > 0:
-            x = torch.cat([x, inputs], dim=-1)
-    raw_density = lin(mlp.density_layer, x)
-    bottleneck = lin(mlp.extra_layer, x)
-    vd = viewdirs_enc.to(dtype)[:, None, :].expand(-1, num_samples, -1)
-    x = torch.cat([bottleneck, vd], dim=-1)
-    for layer in mlp.view_layers:
-        x = torch.relu(lin(layer[0], x))
-    raw_rgb = lin(mlp.color_layer, x)
-    return torch.cat([raw_rgb, raw_density], dim=-1).float()
 
 
 def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_rand=None):

@@ -67,10 +67,14 @@ class NativeContext:
             d = p.detach()
             if d.dtype != torch.float32:
                 raise TypeError("master parameters must be float32")
-            d = d.contiguous()
+            if not d.is_contiguous():
+                # the library keeps these pointers as the fp32 master weights of the backward kernels
+                raise RuntimeError(f"parameter {i} is not contiguous; the native path needs contiguous master parameters")
             keep.append(d)
             arr[i] = d.data_ptr()
-        L.check(L.lib().mipnerf_set_params(self._h, arr, ops._stream()), "mipnerf_set_params")
+        with torch.cuda.device(self.device):
+            L.check(L.lib().mipnerf_set_params(self._h, arr, ops._stream()), "mipnerf_set_params")
+        self._keep = keep
         self._packed_key = key
 
     def workspace(self, num_rays: int) -> torch.Tensor:
@@ -330,10 +334,11 @@ class MipNerf(torch.nn.Module):
         if not o.is_cuda:
             raise RuntimeError("MipNerf.forward needs rays on a HIP device; there is no CPU fallback "
                                "(the CPU restatement lives in oracle/ and is test-only)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            from .autograd import mipnerf_forward_train
-            return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand)
-        return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand)
+        with torch.cuda.device(o.device):      # native launches go to the CURRENT device's stream
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                from .autograd import mipnerf_forward_train
+                return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand)
+            return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand)
 
     def train_step_native(self, rays: Rays, gt_rgb, randomized: bool, white_bkgd: bool, coarse_loss_mult: float = 0.1,
                           distloss_mult: float = 0.01, disable_multiscale_loss: bool = False, t_rand=None, u_rand=None,

@@ -44,9 +44,11 @@ def cast_rays(t_samples, origins, directions, radii, ray_shape="cone", diagonal=
     N = N1 - 1
     means = torch.empty(B, N, 3, device=t_samples.device, dtype=torch.float32)
     covs = torch.empty_like(means)
-    L.check(L.lib().mipnerf_cast_rays(B, N, _ptr(t_samples), _ptr(_f32c(origins, "origins")),
-                                      _ptr(_f32c(directions, "directions")), _ptr(_f32c(radii, "radii")),
-                                      _ptr(means), _ptr(covs), _stream()), "cast_rays")
+    # contiguous copies (if any) are bound to locals: a temporary would be freed, and its block re-used by the next
+    # temporary, before the launch
+    o, d, r = _f32c(origins, "origins"), _f32c(directions, "directions"), _f32c(radii, "radii")
+    L.check(L.lib().mipnerf_cast_rays(B, N, _ptr(t_samples), _ptr(o), _ptr(d), _ptr(r), _ptr(means), _ptr(covs), _stream()),
+            "cast_rays")
     return means, covs
 
 
@@ -58,8 +60,8 @@ def sample_t(num_samples, near, far, randomized, disparity, t_rand=None):
     if randomized and t_rand is None:
         t_rand = torch.rand(B, num_samples + 1, device=near.device)   # mip.py:159
     t = torch.empty(B, num_samples + 1, device=near.device, dtype=torch.float32)
-    L.check(L.lib().mipnerf_sample_along_rays(B, num_samples, _ptr(near), _ptr(far),
-                                              _ptr(_f32c(t_rand, "t_rand")) if randomized else None,
+    tr = _f32c(t_rand, "t_rand") if randomized else None
+    L.check(L.lib().mipnerf_sample_along_rays(B, num_samples, _ptr(near), _ptr(far), _ptr(tr),
                                               int(bool(disparity)), _ptr(t), _stream()), "sample_along_rays")
     return t
 
@@ -79,9 +81,9 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u_rand
     if randomized and u_rand is None:
         u_rand = torch.rand(B, num_samples, device=bins.device)       # stands in for uniform_(mip.py:201)
     out = torch.empty(B, num_samples, device=bins.device, dtype=torch.float32)
+    ur = _f32c(u_rand, "u_rand") if randomized else None
     L.check(L.lib().mipnerf_sorted_piecewise_constant_pdf(
-        B, nb, _ptr(bins), _ptr(weights), num_samples,
-        _ptr(_f32c(u_rand, "u_rand")) if randomized else None, _ptr(out), _stream()),
+        B, nb, _ptr(bins), _ptr(weights), num_samples, _ptr(ur), _ptr(out), _stream()),
         "sorted_piecewise_constant_pdf")
     return out
 
@@ -94,9 +96,9 @@ def resample_t(t_samples, weights, randomized, resample_padding, u_rand=None):
     if randomized and u_rand is None:
         u_rand = torch.rand(B, N + 1, device=weights.device)
     out = torch.empty(B, N + 1, device=weights.device, dtype=torch.float32)
+    ur = _f32c(u_rand, "u_rand") if randomized else None
     L.check(L.lib().mipnerf_resample_along_rays(
-        B, N, _ptr(t_samples), _ptr(weights), _ptr(_f32c(u_rand, "u_rand")) if randomized else None,
-        float(resample_padding), _ptr(out), _stream()), "resample_along_rays")
+        B, N, _ptr(t_samples), _ptr(weights), _ptr(ur), float(resample_padding), _ptr(out), _stream()), "resample_along_rays")
     return out
 
 
@@ -130,9 +132,9 @@ def cast_ipe(t_samples, origins, directions, radii, min_deg, max_deg, disable_in
     t_samples = _f32c(t_samples, "t_samples")
     B, N1 = t_samples.shape
     enc = torch.empty(B, N1 - 1, 6 * (max_deg - min_deg), device=t_samples.device, dtype=_torch_dtype(precision))
+    o, d, r = _f32c(origins, "origins"), _f32c(directions, "directions"), _f32c(radii, "radii")   # kept alive until after the launch
     L.check(L.lib().mipnerf_cast_ipe(B, N1 - 1, min_deg, max_deg, int(bool(disable_integration)), _ptr(t_samples),
-                                     _ptr(_f32c(origins, "origins")), _ptr(_f32c(directions, "directions")),
-                                     _ptr(_f32c(radii, "radii")), _ptr(enc), precision, _stream()), "cast_ipe")
+                                     _ptr(o), _ptr(d), _ptr(r), _ptr(enc), precision, _stream()), "cast_ipe")
     return enc
 
 
@@ -167,7 +169,8 @@ def volumetric_rendering_packed(rgb_sigma, t_samples, dirs, white_bkgd):
     distance = torch.empty(B, device=dev)
     acc = torch.empty(B, device=dev)
     weights = torch.empty(B, N, device=dev)
-    L.check(L.lib().mipnerf_volumetric_rendering(B, N, _ptr(rgb_sigma), _ptr(t_samples), _ptr(_f32c(dirs, "dirs")),
+    dirs = _f32c(dirs, "dirs")
+    L.check(L.lib().mipnerf_volumetric_rendering(B, N, _ptr(rgb_sigma), _ptr(t_samples), _ptr(dirs),
                                                  int(bool(white_bkgd)), _ptr(comp_rgb), _ptr(distance), _ptr(acc),
                                                  _ptr(weights), _stream()), "volumetric_rendering")
     return comp_rgb, distance, acc, weights
@@ -227,7 +230,8 @@ def eval_errors(pred_color, batch_pixels):
     H, W = int(a.shape[0]), int(a.shape[1])
     ws = torch.empty(int(L.lib().mipnerf_eval_workspace_floats(H, W)), device=a.device, dtype=torch.float32)
     out = torch.empty(2, device=a.device, dtype=torch.float32)
-    L.check(L.lib().mipnerf_eval_errors(H, W, _ptr(a.contiguous()), _ptr(b.contiguous()), _ptr(ws), _ptr(out), _stream()),
+    a, b = a.contiguous(), b.contiguous()
+    L.check(L.lib().mipnerf_eval_errors(H, W, _ptr(a), _ptr(b), _ptr(ws), _ptr(out), _stream()),
             "eval_errors")
     return out[0], out[1]
 

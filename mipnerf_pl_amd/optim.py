@@ -18,9 +18,36 @@ class FlatAdam(torch.optim.Optimizer):
             mlp.flatten_parameters()
         self.mlp = mlp
         super().__init__(mlp.ordered_params(), dict(lr=lr, betas=betas, eps=eps))
-        self.exp_avg = torch.zeros_like(mlp._flat_param)
-        self.exp_avg_sq = torch.zeros_like(mlp._flat_param)
-        self.steps = 0
+        # The flat moments and the step count live in `self.state` (keyed on the first parameter), so that
+        # Optimizer.state_dict() / load_state_dict() -- what a Lightning checkpoint stores -- save and restore them
+        # like torch.optim.Adam's per-parameter state.
+        self.state[self._key()] = {"step": torch.zeros((), dtype=torch.int64), "exp_avg": torch.zeros_like(mlp._flat_param),
+                                   "exp_avg_sq": torch.zeros_like(mlp._flat_param)}
+
+    def _key(self):
+        return self.param_groups[0]["params"][0]
+
+    @property
+    def exp_avg(self):
+        return self.state[self._key()]["exp_avg"]
+
+    @property
+    def exp_avg_sq(self):
+        return self.state[self._key()]["exp_avg_sq"]
+
+    @property
+    def steps(self) -> int:
+        return int(self.state[self._key()]["step"])
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        st = self.state[self._key()]
+        flat = self.mlp._flat_param
+        for k in ("exp_avg", "exp_avg_sq"):     # Optimizer.load_state_dict casts to the PARAMETER's shape-agnostic dtype/device only
+            st[k] = st[k].to(device=flat.device, dtype=torch.float32).reshape(-1).clone()
+            if st[k].numel() != flat.numel():
+                raise ValueError(f"FlatAdam.load_state_dict: {k} has {st[k].numel()} elements, expected {flat.numel()}")
+        st["step"] = torch.as_tensor(int(st["step"]), dtype=torch.int64)
 
     def zero_grad(self, set_to_none: bool = True):
         """No kernel: the next backward overwrites the flat gradient (accumulate = 0) instead of adding to it."""
@@ -37,10 +64,11 @@ class FlatAdam(torch.optim.Optimizer):
         if not mlp._flat_grad_valid:
             return loss
         g = self.param_groups[0]
-        self.steps += 1
+        st = self.state[self._key()]
+        st["step"] += 1
         flat = mlp._flat_param
-        L.check(L.lib().mipnerf_adam_step(flat.numel(), flat.data_ptr(), mlp._flat_grad.data_ptr(), self.exp_avg.data_ptr(),
-                                          self.exp_avg_sq.data_ptr(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                          float(g["eps"]), self.steps, ops._stream()), "adam_step")
+        L.check(L.lib().mipnerf_adam_step(flat.numel(), flat.data_ptr(), mlp._flat_grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                          st["exp_avg_sq"].data_ptr(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                          float(g["eps"]), int(st["step"]), ops._stream()), "adam_step")
         mlp.invalidate_packed()
         return loss

@@ -30,6 +30,7 @@ from models import mip as refmip  # noqa: E402  (reference)
 from models.mip_nerf import MipNerf as RefMipNerf  # noqa: E402  (reference)
 
 from oracle import mipnerf_oracle as orc  # noqa: E402
+from synthetic_inputs import traj_target  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -292,8 +293,106 @@ def metrics_case(name):
     print(f"wrote {name}.npz psnr={psnr.item():.4f} ssim={ssim.item():.6f}")
 
 
+def fullsize_case(name, batch, num_samples, param_seed, gain, ray_seed, unbounded=False):
+    """Full-size golden of a BASELINE.json configuration (configs[1] 4096 x 128, configs[3] 8192 x 256): the reference's
+    MipNerf.forward (mip_nerf.py:172-248) on the bench's own synthetic inputs.  Inputs are NOT stored (they regenerate
+    bit-for-bit from the seeds through oracle.synthetic_rays / make_params, which is numpy-only); outputs stored per ray:
+    rgb, distance, acc of both levels (what the metric's 'RGB/depth outputs matching the reference' names)."""
+    import hashlib
+    import time
+    rays = orc.synthetic_rays(batch, seed=ray_seed, unbounded=unbounded)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples)
+    load_params(model, params)
+    model.eval()
+    out = dict(num_samples=num_samples, batch=batch, param_seed=param_seed, density_gain=gain, ray_seed=ray_seed,
+               unbounded=int(unbounded))
+    h = hashlib.sha256()
+    for a in rays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    out["input_sha256"] = h.hexdigest()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ret = model(to_ref_rays(rays), False, True)
+        dt = time.perf_counter() - t0
+    for lvl, (rgb, dist, acc, w, t) in enumerate(ret):
+        out[f"l{lvl}_rgb"] = rgb.numpy()
+        out[f"l{lvl}_distance"] = dist.numpy()
+        out[f"l{lvl}_acc"] = acc.numpy()
+        out[f"l{lvl}_wsum_t"] = (w * 0.5 * (t[:, :-1] + t[:, 1:])).sum(-1).numpy()    # unclamped expected depth (checksum of weights x t)
+    out["ref_cpu_seconds"] = np.float64(dt)
+    out["ref_cpu_threads"] = torch.get_num_threads()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz  reference forward {dt:.2f} s on {torch.get_num_threads()} threads "
+          f"= {batch * num_samples * 2 / dt:.3e} ray-samples/s; acc range [{float(out['l1_acc'].min()):.3f}, {float(out['l1_acc'].max()):.3f}]")
+
+
+TRAJ = dict(batch=256, num_samples=32, steps=300, nbatches=300, lr_init=2e-3, lr_final=1e-4, max_steps=300,
+            lr_delay_steps=30, lr_delay_mult=0.01, heldout=1024, param_seed=11, ray_seed=1000, rng_seed=4321)
+
+
+def trajectory_case(name, randomized):
+    """K-step TRAINING trajectory of the unmodified reference: MipNerf + the loss of nerf_system.py:99-111 +
+    torch.optim.Adam (nerf_system.py:71-72) + the reference's MipLRDecay (utils/lr_schedule.py:5-59), on fixed seeded
+    batches.  Stored: loss / lr per step, held-out render PSNR, parameter norms at the end.  The randomized variant seeds
+    torch's CPU generator with rng_seed + step before every forward, so a test can replay the two draws
+    (mip.py:159 torch.rand, mip.py:201 uniform_) on the CPU and inject them."""
+    from utils.lr_schedule import MipLRDecay as RefMipLRDecay
+    T = TRAJ
+    params = orc.make_params(seed=T["param_seed"], density_gain=1.0)
+    model = RefMipNerf(num_samples=T["num_samples"])
+    load_params(model, params)
+    opt = torch.optim.Adam(model.parameters(), lr=T["lr_init"])
+    sch = RefMipLRDecay(opt, T["lr_init"], T["lr_final"], T["max_steps"], T["lr_delay_steps"], T["lr_delay_mult"])
+    batches = [orc.synthetic_rays(T["batch"], seed=T["ray_seed"] + i, multiscale=True) for i in range(T["nbatches"])]
+    gts = [traj_target(b) for b in batches]
+    held = orc.synthetic_rays(T["heldout"], seed=T["ray_seed"] + 999)
+    held_gt = traj_target(held)
+    losses, lrs, psnrs = [], [], []
+    for step in range(T["steps"]):
+        R = to_ref_rays(batches[step % T["nbatches"]])
+        rgbs = torch.from_numpy(gts[step % T["nbatches"]])
+        if randomized:
+            torch.manual_seed(T["rng_seed"] + step)
+        ret = model(R, randomized, True)
+        mask = R.lossmult
+        ls, dls = [], []
+        for (rgb, _, _, w, t) in ret:
+            ls.append((mask * (rgb - rgbs[..., :3]) ** 2).sum() / mask.sum())
+            dls.append(refmip.distloss(w, t))
+        loss = 0.1 * (ls[0] + 0.01 * dls[0]) + ls[1] + 0.01 * dls[-1]
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sch.step()
+        losses.append(loss.item())
+        psnrs.append(float(-10.0 * torch.log10(torch.mean((ret[-1][0].detach() - rgbs) ** 2))))
+    with torch.no_grad():
+        hret = model(to_ref_rays(held), False, True)
+    hpsnr = float(-10.0 * torch.log10(torch.mean((hret[-1][0] - torch.from_numpy(held_gt)) ** 2)))
+    out = {k: np.asarray(v) for k, v in T.items()}
+    out.update(randomized=int(randomized), loss=np.array(losses, np.float64), lr=np.array(lrs, np.float64),
+               train_psnr=np.array(psnrs, np.float64), heldout_psnr=np.float64(hpsnr),
+               heldout_rgb=hret[-1][0].numpy(), heldout_distance=hret[-1][1].numpy())
+    for k, p in model.mlp.named_parameters():
+        out["pnorm_" + k] = np.float64(p.detach().double().norm().item())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz  loss {losses[0]:.5f} -> {losses[-1]:.5f}, held-out PSNR {hpsnr:.3f} dB, lr {lrs[0]:.2e} .. {max(lrs):.2e} .. {lrs[-1]:.2e}")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
+    if "--only-fullsize" in sys.argv:       # round 2: the BASELINE configurations at full size (same inputs as bench.py)
+        fullsize_case("full_c2_4096x128", 4096, 128, param_seed=0, gain=40.0, ray_seed=100)
+        fullsize_case("full_c4_8192x256", 8192, 256, param_seed=0, gain=40.0, ray_seed=100, unbounded=True)
+        sys.exit(0)
+    if "--only-trajectory" in sys.argv:     # round 2: K-step training trajectories of the reference
+        trajectory_case("traj_256x32_det", randomized=False)
+        trajectory_case("traj_256x32_rand", randomized=True)
+        sys.exit(0)
     if "--only-metrics" in sys.argv:
         metrics_case("metrics_45x70")
         sys.exit(0)

@@ -61,3 +61,29 @@ def maxdiff(a, b):
     b = b.detach().float().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+
+
+import torch.nn.functional as F  # noqa: E402
+
+
+def mlp_torch(mlp, samples_enc, viewdirs_enc, dtype):
+    """models/mip_nerf.py:75-111 through torch ops (library GEMMs): plain-PyTorch fp32 reference of the MLP for the tests."""
+    def lin(layer, x):
+        return F.linear(x, layer.weight.to(dtype), layer.bias.to(dtype))
+    num_samples = samples_enc.shape[1]
+    inputs = samples_enc.to(dtype)
+    x = inputs
+    for i, layer in enumerate(mlp.layers):
+        x = torch.relu(lin(layer[0], x))
+        if i % mlp.skip_index == 0 and i > 0:
+            x = torch.cat([x, inputs], dim=-1)
+    raw_density = lin(mlp.density_layer, x)
+    bottleneck = lin(mlp.extra_layer, x)
+    vd = viewdirs_enc.to(dtype)[:, None, :].expand(-1, num_samples, -1)
+    x = torch.cat([bottleneck, vd], dim=-1)
+    for layer in mlp.view_layers:
+        x = torch.relu(lin(layer[0], x))
+    raw_rgb = lin(mlp.color_layer, x)
+    return torch.cat([raw_rgb, raw_density], dim=-1).float()
+
+

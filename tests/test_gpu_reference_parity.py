@@ -1,0 +1,165 @@
+"""Round-2 parity against the UNMODIFIED reference at the sizes and over the horizon the metric is quoted on:
+
+* full-size goldens of BASELINE.json configs[1] (4096 rays x 128 samples) and configs[3] (8192 rays x 256 samples,
+  per-ray near/far): EVERY ray of (rgb, distance, acc) of both levels against the reference's CPU forward
+  (scripts/make_golden.py --only-fullsize; inputs regenerate bit-for-bit from seeds, checked by sha256);
+* K-step training trajectories of the reference (MipNerf + nerf_system.py:99-111 loss + torch.optim.Adam +
+  utils/lr_schedule.py MipLRDecay, scripts/make_golden.py --only-trajectory): fp32 mode must reproduce the loss curve,
+  bf16 mode (native training kernels + fused flat Adam) must end within 0.1 dB of the reference's held-out PSNR.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import synthetic_inputs as syn
+from oracle import mipnerf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_util
+    assert torch.cuda.is_available()
+    return gpu_util
+
+
+def _inputs(g):
+    rays = syn.synthetic_rays(int(g["batch"]), seed=int(g["ray_seed"]), unbounded=bool(g["unbounded"]))
+    params = syn.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    h = hashlib.sha256()
+    for a in rays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    assert h.hexdigest() == str(g["input_sha256"]), "seeded inputs no longer regenerate bit-for-bit"
+    return rays, params
+
+
+def _psnr(a, b):
+    return float(-10.0 * np.log10(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2) + 1e-30))
+
+
+@pytest.mark.parametrize("name", ["full_c2_4096x128", "full_c4_8192x256"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_size_every_ray(G, name, precision):
+    g = G.load_golden(name)
+    rays, params = _inputs(g)
+    model = G.make_model(params, int(g["num_samples"]), precision)
+    with torch.no_grad():
+        ret = model(G.to_dev(rays), False, True)
+    errs = {}
+    for lvl in range(2):
+        rgb, dist, acc, w, t = ret[lvl]
+        errs[f"l{lvl}_rgb"] = G.maxdiff(rgb, g[f"l{lvl}_rgb"])
+        errs[f"l{lvl}_distance"] = G.maxdiff(dist, g[f"l{lvl}_distance"])
+        errs[f"l{lvl}_acc"] = G.maxdiff(acc, g[f"l{lvl}_acc"])
+        wt = (w * 0.5 * (t[:, :-1] + t[:, 1:])).sum(-1)
+        errs[f"l{lvl}_wsum_t"] = G.maxdiff(wt, g[f"l{lvl}_wsum_t"])
+    errs["psnr_l1_rgb"] = _psnr(ret[1][0].cpu().numpy(), g["l1_rgb"])
+    G.record(f"fullsize {name} {precision}", **errs)
+    if precision == "fp32":
+        for k, e in errs.items():
+            if k.startswith("psnr"):
+                continue
+            kind = k.split("_", 1)[1]
+            tol = G.TOL_FP32["distance" if kind in ("distance", "wsum_t") else kind]
+            # per-ray near/far up to 20 (configs[3]): distances are ~5x larger than in the lego-like case
+            if name.startswith("full_c4") and kind in ("distance", "wsum_t"):
+                tol *= 5
+            assert e <= tol, f"{name} fp32 {k}: {e} > {tol}"
+    else:
+        assert errs["psnr_l1_rgb"] > 55.0, errs
+        assert errs["l0_rgb"] <= 3e-2 and errs["l1_rgb"] <= 3e-2, errs
+        assert errs["l0_acc"] <= 5e-2 and errs["l1_acc"] <= 5e-2, errs
+
+
+# ---- training trajectories ------------------------------------------------------------------------------------------
+def _traj_setup(g, precision, fused):
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({"nerf.num_samples": int(g["num_samples"]), "optimizer.lr_init": float(g["lr_init"]),
+               "optimizer.lr_final": float(g["lr_final"]), "optimizer.max_steps": int(g["max_steps"]),
+               "optimizer.lr_delay_steps": int(g["lr_delay_steps"]), "optimizer.lr_delay_mult": float(g["lr_delay_mult"])})
+    system = MipNeRFSystem(hp, precision=precision)
+    params = syn.make_params(seed=int(g["param_seed"]), density_gain=1.0)
+    system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    system = system.to(DEV)
+    system.fused_adam = fused
+    (opt,), (sch,) = system.configure_optimizers()
+    return system, opt, sch["scheduler"]
+
+
+def _traj_run(G, g, precision, fused, native):
+    system, opt, sch = _traj_setup(g, precision, fused)
+    model = system.mip_nerf
+    B, N, K = int(g["batch"]), int(g["num_samples"]), int(g["steps"])
+    randomized = bool(int(g["randomized"]))
+    losses, lrs = [], []
+    for step in range(K):
+        rays_np = syn.synthetic_rays(B, seed=int(g["ray_seed"]) + step % int(g["nbatches"]), multiscale=True)
+        R = G.to_dev(rays_np)
+        gt = torch.from_numpy(syn.traj_target(rays_np)).to(DEV)
+        t_rand = u_rand = None
+        if randomized:      # replay the reference's two CPU draws (mip.py:159 torch.rand, mip.py:201 uniform_)
+            torch.manual_seed(int(g["rng_seed"]) + step)
+            t_rand = torch.rand(B, N + 1).to(DEV)
+            u_rand = torch.empty(B, N + 1).uniform_(0, 1).to(DEV)
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.zero_grad()
+        if native:
+            scalars, _ = model.train_step_native(R, gt, randomized, True, t_rand=t_rand, u_rand=u_rand)
+            loss = scalars[0]
+        else:
+            ret = model(R, randomized, True, t_rand=t_rand, u_rand=u_rand)
+            loss, _, _ = system.compute_loss(ret, R, gt)
+            loss.backward()
+        opt.step()
+        sch.step()
+        losses.append(float(loss))
+    held = syn.synthetic_rays(int(g["heldout"]), seed=int(g["ray_seed"]) + 999)
+    with torch.no_grad():
+        hret = model(G.to_dev(held), False, True)
+    hrgb = hret[-1][0].cpu().numpy()
+    psnr = _psnr(hrgb, syn.traj_target(held))
+    return np.array(losses), np.array(lrs), psnr, hrgb, model
+
+
+@pytest.mark.parametrize("name", ["traj_256x32_det", "traj_256x32_rand"])
+def test_training_trajectory_fp32_reproduces_reference(G, name):
+    """fp32 parity mode + torch.optim.Adam + MipLRDecay: the reference's loss curve, step by step.  Tolerance: rounding
+    differences (GEMM summation order) are amplified by Adam's g/sqrt(v) normalisation over hundreds of steps, so the
+    bound is 1e-4 relative over the first 20 steps (pure arithmetic parity) and 2 % of the loss afterwards; the held-out
+    PSNR must agree within 0.1 dB and the LR schedule exactly."""
+    g = G.load_golden(name)
+    losses, lrs, psnr, hrgb, model = _traj_run(G, g, "fp32", fused=False, native=False)
+    ref = g["loss"]
+    rel = np.abs(losses - ref) / np.abs(ref)
+    G.record(f"trajectory {name} fp32", rel_first20=rel[:20].max(), rel_max=rel.max(), rel_last=rel[-1],
+             heldout_psnr=psnr, ref_heldout_psnr=float(g["heldout_psnr"]), loss_last=losses[-1], ref_loss_last=ref[-1])
+    assert np.allclose(lrs, g["lr"], rtol=1e-12, atol=0)
+    assert rel[:20].max() <= 1e-4, rel[:20]
+    assert rel.max() <= 2e-2, (rel.max(), int(rel.argmax()))
+    assert abs(psnr - float(g["heldout_psnr"])) <= 0.1
+    for k, p in model.mlp.named_parameters():
+        want = float(g["pnorm_" + k])
+        assert abs(float(p.detach().double().norm()) - want) <= 5e-3 * max(want, 1e-3), k
+
+
+@pytest.mark.parametrize("name", ["traj_256x32_det", "traj_256x32_rand"])
+def test_training_trajectory_bf16_within_0p1_db_of_reference(G, name):
+    """The headline precision, the way bench.py trains: native bf16 training kernels (mipnerf_train_step) + fused flat
+    Adam + MipLRDecay on the reference's batches.  north_star: "PSNR within 0.1 dB of reference"."""
+    g = G.load_golden(name)
+    losses, lrs, psnr, hrgb, model = _traj_run(G, g, "bf16", fused=True, native=True)
+    ref = g["loss"]
+    rel = np.abs(losses - ref) / np.abs(ref)
+    G.record(f"trajectory {name} bf16", rel_first20=rel[:20].max(), rel_max=rel.max(), rel_last=rel[-1],
+             heldout_psnr=psnr, ref_heldout_psnr=float(g["heldout_psnr"]), loss_last=losses[-1], ref_loss_last=ref[-1],
+             psnr_vs_ref_render=_psnr(hrgb, g["heldout_rgb"]))
+    assert np.allclose(lrs, g["lr"], rtol=1e-6, atol=0)
+    assert rel[:20].max() <= 2e-2
+    assert abs(psnr - float(g["heldout_psnr"])) <= 0.1, (psnr, float(g["heldout_psnr"]))

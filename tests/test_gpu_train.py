@@ -420,7 +420,8 @@ def test_mlp_module_forward_is_differentiable(G):
 def test_fp32_native_mlp_backward_matches_reference_golden(G):
     """Parity mode: fused fp32 forward-with-save + fp32-MFMA GEMM backward against the reference's autograd gradients
     (golden, full fp32 tolerance) and against a plain-PyTorch fp32 restatement of the same op."""
-    from mipnerf_pl_amd.autograd import mlp_native_f32, mlp_torch
+    from mipnerf_pl_amd.autograd import mlp_native_f32
+    from gpu_util import mlp_torch
     g = G.load_golden("mlp_bwd_8x32_trained")
     params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
     d_raw = torch.from_numpy(np.concatenate([g["d_rgb"], g["d_den"]], -1)).to(DEV)

@@ -170,3 +170,37 @@ def test_eval_errors_matches_reference(golden_dir):
     g = load(golden_dir, "metrics_45x70")
     psnr, ssim = orc.eval_errors(g["pred"], g["gt"])
     assert abs(float(psnr) - float(g["psnr"])) <= 1e-4 and abs(float(ssim) - float(g["ssim"])) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["full_c2_4096x128", "full_c4_8192x256"])
+def test_fullsize_golden_inputs_regenerate(golden_dir, name):
+    """The full-size goldens store only the reference's outputs; their inputs must regenerate bit-for-bit from the seeds."""
+    import hashlib
+    import os
+    import synthetic_inputs as syn
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    rays = syn.synthetic_rays(int(g["batch"]), seed=int(g["ray_seed"]), unbounded=bool(g["unbounded"]))
+    params = syn.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    h = hashlib.sha256()
+    for a in rays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    assert h.hexdigest() == str(g["input_sha256"])
+    assert g["l1_rgb"].shape == (int(g["batch"]), 3) and np.isfinite(g["l1_rgb"]).all()
+
+
+def test_oracle_on_fullsize_golden_sample(golden_dir):
+    """Oracle vs the reference's full-size configs[1] outputs on a 96-ray sample (rays are independent)."""
+    import os
+    import synthetic_inputs as syn
+    g = np.load(os.path.join(golden_dir, "full_c2_4096x128.npz"))
+    rays = syn.synthetic_rays(int(g["batch"]), seed=int(g["ray_seed"]))
+    params = syn.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    idx = np.arange(0, 4096, 43)[:96]
+    sub = orc.Rays(*[a[idx] for a in rays])
+    ret = orc.mipnerf_forward(params, sub, False, True, num_samples=int(g["num_samples"]))
+    for lvl in range(2):
+        assert np.max(np.abs(ret[lvl][0] - g[f"l{lvl}_rgb"][idx])) <= 2e-4
+        assert np.max(np.abs(ret[lvl][1] - g[f"l{lvl}_distance"][idx])) <= 5e-4
+        assert np.max(np.abs(ret[lvl][2] - g[f"l{lvl}_acc"][idx])) <= 2e-4

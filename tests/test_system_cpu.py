@@ -89,3 +89,23 @@ def test_flat_mode_bookkeeping_survives_foreign_zero_grad():
     mlp.gather_foreign_grads()
     assert mlp.grads_are_flat() and mlp._flat_grad_valid is True and float(w.grad.mean()) == 3.0
     assert w.grad.data_ptr() != 0 and w.grad.data_ptr() >= mlp._flat_grad.data_ptr()
+
+
+def test_flat_adam_state_dict_round_trip():
+    """FlatAdam keeps its moments and step count in Optimizer.state, so a (Lightning) checkpoint's
+    optimizer.state_dict() restores them like torch.optim.Adam's."""
+    import torch
+    from mipnerf_pl_amd import MipNerf
+    from mipnerf_pl_amd.optim import FlatAdam
+    m1, m2 = MipNerf(num_samples=8), MipNerf(num_samples=8)
+    o1, o2 = FlatAdam(m1.mlp, lr=1e-3), FlatAdam(m2.mlp, lr=5e-4)
+    st = o1.state[o1._key()]
+    st["exp_avg"].uniform_(-1, 1)
+    st["exp_avg_sq"].uniform_(0, 1)
+    st["step"] += 7
+    sd = o1.state_dict()
+    assert len(sd["state"]) == 1 and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    o2.load_state_dict(sd)
+    assert o2.steps == 7 and o2.param_groups[0]["lr"] == 1e-3
+    assert torch.equal(o2.exp_avg, o1.exp_avg) and torch.equal(o2.exp_avg_sq, o1.exp_avg_sq)
+    assert o2.exp_avg.data_ptr() != o1.exp_avg.data_ptr()
