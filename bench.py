@@ -232,18 +232,32 @@ def run_train(args, e):
     reduce_grads = FlatGradAllReduce(list(model.parameters()), mlp=model.mlp)
     gt = torch.rand(B, 3, device=e.dev)
     native = not args.autograd and args.precision == "bf16"
+    graphed = native and not args.torch_adam
+    if graphed:
+        # the whole step (draws + forward + loss + backward [+ all-reduce] + scheduled Adam + weight re-pack) replayed from
+        # captured hipGraph(s); MipLRDecay runs on the device, the scheduler object only mirrors the epoch on the host
+        from mipnerf_pl_amd.train_graph import GraphedTrainStep
+        gstep = GraphedTrainStep(system, opt, B, e.dev, use_graph=not args.no_graph)
+        for dst, src in zip(gstep.rays, R):
+            dst.copy_(src)
+        gstep.gt.copy_(gt)
 
-    def step():
-        opt.zero_grad(set_to_none=False)              # FlatAdam: no kernel, the next backward overwrites
-        if native:
-            loss = system.training_step_native((R, gt), 0)     # forward + loss + backward, one native call
-        else:
-            loss = system.training_step((R, gt), 0)            # randomized=True, nerf_system.py:95-121
-            loss.backward()
-        reduce_grads()                                # one flat all-reduce over RCCL (no-op at world 1)
-        opt.step()
-        sch["scheduler"].step()
-        return [(loss.detach().reshape(1),)]
+        def step():
+            sc = gstep()
+            sch["scheduler"].step()
+            return [(sc[:1],)]
+    else:
+        def step():
+            opt.zero_grad(set_to_none=False)              # FlatAdam: no kernel, the next backward overwrites
+            if native:
+                loss = system.training_step_native((R, gt), 0)     # forward + loss + backward, one native call
+            else:
+                loss = system.training_step((R, gt), 0)            # randomized=True, nerf_system.py:95-121
+                loss.backward()
+            reduce_grads()                                # one flat all-reduce over RCCL (no-op at world 1)
+            opt.step()
+            sch["scheduler"].step()
+            return [(loss.detach().reshape(1),)]
     step()
     dt, out = timed(e, step, args.warmup, args.steps)
     assert bool(torch.isfinite(out[-1][0]).all())
@@ -261,6 +275,7 @@ def run_train(args, e):
                                    f"Adam + MipLRDecay), {B} rays x ({N}+{N}) samples per GPU"),
                       "mode": "train", "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
                       "native_step": native, "fused_adam": not args.torch_adam,
+                      "hip_graph": bool(graphed and not args.no_graph), "lr_schedule": "device" if graphed else "host",
                       "parallelism": f"data-parallel x{e.world}, one {4 * sum(p.numel() for p in model.parameters())} B all-reduce per step"}}
     return rec
 

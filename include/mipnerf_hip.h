@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MIPNERF_ABI_VERSION 1
+#define MIPNERF_ABI_VERSION 2
 
 enum {
     MIPNERF_OK = 0,
@@ -74,6 +74,8 @@ typedef struct mipnerf_config {
     float resample_padding;      /* 0.01                                                    */
     float density_bias;          /* -1                                                      */
     float rgb_padding;           /* 0.001                                                   */
+    float density_noise;         /* 0 ; std-dev of the noise added to raw density when a    */
+                                 /* density_randn tensor is given (mip_nerf.py:232-233)     */
 } mipnerf_config;
 
 #define MIPNERF_MAX_SAMPLES 512
@@ -133,10 +135,13 @@ int mipnerf_set_params(mipnerf_ctx* ctx, const float* const* params_host, void* 
 /* ---- the whole hot path: MipNerf.forward (mip_nerf.py:172-248) ------------------------ */
 size_t mipnerf_workspace_bytes(const mipnerf_ctx* ctx, int64_t num_rays);
 /* t_rand [B,N+1] / u_rand [B,N+1]: uniform [0,1) noise replacing torch.rand (mip.py:159)
- * and uniform_ (mip.py:201); both NULL <=> randomized=False.  out[level], level <
- * num_levels. */
+ * and uniform_ (mip.py:201); both NULL <=> randomized=False.  density_randn (NULL = none):
+ * standard-normal draws [num_levels, B, N] replacing torch.randn of mip_nerf.py:232-233; the raw
+ * density of level l becomes raw + cfg.density_noise * density_randn[l] before the softplus.
+ * out[level], level < num_levels. */
 int mipnerf_forward(mipnerf_ctx* ctx, int64_t num_rays, const mipnerf_rays* rays,
-                    const float* t_rand, const float* u_rand, uint32_t flags, int precision,
+                    const float* t_rand, const float* u_rand, const float* density_randn,
+                    uint32_t flags, int precision,
                     void* workspace, size_t workspace_bytes, const mipnerf_level_out* out,
                     void* stream);
 
@@ -202,9 +207,10 @@ int mipnerf_eval_errors(int32_t height, int32_t width, const float* pred, const 
                         float* workspace, float* out_psnr_ssim, void* stream);
 
 /* ---- training side ---------------------------------------------------------------------- */
-/* activations (mip_nerf.py:236-238): raw [M,4] = (raw_rgb, raw_density) -> rgb_sigma [M,4]. */
+/* activations (mip_nerf.py:236-238): raw [M,4] = (raw_rgb, raw_density) -> rgb_sigma [M,4];
+ * density_randn [M] (NULL = none): raw_density + density_noise * density_randn first (mip_nerf.py:232-233). */
 int mipnerf_activate(int64_t num_points, const float* raw, float rgb_padding, float density_bias,
-                     float* rgb_sigma, void* stream);
+                     const float* density_randn, float density_noise, float* rgb_sigma, void* stream);
 /* backward of volumetric_rendering (mip.py:366-401) fused with the activation derivatives:
  * upstream g_rgb [B,3], g_dist [B], g_acc [B], g_w [B,N] (any may be NULL = zero) ->
  * d_raw [B*N,4] = dL/d(raw_rgb, raw_density).  rgb_sigma is the ACTIVATED forward tensor. */
@@ -259,6 +265,23 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* ctx, int64_t num_points, int32_t num_s
                              const float* enc, const float* viewenc, const float* save, void* workspace,
                              float* grad_flat, int32_t accumulate, void* stream);
 
+/* ---- optimiser step with the LR schedule on the device (graph-capturable: no per-step host scalars) ------------------
+ * torch.optim.Adam(lr) + MipLRDecay of the reference (nerf_system.py:70-76, utils/lr_schedule.py:51-59).
+ * *step_count (device int64, starts at 0) is incremented to t; the step runs with lr = MipLRDecay(last_epoch = t - 1)
+ * (constant_lr > 0 overrides the schedule), bias corrections of step t, and grad * grad_scale (1 / world_size after a SUM
+ * all-reduce).  hyper_out (device float[4]) receives lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale (the `lr` that
+ * nerf_system.py:117 logs). */
+typedef struct mipnerf_lr_schedule {
+    double lr_init, lr_final, lr_delay_mult, constant_lr;
+    int64_t max_steps, lr_delay_steps;
+    double beta1, beta2, eps;
+    float grad_scale;
+    int32_t reserved;
+} mipnerf_lr_schedule;
+int mipnerf_adam_step_scheduled(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                const mipnerf_lr_schedule* schedule, int64_t* step_count, float* hyper_out,
+                                void* stream);
+
 /* ---- the whole training step (bf16): MipNeRFSystem.training_step (nerf_system.py:95-111) + loss.backward() --------
  * forward of all levels with saved activations, loss = cm (mse_c + dm dl_c) + mse_f + dm dl_f (cm = loss.coarse_loss_mult,
  * dm = 0.01, mse masked by rays.lossmult unless disable_multiscale_loss), backward of compositing / activations / MLP.
@@ -267,7 +290,8 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* ctx, int64_t num_points, int32_t num_s
  * receives copies of what MipNerf.forward returns.  No autograd graph, no allocation, one stream: graph-capturable. */
 size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* ctx, int64_t num_rays);
 int mipnerf_train_step(mipnerf_ctx* ctx, int64_t num_rays, const mipnerf_rays* rays, const float* gt_rgb,
-                       const float* t_rand, const float* u_rand, uint32_t flags, float coarse_loss_mult,
+                       const float* t_rand, const float* u_rand, const float* density_randn, uint32_t flags,
+                       float coarse_loss_mult,
                        float distloss_mult, int32_t disable_multiscale_loss, void* workspace,
                        size_t workspace_bytes, float* grad_flat, int32_t accumulate, float* out_scalars,
                        const mipnerf_level_out* out, void* stream);

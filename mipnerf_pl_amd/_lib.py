@@ -22,12 +22,19 @@ class Config(C.Structure):
         "num_samples", "num_levels", "min_deg_point", "max_deg_point", "deg_view", "use_viewdirs",
         "disparity", "disable_integration", "net_depth", "net_width", "net_depth_condition",
         "net_width_condition", "skip_index", "num_rgb_channels", "num_density_channels")] + [
-        ("resample_padding", C.c_float), ("density_bias", C.c_float), ("rgb_padding", C.c_float)]
+        ("resample_padding", C.c_float), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
+        ("density_noise", C.c_float)]
 
 
 class RaysPtrs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("origins", "directions", "viewdirs", "radii", "lossmult", "near", "far")]
+
+
+class LrSchedule(C.Structure):
+    _fields_ = [("lr_init", C.c_double), ("lr_final", C.c_double), ("lr_delay_mult", C.c_double), ("constant_lr", C.c_double),
+                ("max_steps", C.c_int64), ("lr_delay_steps", C.c_int64), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_double), ("grad_scale", C.c_float), ("reserved", C.c_int32)]
 
 
 class LevelOut(C.Structure):
@@ -45,7 +52,7 @@ SIGNATURES = {
     "mipnerf_compiled_arch": (C.c_int, [C.POINTER(Config)]),
     "mipnerf_set_params": (C.c_int, [_P, C.POINTER(_P), _P]),
     "mipnerf_workspace_bytes": (_SZ, [_P, _I64]),
-    "mipnerf_forward": (C.c_int, [_P, _I64, C.POINTER(RaysPtrs), _P, _P, C.c_uint32, C.c_int, _P, _SZ,
+    "mipnerf_forward": (C.c_int, [_P, _I64, C.POINTER(RaysPtrs), _P, _P, _P, C.c_uint32, C.c_int, _P, _SZ,
                                   C.POINTER(LevelOut), _P]),
     "mipnerf_sample_along_rays": (C.c_int, [_I64, _I32, _P, _P, _P, _I32, _P, _P]),
     "mipnerf_cast_rays": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
@@ -59,13 +66,14 @@ SIGNATURES = {
     "mipnerf_generate_rays": (C.c_int, [_I64, _P, _P, _P, C.POINTER(RaysPtrs), _P]),
     "mipnerf_eval_workspace_floats": (_I64, [_I32, _I32]),
     "mipnerf_eval_errors": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P]),
-    "mipnerf_activate": (C.c_int, [_I64, _P, _F, _F, _P, _P]),
+    "mipnerf_activate": (C.c_int, [_I64, _P, _F, _F, _P, _F, _P, _P]),
     "mipnerf_volumetric_rendering_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _F, _P, _P]),
     "mipnerf_distloss": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P]),
     "mipnerf_mlp_train_sizes": (C.c_int, [_P, _I64, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ)]),
     "mipnerf_mlp_forward_train": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "mipnerf_mlp_backward": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "mipnerf_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _F, _F, _F, _F, _I32, _P]),
+    "mipnerf_adam_step_scheduled": (C.c_int, [_I64, _P, _P, _P, _P, C.POINTER(LrSchedule), _P, _P, _P]),
     "mipnerf_mlp_dgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P]),
     "mipnerf_mlp_wgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P]),
     "mipnerf_set_wgrad_splits": (C.c_int, [_P, _P]),
@@ -73,7 +81,7 @@ SIGNATURES = {
     "mipnerf_mlp_forward_train_f32": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "mipnerf_mlp_backward_f32": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "mipnerf_train_workspace_bytes": (_SZ, [_P, _I64]),
-    "mipnerf_train_step": (C.c_int, [_P, _I64, C.POINTER(RaysPtrs), _P, _P, _P, C.c_uint32, _F, _F, _I32, _P, _SZ, _P, _I32, _P,
+    "mipnerf_train_step": (C.c_int, [_P, _I64, C.POINTER(RaysPtrs), _P, _P, _P, _P, C.c_uint32, _F, _F, _I32, _P, _SZ, _P, _I32, _P,
                                      C.POINTER(LevelOut), _P]),
     "mipnerf_time_mlp": (C.c_int, [_P, _I64, _I32, _P, _P, C.c_int, _P, C.c_int, C.POINTER(_F), _P]),
     "mipnerf_selftest": (C.c_int, [_P]),

@@ -19,11 +19,13 @@ class _RenderFromRaw(torch.autograd.Function):
     """activations (mip_nerf.py:236-238) + volumetric_rendering (mip.py:366-401) on raw [B,N,4]."""
 
     @staticmethod
-    def forward(ctx, raw, t_samples, dirs, white_bkgd, rgb_padding, density_bias):
+    def forward(ctx, raw, t_samples, dirs, white_bkgd, rgb_padding, density_bias, density_randn=None, density_noise=0.0):
         raw = ops._f32c(raw, "raw")
         B, N = raw.shape[0], raw.shape[1]
         rgb_sigma = torch.empty_like(raw)
+        dz = None if density_randn is None else ops._f32c(density_randn, "density_randn")     # mip_nerf.py:232-233
         L.check(L.lib().mipnerf_activate(B * N, raw.data_ptr(), float(rgb_padding), float(density_bias),
+                                         None if dz is None else dz.data_ptr(), float(density_noise),
                                          rgb_sigma.data_ptr(), ops._stream()), "activate")
         comp_rgb, distance, acc, weights = ops.volumetric_rendering_packed(rgb_sigma, t_samples, dirs, white_bkgd)
         ctx.save_for_backward(rgb_sigma, ops._f32c(t_samples, "t"), ops._f32c(dirs, "dirs"))
@@ -45,7 +47,7 @@ class _RenderFromRaw(torch.autograd.Function):
             B, N, rgb_sigma.data_ptr(), t.data_ptr(), dirs.data_ptr(), int(ctx.white),
             *[None if k is None else k.data_ptr() for k in keep], ctx.rgb_padding, d_raw.data_ptr(), ops._stream()),
             "volumetric_rendering_bwd")
-        return d_raw, None, None, None, None, None
+        return d_raw, None, None, None, None, None, None, None
 
 
 class _DistLossRays(torch.autograd.Function):
@@ -191,16 +193,20 @@ def distloss(weight, samples):
     return _DistLossRays.apply(weight, samples).mean()
 
 
-def render_from_raw(raw, t_samples, dirs, white_bkgd, rgb_padding=0.001, density_bias=-1.0):
-    return _RenderFromRaw.apply(raw, t_samples, dirs, white_bkgd, rgb_padding, density_bias)
+def render_from_raw(raw, t_samples, dirs, white_bkgd, rgb_padding=0.001, density_bias=-1.0, density_randn=None,
+                    density_noise=0.0):
+    return _RenderFromRaw.apply(raw, t_samples, dirs, white_bkgd, rgb_padding, density_bias, density_randn, density_noise)
 
 
-def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_rand=None):
+def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_rand=None, density_randn=None):
     """Differentiable MipNerf.forward (mip_nerf.py:172-248): list of (comp_rgb, distance, acc, weights, t_samples)."""
     dev = rays.origins.device
     native = model.precision == L.PREC_BF16
     N = model.num_samples
     model.mlp.native(dev)      # raises NotImplementedError for an MLP shape the kernels were not generated for
+    dz = model._density_randn(randomized, rays.origins.shape[0], dev, density_randn)
+    if dz is not None:
+        dz = dz.reshape(model.num_levels, -1)
     with torch.no_grad():
         venc = ops.pos_enc(rays.viewdirs, 0, model.deg_view, True, precision=model.precision, ld=32)
     ret = []
@@ -215,6 +221,7 @@ def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_ra
                                model.max_deg_point, model.disable_integration, precision=model.precision)
         raw = mlp_native(model.mlp, enc, venc) if native else mlp_native_f32(model.mlp, enc, venc)
         comp_rgb, distance, acc, weights = render_from_raw(raw, t_samples, rays.directions, white_bkgd,
-                                                           model.rgb_padding, model.density_bias)
+                                                           model.rgb_padding, model.density_bias,
+                                                           None if dz is None else dz[lvl], model.density_noise)
         ret.append((comp_rgb, distance, acc, weights, t_samples))
     return ret

@@ -211,6 +211,7 @@ struct mipnerf_ctx {
     int fused_ipe = 1;               // bf16 mipnerf_forward: IPE computed inside the MLP kernel (0: k_cast_ipe + enc buffer)
     int grid_limit = 256;            // persistent workgroups of the bf16 MLP kernel (= CUs)
     // optional instrumentation: HIP events around every MLP launch made by mipnerf_forward
+    const float* dnoise = nullptr;   // density noise draws of the level being evaluated (set by mipnerf_forward / _train_step only)
     int time_mlp = 0;
     std::vector<hipEvent_t> ev;      // pairs (start, stop)
     size_t ev_used = 0;
@@ -243,7 +244,7 @@ int mipnerf_compiled_arch(mipnerf_config* cfg) {
     cfg->deg_view = (kViewDim - 3) / 6; cfg->use_viewdirs = 1; cfg->net_depth = kNetDepth; cfg->net_width = kNetWidth;
     cfg->net_depth_condition = kNetDepthCond; cfg->net_width_condition = kNetWidthCond; cfg->skip_index = kSkipIndex;
     cfg->num_rgb_channels = kNumRgb; cfg->num_density_channels = kNumDensity;
-    cfg->resample_padding = 0.01f; cfg->density_bias = -1.0f; cfg->rgb_padding = 0.001f;
+    cfg->resample_padding = 0.01f; cfg->density_bias = -1.0f; cfg->rgb_padding = 0.001f; cfg->density_noise = 0.0f;
     return MIPNERF_OK;
 }
 
@@ -414,10 +415,12 @@ int mipnerf_mlp_forward(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, c
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward: mipnerf_set_params has not been called");
     if (precision == MIPNERF_PREC_BF16) {
         HIP_TRY(mip::launch_mlp_bf16(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias,
-                                     c->cfg.rgb_padding, c->grid_limit, c->mlp_dma != 0, nullptr, S(stream)));
+                                     c->cfg.rgb_padding, c->grid_limit, c->mlp_dma != 0, nullptr, c->dnoise, c->cfg.density_noise,
+                                     S(stream)));
     } else if (precision == MIPNERF_PREC_FP32) {
         HIP_TRY(mip::launch_mlp_f32(c->tab.net, c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
-                                    rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, S(stream)));
+                                    rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, c->dnoise,
+                                    c->cfg.density_noise, S(stream)));
     } else {
         return fail(MIPNERF_E_INVALID, "unknown precision %d", precision);
     }
@@ -474,9 +477,10 @@ int mipnerf_eval_errors(int32_t H, int32_t W, const float* pred, const float* gt
 }
 
 // ---- training-side entry points ------------------------------------------------------------------
-int mipnerf_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, float* rgb_sigma, void* stream) {
+int mipnerf_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, const float* density_randn,
+                     float density_noise, float* rgb_sigma, void* stream) {
     if (M < 1 || !raw || !rgb_sigma) return fail(MIPNERF_E_INVALID, "activate: bad argument");
-    HIP_TRY(mip::launch_activate(M, raw, rgb_padding, density_bias, rgb_sigma, S(stream)));
+    HIP_TRY(mip::launch_activate(M, raw, rgb_padding, density_bias, density_randn, density_noise, rgb_sigma, S(stream)));
     return MIPNERF_OK;
 }
 
@@ -516,7 +520,8 @@ int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* 
         return fail(MIPNERF_E_INVALID, "mlp_forward_train: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train: mipnerf_set_params has not been called");
     HIP_TRY(mip::launch_mlp_bf16_trainfwd(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, act, masks, M, N,
-                                          c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, nullptr, S(stream)));
+                                          c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, nullptr, c->dnoise,
+                                          c->cfg.density_noise, S(stream)));
     return MIPNERF_OK;
 }
 
@@ -570,6 +575,19 @@ int mipnerf_adam_step(int64_t n, float* param, const float* grad, float* exp_avg
                       float beta2, float eps, int32_t step, void* stream) {
     if (n < 1 || !param || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail(MIPNERF_E_INVALID, "adam_step: bad argument");
     HIP_TRY(mip::launch_adam_flat(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_adam_step_scheduled(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                const mipnerf_lr_schedule* sc, int64_t* step_count, float* hyper_out, void* stream) {
+    if (n < 1 || !param || !grad || !exp_avg || !exp_avg_sq || !sc || !step_count || !hyper_out)
+        return fail(MIPNERF_E_INVALID, "adam_step_scheduled: bad argument");
+    if (sc->constant_lr <= 0.0 && (sc->lr_init <= 0.0 || sc->lr_final <= 0.0 || sc->max_steps < 1))
+        return fail(MIPNERF_E_INVALID, "adam_step_scheduled: lr_init, lr_final and max_steps must be positive");
+    static_assert(sizeof(mipnerf_lr_schedule) == sizeof(mip::LrSchedule), "schedule structs must match");
+    mip::LrSchedule k;
+    memcpy(&k, sc, sizeof k);
+    HIP_TRY(mip::launch_adam_scheduled(n, param, grad, exp_avg, exp_avg_sq, k, step_count, hyper_out, S(stream)));
     return MIPNERF_OK;
 }
 
@@ -628,7 +646,7 @@ int mipnerf_mlp_forward_train_f32(mipnerf_ctx* c, int64_t M, int32_t N, const fl
         return fail(MIPNERF_E_INVALID, "mlp_forward_train_f32: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train_f32: mipnerf_set_params has not been called");
     HIP_TRY(mip::launch_mlp_f32(c->tab.net, c->d_stream_f32, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias,
-                                c->cfg.rgb_padding, save, S(stream)));
+                                c->cfg.rgb_padding, save, nullptr, 0.0f, S(stream)));
     return MIPNERF_OK;
 }
 
@@ -715,7 +733,7 @@ size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
 }
 
 int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* gt_rgb, const float* t_rand,
-                       const float* u_rand, uint32_t flags, float coarse_loss_mult, float distloss_mult,
+                       const float* u_rand, const float* density_randn, uint32_t flags, float coarse_loss_mult, float distloss_mult,
                        int32_t disable_multiscale_loss, void* workspace, size_t workspace_bytes, float* grad_flat,
                        int32_t accumulate, float* out_scalars, const mipnerf_level_out* out, void* stream) {
     if (!c || !rays || !gt_rgb || !workspace || !grad_flat || !out_scalars || B < 1)
@@ -751,7 +769,12 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
     // ---- forward (mip_nerf.py:182-246), activations saved for the backward -------------------------------------------
     if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, MIPNERF_PREC_BF16, stream))) return rc;
+    struct NoiseScope {            // the per-level noise pointer is visible to the MLP launches of THIS call only
+        mipnerf_ctx* c;
+        ~NoiseScope() { c->dnoise = nullptr; }
+    } noise_scope{c};
     for (int l = 0; l < L; ++l) {
+        c->dnoise = density_randn ? density_randn + (size_t)l * M : nullptr;
         if (l == 0) {
             if ((rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, lv[0].t, stream))) return rc;
         } else {
@@ -762,7 +785,7 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
                                        cfg.disable_integration};
             HIP_TRY(mip::launch_mlp_bf16_trainfwd(c->d_stream_bf16, c->d_bias, nullptr, viewenc, lv[l].rgb_sigma, lv[l].raw,
                                                   lv[l].act, lv[l].masks, (int64_t)M, N, cfg.density_bias, cfg.rgb_padding,
-                                                  c->grid_limit, &ri, S(stream)));
+                                                  c->grid_limit, &ri, c->dnoise, cfg.density_noise, S(stream)));
         } else {
             if ((rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, lv[l].t, rays->origins,
                                        rays->directions, rays->radii, lv[l].enc, MIPNERF_PREC_BF16, stream))) return rc;
@@ -808,7 +831,7 @@ size_t mipnerf_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
 }
 
 int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* t_rand, const float* u_rand,
-                    uint32_t flags, int precision, void* workspace, size_t workspace_bytes,
+                    const float* density_randn, uint32_t flags, int precision, void* workspace, size_t workspace_bytes,
                     const mipnerf_level_out* out, void* stream) {
     if (!c || !rays || !out || !workspace || B < 1) return fail(MIPNERF_E_INVALID, "forward: bad argument");
     if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->radii || !rays->near || !rays->far)
@@ -831,7 +854,12 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
     int rc;
     // pos_enc(viewdirs) is level-independent: computed once (the reference recomputes it, mip_nerf.py:220-226)
     if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, precision, stream))) return rc;
+    struct NoiseScope {
+        mipnerf_ctx* c;
+        ~NoiseScope() { c->dnoise = nullptr; }
+    } noise_scope{c};
     for (int lvl = 0; lvl < cfg.num_levels; ++lvl) {
+        c->dnoise = density_randn ? density_randn + (size_t)lvl * M : nullptr;
         const mipnerf_level_out& o = out[lvl];
         if (!o.comp_rgb || !o.distance || !o.acc || !o.weights || !o.t_samples)
             return fail(MIPNERF_E_INVALID, "forward: output pointer of level %d is null", lvl);
@@ -859,7 +887,8 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
             const mip::RayInputs ri = {o.t_samples, rays->origins, rays->directions, rays->radii, cfg.min_deg_point,
                                        cfg.disable_integration};
             HIP_TRY(mip::launch_mlp_bf16(c->d_stream_bf16, c->d_bias, nullptr, viewenc, rgb_sigma, nullptr, (int64_t)M, N,
-                                         cfg.density_bias, cfg.rgb_padding, c->grid_limit, true, &ri, S(stream)));
+                                         cfg.density_bias, cfg.rgb_padding, c->grid_limit, true, &ri, c->dnoise, cfg.density_noise,
+                                         S(stream)));
         } else if ((rc = mipnerf_mlp_forward(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream))) {
             return rc;
         }

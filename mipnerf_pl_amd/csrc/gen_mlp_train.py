@@ -385,7 +385,8 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     e("k_mlp_bf16_trainfwd(const char* __restrict__ stream, const float* __restrict__ bias_tab,")
     e("                    const __bf16* __restrict__ enc, const __bf16* __restrict__ viewenc, float4* __restrict__ rgb_sigma,")
     e("                    float4* __restrict__ raw_out, char* __restrict__ HT, char* __restrict__ masks, int64_t M,")
-    e("                    int num_samples, int ntiles, float density_bias, float rgb_padding, RayIn rin) {")
+    e("                    int num_samples, int ntiles, float density_bias, float rgb_padding, RayIn rin,")
+    e("                    const float* __restrict__ dnoise, float dnoise_scale) {")
     e("    extern __shared__ __attribute__((aligned(16))) char smem[];")
     e("    const int tid = threadIdx.x;")
     e("    const int lane = tid & 63;")
@@ -446,8 +447,9 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     final = list(prog.panels[-1]["post"])
     final += [
         "if (hi == 0 && s < M) {",
+        "    const float noisy_density = dnoise ? raw_density + dnoise_scale * dnoise[s] : raw_density;   // mip_nerf.py:232-233",
         "    rgb_sigma[s] = make_float4(rgb_activation(raw_r, rgb_padding), rgb_activation(raw_g, rgb_padding),",
-        "                               rgb_activation(raw_b, rgb_padding), density_activation(raw_density, density_bias));",
+        "                               rgb_activation(raw_b, rgb_padding), density_activation(noisy_density, density_bias));",
         "    raw_out[s] = make_float4(raw_r, raw_g, raw_b, raw_density);",
         "}",
     ]
@@ -460,7 +462,7 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     e("hipError_t launch_mlp_bf16_trainfwd(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,")
     e("                                    float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,")
     e("                                    float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,")
-    e("                                    hipStream_t st) {")
+    e("                                    const float* dnoise, float dnoise_scale, hipStream_t st) {")
     e("    using namespace trainfwd;")
     e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
     e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
@@ -477,7 +479,7 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     e("    if (rays) rin = RayIn{rays->t, rays->origins, rays->dirs, rays->radii, rays->min_deg, rays->disable_integration};")
     e("#define MIP_LAUNCH(I) hipLaunchKernelGGL((k_mlp_bf16_trainfwd<I>), dim3(grid), dim3(%d), kLdsBytes, st, (const char*)stream_w, \\" % (WAVES * 64))
     e("        bias_tab, (const __bf16*)enc, (const __bf16*)viewenc, (float4*)rgb_sigma, (float4*)raw_out, (char*)HT, (char*)masks, M, \\")
-    e("        num_samples, ntiles, density_bias, rgb_padding, rin)")
+    e("        num_samples, ntiles, density_bias, rgb_padding, rin, dnoise, dnoise_scale)")
     e("    if (rays) MIP_LAUNCH(true); else MIP_LAUNCH(false);")
     e("#undef MIP_LAUNCH")
     e("    return hipGetLastError();")

@@ -38,7 +38,9 @@ hipError_t launch_generate_rays(int64_t n, const float* cams, const int32_t* cam
                                 float* nearp, float* farp, hipStream_t st);
 
 // ---- kernels_train.hip ------------------------------------------------------------------------
-hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, float* out, hipStream_t st);
+// dnoise (nullable): standard-normal draws [M]; the density pre-activation becomes raw + dnoise_scale * dnoise (mip_nerf.py:232-233)
+hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, const float* dnoise,
+                           float dnoise_scale, float* out, hipStream_t st);
 hipError_t launch_volumetric_rendering_bwd(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs,
                                            int white_bkgd, const float* g_rgb, const float* g_dist, const float* g_acc,
                                            const float* g_w, float rgb_padding, float* d_raw, hipStream_t st);
@@ -51,19 +53,30 @@ hipError_t launch_loss_fused(int64_t B, int nlevels, const float* rgb0, const fl
 hipError_t launch_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                             float eps, int step, hipStream_t st);
 
+struct LrSchedule {          // MipLRDecay (utils/lr_schedule.py:5-59) + Adam constants, evaluated on the device
+    double lr_init, lr_final, lr_delay_mult, constant_lr;   // constant_lr > 0: no schedule
+    int64_t max_steps, lr_delay_steps;
+    double beta1, beta2, eps;
+    float grad_scale;
+    int pad;
+};
+hipError_t launch_adam_scheduled(int64_t n, float* p, const float* g, float* m, float* v, const LrSchedule& sc,
+                                 int64_t* step_count, float* hyper, hipStream_t st);
+
 // ---- mlp_bf16_gen.hip (generated) -------------------------------------------------------------
 int mlp_bf16_lds_bytes();
 // rays != nullptr: enc is ignored (may be null) and the encoding is computed in the kernel from `rays`
 hipError_t launch_mlp_bf16(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,
                            float* rgb_sigma, float* raw_out, int64_t M, int num_samples, float density_bias,
-                           float rgb_padding, int grid_limit, bool dma, const RayInputs* rays, hipStream_t st);
+                           float rgb_padding, int grid_limit, bool dma, const RayInputs* rays, const float* dnoise,
+                           float dnoise_scale, hipStream_t st);
 
 // ---- mlp_bf16_trainfwd_gen.hip / mlp_bf16_dgrad_gen.hip (generated by gen_mlp_train.py) -------
 int mlp_trainfwd_lds_bytes();
 hipError_t launch_mlp_bf16_trainfwd(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,
                                     float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,
                                     float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,
-                                    hipStream_t st);
+                                    const float* dnoise, float dnoise_scale, hipStream_t st);
 int mlp_dgrad_lds_bytes();
 hipError_t launch_mlp_bf16_dgrad(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,
                                  int grid_limit, hipStream_t st);
@@ -112,7 +125,8 @@ struct F32Net {
 };
 hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float* bias_tab, const float* enc,
                           const float* viewenc, float* rgb_sigma, float* raw_out, int64_t M, int num_samples,
-                          float density_bias, float rgb_padding, float* save, hipStream_t st);
+                          float density_bias, float rgb_padding, float* save, const float* dnoise, float dnoise_scale,
+                          hipStream_t st);
 
 // ---- kernels_gemm_f32.hip (parity-mode backward) -------------------------------------------------
 hipError_t launch_gemm_f32(bool trans_a, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,

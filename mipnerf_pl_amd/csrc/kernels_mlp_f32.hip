@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256)
 k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __restrict__ bias_tab,
           const float* __restrict__ enc, const float* __restrict__ viewenc, float4* __restrict__ rgb_sigma,
           float4* __restrict__ raw_out, int64_t M, int num_samples, int ntiles_total, float density_bias,
-          float rgb_padding, float* __restrict__ save) {
+          float rgb_padding, float* __restrict__ save, const float* __restrict__ dnoise, float dnoise_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* X = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x;
@@ -113,10 +113,12 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                                 const int64_t s = s0 + nt * 32 + n;
                                 if (s < M) {
                                     const float r0 = acc[rd][nt][0], r1 = acc[rd][nt][1], r2 = acc[rd][nt][2];
+                                    // mip_nerf.py:232-233: raw_density += density_noise * randn, before the activation
+                                    const float nd = dnoise ? dens[nt] + dnoise_scale * dnoise[s] : dens[nt];
                                     rgb_sigma[s] = make_float4(rgb_activation(r0, rgb_padding),
                                                                rgb_activation(r1, rgb_padding),
                                                                rgb_activation(r2, rgb_padding),
-                                                               density_activation(dens[nt], density_bias));
+                                                               density_activation(nd, density_bias));
                                     if (raw_out) raw_out[s] = make_float4(r0, r1, r2, dens[nt]);
                                 }
                             }
@@ -175,7 +177,8 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
 
 hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float* bias_tab, const float* enc,
                           const float* viewenc, float* rgb_sigma, float* raw_out, int64_t M, int num_samples,
-                          float density_bias, float rgb_padding, float* save, hipStream_t st) {
+                          float density_bias, float rgb_padding, float* save, const float* dnoise, float dnoise_scale,
+                          hipStream_t st) {
     const int ntiles = (int)((M + kF32TileSamples - 1) / kF32TileSamples);
     const int lds = kF32TileSamples * net.ldx * (int)sizeof(float);
     static int attr_lds = 0;
@@ -187,7 +190,7 @@ hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float*
     int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_mlp_f32, dim3(grid), dim3(256), lds, st, net, stream_w, bias_tab, enc, viewenc,
-                       (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save);
+                       (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save, dnoise, dnoise_scale);
     return hipGetLastError();
 }
 

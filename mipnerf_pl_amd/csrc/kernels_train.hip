@@ -39,12 +39,14 @@ __device__ __forceinline__ double wexcl_suffix64(double v, int lane) {
 
 // raw [M,4] = (raw_rgb, raw_density) -> (sigmoid*(1+2p)-p, softplus(raw+bias))  (mip_nerf.py:236-238)
 __global__ void __launch_bounds__(256)
-k_activate(int64_t M, const float4* __restrict__ raw, float rgb_padding, float density_bias, float4* __restrict__ out) {
+k_activate(int64_t M, const float4* __restrict__ raw, float rgb_padding, float density_bias, const float* __restrict__ dnoise,
+           float dnoise_scale, float4* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const float4 r = raw[i];
+    const float nd = dnoise ? r.w + dnoise_scale * dnoise[i] : r.w;      // mip_nerf.py:232-233
     out[i] = make_float4(rgb_activation(r.x, rgb_padding), rgb_activation(r.y, rgb_padding),
-                         rgb_activation(r.z, rgb_padding), density_activation(r.w, density_bias));
+                         rgb_activation(r.z, rgb_padding), density_activation(nd, density_bias));
 }
 
 // Backward of volumetric_rendering + activations.
@@ -186,9 +188,10 @@ k_distloss(int64_t B, int N, const float* __restrict__ weights, const float* __r
 
 static inline unsigned gridf(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
-hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, float* out, hipStream_t st) {
+hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, const float* dnoise,
+                           float dnoise_scale, float* out, hipStream_t st) {
     hipLaunchKernelGGL(k_activate, dim3(gridf(M, 256)), dim3(256), 0, st, M, (const float4*)raw, rgb_padding,
-                       density_bias, (float4*)out);
+                       density_bias, dnoise, dnoise_scale, (float4*)out);
     return hipGetLastError();
 }
 
@@ -319,6 +322,56 @@ k_adam_flat(int64_t n, float* __restrict__ p, const float* __restrict__ g, float
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+// ---- device-side MipLRDecay + Adam hyper-parameters (graph-capturable optimiser step) ---------------------------------------
+// One thread: t = ++(*step_count) is the 1-based Adam step; the learning rate is the reference scheduler's value at
+// last_epoch = t - 1 (utils/lr_schedule.py:51-59: the scheduler is stepped AFTER the optimiser, so step t runs with
+// get_lr(t - 1)); fp64 like numpy.  hyper[0..3] = lr, 1 - beta1^t, sqrt(1 - beta2^t), grad_scale.
+__global__ void k_lr_schedule(LrSchedule sc, int64_t* __restrict__ step_count, float* __restrict__ hyper) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t t = *step_count + 1;
+    *step_count = t;
+    const double epoch = (double)(t - 1);
+    double delay_rate = 1.0;
+    if (sc.lr_delay_steps > 0) {
+        double x = epoch / (double)sc.lr_delay_steps;
+        x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
+        delay_rate = sc.lr_delay_mult + (1.0 - sc.lr_delay_mult) * sin(0.5 * 3.141592653589793 * x);
+    }
+    double tt = epoch / (double)sc.max_steps;
+    tt = tt < 0.0 ? 0.0 : (tt > 1.0 ? 1.0 : tt);
+    const double log_lerp = exp(log(sc.lr_init) * (1.0 - tt) + log(sc.lr_final) * tt);
+    const double lr = sc.constant_lr > 0.0 ? sc.constant_lr : delay_rate * log_lerp;
+    hyper[0] = (float)lr;
+    hyper[1] = (float)(1.0 - pow(sc.beta1, (double)t));
+    hyper[2] = (float)sqrt(1.0 - pow(sc.beta2, (double)t));
+    hyper[3] = sc.grad_scale;
+}
+
+// k_adam_flat with lr / bias corrections read from device memory and the gradient pre-scaled (1 / world_size of the
+// data-parallel SUM all-reduce: the mean is taken here instead of in a separate div_ kernel)
+__global__ void __launch_bounds__(256)
+k_adam_flat_dev(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                const float* __restrict__ hyper, float beta1, float beta2, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float lr = hyper[0], bc1 = hyper[1], bc2_sqrt = hyper[2], gs = hyper[3];
+    const float gi = gs == 1.0f ? g[i] : g[i] * gs;
+    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+
+hipError_t launch_adam_scheduled(int64_t n, float* p, const float* g, float* m, float* v, const LrSchedule& sc,
+                                 int64_t* step_count, float* hyper, hipStream_t st) {
+    hipLaunchKernelGGL(k_lr_schedule, dim3(1), dim3(64), 0, st, sc, step_count, hyper);
+    hipLaunchKernelGGL(k_adam_flat_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, hyper,
+                       (float)sc.beta1, (float)sc.beta2, (float)sc.eps);
+    return hipGetLastError();
 }
 
 hipError_t launch_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,

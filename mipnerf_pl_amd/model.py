@@ -234,7 +234,7 @@ class MLP(torch.nn.Module):
                 net_width_condition=a["net_width_condition"], skip_index=a["skip_index"],
                 num_rgb_channels=a["num_rgb_channels"], num_density_channels=a["num_density_channels"],
                 resample_padding=e.get("resample_padding", 0.01), density_bias=e.get("density_bias", -1.0),
-                rgb_padding=e.get("rgb_padding", 0.001))
+                rgb_padding=e.get("rgb_padding", 0.001), density_noise=e.get("density_noise", 0.0))
             self._ctx = NativeContext(cfg, device)
         self._ctx.sync_params(self.ordered_params())
         return self._ctx
@@ -324,12 +324,24 @@ class MipNerf(torch.nn.Module):
                                    max_deg_point=max_deg_point, deg_view=deg_view, use_viewdirs=int(use_viewdirs),
                                    disparity=int(disparity), disable_integration=int(disable_integration),
                                    resample_padding=resample_padding, density_bias=density_bias,
-                                   rgb_padding=rgb_padding)
+                                   rgb_padding=rgb_padding, density_noise=float(density_noise))
 
-    def forward(self, rays: Rays, randomized: bool, white_bkgd: bool, t_rand=None, u_rand=None):
+    def _density_randn(self, randomized, B, dev, density_randn):
+        """mip_nerf.py:232-233: standard-normal draws [num_levels, B, N] when randomized and density_noise > 0 (the
+        reference draws them on the CPU; here torch's device generator), else None."""
+        if not (randomized and self.density_noise > 0):
+            return None
+        if density_randn is None:
+            return torch.randn(self.num_levels, B, self.num_samples, device=dev)
+        z = ops._f32c(density_randn, "density_randn")
+        if z.numel() != self.num_levels * B * self.num_samples:
+            raise ValueError("density_randn must have num_levels x B x num_samples elements")
+        return z
+
+    def forward(self, rays: Rays, randomized: bool, white_bkgd: bool, t_rand=None, u_rand=None, density_randn=None):
         """rays: Rays of [B,k] float32 HIP tensors.  Returns [(comp_rgb [B,3], distance [B], acc [B],
-        weights [B,N], t_samples [B,N+1])] * num_levels (mip_nerf.py:246).  `t_rand` / `u_rand`
-        optionally inject the uniform noise of the randomized path (tests)."""
+        weights [B,N], t_samples [B,N+1])] * num_levels (mip_nerf.py:246).  `t_rand` / `u_rand` / `density_randn`
+        optionally inject the random draws of the randomized path (tests)."""
         o = rays.origins
         if not o.is_cuda:
             raise RuntimeError("MipNerf.forward needs rays on a HIP device; there is no CPU fallback "
@@ -337,12 +349,12 @@ class MipNerf(torch.nn.Module):
         with torch.cuda.device(o.device):      # native launches go to the CURRENT device's stream
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 from .autograd import mipnerf_forward_train
-                return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand)
-            return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand)
+                return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
+            return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
 
     def train_step_native(self, rays: Rays, gt_rgb, randomized: bool, white_bkgd: bool, coarse_loss_mult: float = 0.1,
                           distloss_mult: float = 0.01, disable_multiscale_loss: bool = False, t_rand=None, u_rand=None,
-                          return_outputs: bool = False):
+                          return_outputs: bool = False, density_randn=None):
         """forward + loss (nerf_system.py:99-111) + backward of the whole hot path in ONE native call
         (mipnerf_train_step): no autograd graph.  The gradient of the loss lands in the parameters' .grad (zero-copy
         when the MLP is in flat mode, `mlp.flatten_parameters()`).  Returns (scalars [6] tensor = loss, mse_c, mse_f,
@@ -361,8 +373,7 @@ class MipNerf(torch.nn.Module):
         if randomized:
             t_rand = torch.rand(B, N + 1, device=dev) if t_rand is None else ops._f32c(t_rand, "t_rand")
             u_rand = torch.rand(B, N + 1, device=dev) if u_rand is None else ops._f32c(u_rand, "u_rand")
-        if randomized and self.density_noise > 0:
-            raise NotImplementedError("density_noise > 0 is not implemented (reference default 0)")
+        dz = self._density_randn(randomized, B, dev, density_randn)
         need = int(L.lib().mipnerf_train_workspace_bytes(ctx.handle, B))
         ws = ctx.scratch("train_step", need)
         dropped = all(p.grad is None for p in mlp.ordered_params())
@@ -387,7 +398,8 @@ class MipNerf(torch.nn.Module):
                 ret.append(tens)
         flags = L.FLAG_WHITE_BKGD if white_bkgd else 0
         L.check(L.lib().mipnerf_train_step(ctx.handle, B, C.byref(rp), gt.data_ptr(), t_rand.data_ptr() if randomized else None,
-                                           u_rand.data_ptr() if randomized else None, flags, float(coarse_loss_mult),
+                                           u_rand.data_ptr() if randomized else None, None if dz is None else dz.data_ptr(),
+                                           flags, float(coarse_loss_mult),
                                            float(distloss_mult), int(bool(disable_multiscale_loss)), ws.data_ptr(), ws.numel(),
                                            grad.data_ptr(), accumulate, scalars.data_ptr(), outs, ops._stream()), "train_step")
         if flat_mode:
@@ -400,7 +412,7 @@ class MipNerf(torch.nn.Module):
                 off += p.numel()
         return scalars, ret
 
-    def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None):
+    def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None, density_randn=None):
         dev = rays.origins.device
         B, N = rays.origins.shape[0], self.num_samples
         ctx = self.mlp.native(dev)
@@ -423,13 +435,10 @@ class MipNerf(torch.nn.Module):
             ret.append((comp_rgb, distance, acc, weights, t_samples))
         ws = ctx.workspace(B)
         flags = L.FLAG_WHITE_BKGD if white_bkgd else 0
+        dz = self._density_randn(randomized, B, dev, density_randn)     # mip_nerf.py:232-233
         L.check(L.lib().mipnerf_forward(ctx.handle, B, C.byref(rp), t_rand.data_ptr() if randomized else None,
-                                        u_rand.data_ptr() if randomized else None, flags, self.precision,
-                                        ws.data_ptr(), ws.numel(), outs, ops._stream()), "mipnerf_forward")
-        # mip_nerf.py:232-233 density noise is a no-op at the shipped config (density_noise = 0)
-        if randomized and self.density_noise > 0:
-            raise NotImplementedError("density_noise > 0 is not implemented (reference default 0; upstream code "
-                                      "draws it on the CPU and would fail on GPU)")
+                                        u_rand.data_ptr() if randomized else None, None if dz is None else dz.data_ptr(),
+                                        flags, self.precision, ws.data_ptr(), ws.numel(), outs, ops._stream()), "mipnerf_forward")
         return ret
 
 

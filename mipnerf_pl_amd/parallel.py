@@ -35,13 +35,25 @@ class FlatGradAllReduce:
         self.flat = None
         self.mlp = mlp      # optional: an MLP in flat mode (MLP.flatten_parameters) -> its gradient buffer is reduced in place
 
-    def __call__(self, group=None) -> None:
+    def start(self, group=None):
+        """Flat mode only: issue the ONE all-reduce (SUM) of the gradient buffer asynchronously and return the work handle
+        (None at world 1).  c10d orders it behind the kernels already queued on the current stream and runs it on its own
+        stream; the caller overlaps whatever does not need the gradient (next batch's rays / random draws), then calls
+        `handle.wait()` and lets the optimiser take the mean (`FlatAdam.grad_scale = 1 / world`) -- no div_ kernel."""
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return None
+        if self.mlp is None or not self.mlp.grads_are_flat():
+            raise RuntimeError("FlatGradAllReduce.start needs an MLP in flat mode (MLP.flatten_parameters)")
+        return dist.all_reduce(self.mlp._flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+    def __call__(self, group=None, mean: bool = True) -> None:
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
         if self.mlp is not None and self.mlp.grads_are_flat():
             g = self.mlp._flat_grad
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-            g.div_(dist.get_world_size(group))
+            if mean:
+                g.div_(dist.get_world_size(group))
             return
         p0 = self.params[0]
         if self.flat is None or self.flat.device != p0.device:

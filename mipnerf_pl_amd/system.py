@@ -128,6 +128,18 @@ class MipNeRFSystem(_Base):
                                    batch_type=self.hparams['val.batch_type'])
 
     def configure_optimizers(self):   # nerf_system.py:70-76
+        hp = self.hparams
+        sched = dict(lr_init=hp['optimizer.lr_init'], lr_final=hp['optimizer.lr_final'], max_steps=hp['optimizer.max_steps'],
+                     lr_delay_steps=hp['optimizer.lr_delay_steps'], lr_delay_mult=hp['optimizer.lr_delay_mult'])
+        if getattr(self, "fused_adam", False) and getattr(self, "device_lr_schedule", True):
+            # same update rule + same schedule, evaluated on the device: one tiny kernel (step count, lr, bias corrections)
+            # + one Adam kernel over the flat parameter buffer; nothing per-step comes from the host (graph-capturable)
+            from .lr_schedule import DeviceMipLRDecay
+            from .optim import FlatAdam
+            optimizer = FlatAdam(self.mip_nerf.mlp, lr=hp['optimizer.lr_init'], schedule=sched)
+            scheduler = DeviceMipLRDecay(optimizer, **sched)
+            self._optimizer_for_log = optimizer
+            return [optimizer], [{'scheduler': scheduler, 'interval': 'step'}]
         if getattr(self, "fused_adam", False):
             # same update rule as torch.optim.Adam below, one HIP kernel over the flat parameter buffer
             from .optim import FlatAdam
@@ -137,6 +149,7 @@ class MipNeRFSystem(_Base):
         scheduler = MipLRDecay(optimizer, self.hparams['optimizer.lr_init'], self.hparams['optimizer.lr_final'],
                                self.hparams['optimizer.max_steps'], self.hparams['optimizer.lr_delay_steps'],
                                self.hparams['optimizer.lr_delay_mult'])
+        self._optimizer_for_log = optimizer
         return [optimizer], [{'scheduler': scheduler, 'interval': 'step'}]
 
     def train_dataloader(self):   # nerf_system.py:78-83
@@ -171,7 +184,15 @@ class MipNeRFSystem(_Base):
             psnr_fine = calc_psnr(ret[-1][0], rgbs[..., :3])
         self.log('train/loss', loss)
         self.log('train/psnr', psnr_fine, prog_bar=True)
+        self._log_lr()
         return loss
+
+    def _log_lr(self):
+        """nerf_system.py:117 `self.log('lr', ...)`: the learning rate of the first param group of the configured optimiser
+        (a host float; with the device-side schedule it is the host mirror, no synchronisation)."""
+        opt = getattr(self, "_optimizer_for_log", None)
+        if opt is not None:
+            self.log('lr', opt.param_groups[0]['lr'])
 
     def training_step_native(self, batch, batch_nb=0):
         """training_step + loss.backward() in one native call (no autograd graph; bf16): the gradients are in
@@ -182,6 +203,7 @@ class MipNeRFSystem(_Base):
             disable_multiscale_loss=self.hparams['loss.disable_multiscale_loss'])
         self.log('train/loss', scalars[0])
         self.log('train/psnr', scalars[5], prog_bar=True)
+        self._log_lr()
         return scalars[0]
 
     def validation_step(self, batch, batch_nb):   # nerf_system.py:123-142 (TensorBoard images left to the caller)

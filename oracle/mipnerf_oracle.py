@@ -340,7 +340,8 @@ def mipnerf_forward(params, rays, randomized, white_bkgd, num_samples=128, num_l
                     disparity=False, ray_shape="cone", min_deg_point=0, max_deg_point=16,
                     deg_view=4, density_noise=0., density_bias=-1., rgb_padding=0.001,
                     disable_integration=False, skip_index=4, net_depth=8,
-                    net_depth_condition=1, t_rand=None, u_rand=None, return_stages=False):
+                    net_depth_condition=1, t_rand=None, u_rand=None, return_stages=False,
+                    density_randn=None):
     """models/mip_nerf.py:172-248.  Returns the list of per-level 5-tuples
     (comp_rgb, distance, acc, weights, t_samples)."""
     ret = []
@@ -365,7 +366,13 @@ def mipnerf_forward(params, rays, randomized, white_bkgd, num_samples=128, num_l
         else:
             raw_rgb, raw_density = mlp_forward(params, samples_enc, None, skip_index,
                                                net_depth, net_depth_condition)
-        # mip_nerf.py:232-233 density noise: never active at the shipped config (0.)
+        # mip_nerf.py:232-233: raw_density += density_noise * randn (only when randomized and density_noise > 0);
+        # density_randn [num_levels, B, N] carries the standard-normal draws (the reference draws them with torch.randn)
+        if randomized and density_noise > 0:
+            if density_randn is None:
+                raise ValueError("density_noise > 0 needs the standard-normal draws `density_randn`")
+            z = _f32(density_randn[i_level]).reshape(raw_density.shape)
+            raw_density = (raw_density + F32(density_noise) * z).astype(F32)
         rgb = sigmoid(raw_rgb)
         rgb = (rgb * F32(1 + 2 * rgb_padding) - F32(rgb_padding)).astype(F32)
         density = softplus(raw_density + F32(density_bias))

@@ -115,6 +115,37 @@ def randomized_case(name, batch, num_samples, param_seed, gain, ray_seed, torch_
     print(f"wrote {name}.npz")
 
 
+def noise_case(name, batch, num_samples, param_seed, gain, ray_seed, torch_seed, density_noise):
+    """randomized forward WITH density noise (mip_nerf.py:232-233, density_noise > 0).  The reference's draws per forward,
+    in order: torch.rand [B,N+1] (mip.py:159), torch.randn [B,N,1] (level 0), uniform_ [B,N+1] (mip.py:201), torch.randn
+    [B,N,1] (level 1) -- replayed here from the same seed and stored."""
+    rays = orc.synthetic_rays(batch, seed=ray_seed)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples, density_noise=density_noise)
+    load_params(model, params)
+    with torch.no_grad():
+        torch.manual_seed(torch_seed)
+        ret = model(to_ref_rays(rays), True, True)
+        torch.manual_seed(torch_seed)
+        t_rand = torch.rand(batch, num_samples + 1).numpy()
+        z0 = torch.randn(batch, num_samples, 1).numpy()
+        u_rand = torch.empty(batch, num_samples + 1).uniform_(0, 1).numpy()
+        z1 = torch.randn(batch, num_samples, 1).numpy()
+    dz = np.stack([z0[..., 0], z1[..., 0]])
+    oret = orc.mipnerf_forward(params, rays, True, True, num_samples=num_samples, t_rand=t_rand, u_rand=u_rand,
+                               density_noise=density_noise, density_randn=dz)
+    check_oracle(name, ret, oret, 2e-4)
+    out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain, ray_seed=ray_seed,
+               t_rand=t_rand, u_rand=u_rand, density_randn=dz, density_noise=np.float32(density_noise))
+    out.update(ret_dict(ret, prefix="wb1_"))
+    # sanity: the noise must matter (otherwise the golden pins nothing)
+    oret0 = orc.mipnerf_forward(params, rays, True, True, num_samples=num_samples, t_rand=t_rand, u_rand=u_rand)
+    moved = maxdiff(oret0[1][0], oret[1][0])
+    assert moved > 1e-3, moved
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz (noise moves the fine rgb by up to {moved:.3f})")
+
+
 def stage_case(name, batch, num_samples, param_seed, gain, ray_seed):
     """Per-function goldens: every free function of models/mip.py on the hot path,
     called directly on the reference."""
@@ -333,7 +364,7 @@ TRAJ = dict(batch=256, num_samples=32, steps=300, nbatches=300, lr_init=2e-3, lr
             lr_delay_steps=30, lr_delay_mult=0.01, heldout=1024, param_seed=11, ray_seed=1000, rng_seed=4321)
 
 
-def trajectory_case(name, randomized):
+def trajectory_case(name, randomized, threads=None, save=True):
     """K-step TRAINING trajectory of the unmodified reference: MipNerf + the loss of nerf_system.py:99-111 +
     torch.optim.Adam (nerf_system.py:71-72) + the reference's MipLRDecay (utils/lr_schedule.py:5-59), on fixed seeded
     batches.  Stored: loss / lr per step, held-out render PSNR, parameter norms at the end.  The randomized variant seeds
@@ -341,6 +372,8 @@ def trajectory_case(name, randomized):
     (mip.py:159 torch.rand, mip.py:201 uniform_) on the CPU and inject them."""
     from utils.lr_schedule import MipLRDecay as RefMipLRDecay
     T = TRAJ
+    if threads is not None:
+        torch.set_num_threads(threads)
     params = orc.make_params(seed=T["param_seed"], density_gain=1.0)
     model = RefMipNerf(num_samples=T["num_samples"])
     load_params(model, params)
@@ -379,12 +412,29 @@ def trajectory_case(name, randomized):
                heldout_rgb=hret[-1][0].numpy(), heldout_distance=hret[-1][1].numpy())
     for k, p in model.mlp.named_parameters():
         out["pnorm_" + k] = np.float64(p.detach().double().norm().item())
+    if not save:
+        return out
+    # How far do two LEGITIMATE runs of the unmodified reference drift apart?  Same code, same seeds, 1 CPU thread instead
+    # of all: only the summation order inside the GEMMs changes.  Training is chaotic (Adam divides by sqrt(v)), so this
+    # self-divergence -- not fp32 epsilon -- is the resolution at which a loss CURVE can be compared after hundreds of steps.
+    alt = trajectory_case(name, randomized, threads=1, save=False)
+    torch.set_num_threads(os.cpu_count())
+    rel = np.abs(alt["loss"] - out["loss"]) / np.abs(out["loss"])
+    out["self_rel_first20"] = np.float64(rel[:20].max())
+    out["self_rel_max"] = np.float64(rel.max())
+    out["self_heldout_psnr_diff"] = np.float64(abs(float(alt["heldout_psnr"]) - hpsnr))
+    out["self_loss_alt"] = alt["loss"]
+    print(f"  reference vs itself (1 thread vs {os.cpu_count()}): loss rel diff first 20 steps {rel[:20].max():.2e}, max {rel.max():.2e}, "
+          f"held-out PSNR diff {out['self_heldout_psnr_diff']:.4f} dB")
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"wrote {name}.npz  loss {losses[0]:.5f} -> {losses[-1]:.5f}, held-out PSNR {hpsnr:.3f} dB, lr {lrs[0]:.2e} .. {max(lrs):.2e} .. {lrs[-1]:.2e}")
 
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
+    if "--only-noise" in sys.argv:          # round 2: density_noise > 0
+        noise_case("fwd_noise_48x64_trained", 48, 64, param_seed=9, gain=4.0, ray_seed=9, torch_seed=77, density_noise=1.0)
+        sys.exit(0)
     if "--only-fullsize" in sys.argv:       # round 2: the BASELINE configurations at full size (same inputs as bench.py)
         fullsize_case("full_c2_4096x128", 4096, 128, param_seed=0, gain=40.0, ray_seed=100)
         fullsize_case("full_c4_8192x256", 8192, 256, param_seed=0, gain=40.0, ray_seed=100, unbounded=True)

@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from mipnerf_pl_amd import MipNerf, _lib as L  # noqa: E402
-from oracle import mipnerf_oracle as orc  # noqa: E402  (synthetic weights only)
+import synthetic_inputs as orc  # noqa: E402  (synthetic weights)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=10)

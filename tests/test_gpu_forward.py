@@ -144,3 +144,41 @@ def test_fused_ipe_equals_separate_kernel(G, case):
     for la, lb in zip(outs[1], outs[0]):
         for a, b in zip(la, lb):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_density_noise_matches_reference(G, precision):
+    """mip_nerf.py:232-233 (density_noise > 0, randomized): raw_density += density_noise * randn before the softplus,
+    with the reference's own draws replayed (golden fwd_noise_48x64_trained).  Checked on all three routes that apply
+    the activation: the inference kernels, the autograd training path (mipnerf_activate) and the native training step."""
+    g = G.load_golden("fwd_noise_48x64_trained")
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    N = int(g["num_samples"])
+    model = G.make_model(params, N, precision, density_noise=float(g["density_noise"]))
+    rays = G.to_dev(G.rays_of(g))
+    tr, ur, dz = (torch.from_numpy(g[k]).to(G.DEV) for k in ("t_rand", "u_rand", "density_randn"))
+    tol = G.TOL_FP32 if precision == "fp32" else G.TOL_BF16
+    routes = {}
+    with torch.no_grad():
+        routes["inference"] = model(rays, True, True, t_rand=tr, u_rand=ur, density_randn=dz)
+        plain = model(rays, True, True, t_rand=tr, u_rand=ur, density_randn=torch.zeros_like(dz))
+        det = model(rays, False, True)
+    routes["autograd"] = model(rays, True, True, t_rand=tr, u_rand=ur, density_randn=dz)     # grad enabled: training path
+    if precision == "bf16":
+        gt = torch.rand(rays.origins.shape[0], 3, device=G.DEV)
+        _, outs = model.train_step_native(rays, gt, True, True, t_rand=tr, u_rand=ur, density_randn=dz, return_outputs=True)
+        routes["native_train_step"] = outs
+    for route, ret in routes.items():
+        errs = {}
+        for lvl in range(2):
+            for nm, val in zip(G.NAMES, ret[lvl]):
+                errs[f"l{lvl}_{nm}"] = G.maxdiff(val.detach(), g[f"wb1_l{lvl}_{nm}"])
+        G.record(f"density_noise {route} {precision}", **errs)
+        for k, e in errs.items():
+            assert e <= tol[k.split("_", 1)[1]], f"{route} {precision} {k}: {e}"
+    # the noise is really applied (vs zero draws) and never when randomized=False
+    assert G.maxdiff(plain[1][0], routes["inference"][1][0]) > 1e-3
+    model0 = G.make_model(params, N, precision)
+    with torch.no_grad():
+        det0 = model0(rays, False, True)
+    assert G.maxdiff(det[1][0], det0[1][0]) == 0.0

@@ -119,7 +119,7 @@ def _traj_run(G, g, precision, fused, native):
             loss.backward()
         opt.step()
         sch.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     held = syn.synthetic_rays(int(g["heldout"]), seed=int(g["ray_seed"]) + 999)
     with torch.no_grad():
         hret = model(G.to_dev(held), False, True)
@@ -130,19 +130,22 @@ def _traj_run(G, g, precision, fused, native):
 
 @pytest.mark.parametrize("name", ["traj_256x32_det", "traj_256x32_rand"])
 def test_training_trajectory_fp32_reproduces_reference(G, name):
-    """fp32 parity mode + torch.optim.Adam + MipLRDecay: the reference's loss curve, step by step.  Tolerance: rounding
-    differences (GEMM summation order) are amplified by Adam's g/sqrt(v) normalisation over hundreds of steps, so the
-    bound is 1e-4 relative over the first 20 steps (pure arithmetic parity) and 2 % of the loss afterwards; the held-out
-    PSNR must agree within 0.1 dB and the LR schedule exactly."""
+    """fp32 parity mode + torch.optim.Adam + MipLRDecay: the reference's loss curve, step by step.  Tolerance: training is
+    chaotic (Adam divides by sqrt(v)), so fp32 round-off grows over hundreds of steps -- the golden stores how far the
+    UNMODIFIED reference drifts from ITSELF when only its GEMM summation order changes (1 CPU thread vs all:
+    self_rel_first20 ~3e-5, self_rel_max 1.3e-2 .. 4.3e-2, held-out PSNR 0.003 .. 0.011 dB).  Bounds: 1e-4 relative over
+    the first 20 steps (pure arithmetic parity), 3 x the reference's self-divergence afterwards, held-out PSNR within
+    0.1 dB, final parameter norms within 0.5 %, and the LR schedule exactly."""
     g = G.load_golden(name)
     losses, lrs, psnr, hrgb, model = _traj_run(G, g, "fp32", fused=False, native=False)
     ref = g["loss"]
     rel = np.abs(losses - ref) / np.abs(ref)
     G.record(f"trajectory {name} fp32", rel_first20=rel[:20].max(), rel_max=rel.max(), rel_last=rel[-1],
+             ref_self_rel_first20=float(g["self_rel_first20"]), ref_self_rel_max=float(g["self_rel_max"]),
              heldout_psnr=psnr, ref_heldout_psnr=float(g["heldout_psnr"]), loss_last=losses[-1], ref_loss_last=ref[-1])
     assert np.allclose(lrs, g["lr"], rtol=1e-12, atol=0)
     assert rel[:20].max() <= 1e-4, rel[:20]
-    assert rel.max() <= 2e-2, (rel.max(), int(rel.argmax()))
+    assert rel.max() <= 3.0 * max(float(g["self_rel_max"]), 1e-2), (rel.max(), int(rel.argmax()), float(g["self_rel_max"]))
     assert abs(psnr - float(g["heldout_psnr"])) <= 0.1
     for k, p in model.mlp.named_parameters():
         want = float(g["pnorm_" + k])

@@ -480,3 +480,91 @@ def test_native_train_step_ragged_shapes_randomized(G, B, N, white):
     eg = G.maxdiff(g0, g1) / float(g0.abs().max())
     G.record(f"native_train_step_ragged B={B} N={N}", loss_autograd=l0, loss_native=l1, grad_rel=eg)
     assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)) and eg <= 2e-5
+
+
+def test_device_lr_schedule_equals_host_miplrdecay(G):
+    """FlatAdam(schedule=...) evaluates MipLRDecay (utils/lr_schedule.py:51-59) and Adam's bias corrections
+    on the device.  Against torch.optim.Adam + the host MipLRDecay on the same gradients: parameters agree to fp32
+    round-off, and the learning rate the device used equals the host schedule at every step."""
+    from mipnerf_pl_amd import MipNerf
+    from mipnerf_pl_amd.lr_schedule import MipLRDecay, mip_lr
+    from mipnerf_pl_amd.optim import FlatAdam
+    sched = dict(lr_init=2e-3, lr_final=1e-4, max_steps=40, lr_delay_steps=10, lr_delay_mult=0.01)
+    torch.manual_seed(0)
+    m1, m2 = MipNerf(num_samples=8).to(DEV), MipNerf(num_samples=8).to(DEV)
+    m2.load_state_dict(m1.state_dict())
+    o1 = FlatAdam(m1.mlp, lr=sched["lr_init"], schedule=sched)
+    o2 = torch.optim.Adam(m2.parameters(), lr=sched["lr_init"])
+    s2 = MipLRDecay(o2, **sched)
+    n = m1.mlp._flat_grad.numel()
+    for step in range(45):
+        g = torch.randn(n, device=DEV) * (0.1 if step % 3 else 1e-4)
+        m1.mlp._flat_grad.copy_(g)
+        m1.mlp._flat_grad_valid = True
+        off = 0
+        for p in m2.parameters():
+            p.grad = g[off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+        want_lr = o2.param_groups[0]["lr"]
+        o1.step()
+        o2.step()
+        s2.step()
+        assert abs(o1.last_lr() - want_lr) <= 2e-7 * want_lr, (step, o1.last_lr(), want_lr)
+        assert abs(want_lr - mip_lr(step, **sched)) <= 1e-18
+    assert o1.steps == 45 and int(o1._dev_step.item()) == 45
+    a = torch.cat([p.detach().reshape(-1) for p in m1.parameters()])
+    b = torch.cat([p.detach().reshape(-1) for p in m2.parameters()])
+    G.record("device_lr_adam", max_abs=G.maxdiff(a, b))
+    assert G.maxdiff(a, b) <= 5e-6
+
+
+def test_graphed_train_step_equals_eager(G):
+    """The whole optimisation step (forward + loss + backward + scheduled Adam + weight re-pack) replayed from one
+    captured hipGraph must equal the same launches issued eagerly, bit for bit, and the plain hook loop
+    (training_step_native + FlatAdam.step + scheduler.step) to round-off."""
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    from mipnerf_pl_amd.train_graph import GraphedTrainStep
+    g = G.load_golden("train_64x64_trained")
+    rays, gt = G.to_dev(G.rays_of(g)), torch.from_numpy(g["gt"]).to(DEV)
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    B = rays.origins.shape[0]
+
+    def make():
+        hp = dict(DEFAULT_HPARAMS)
+        hp.update({'nerf.num_samples': 64, 'train.randomized': False, 'optimizer.lr_init': 1e-3, 'optimizer.lr_final': 1e-5,
+                   'optimizer.max_steps': 20, 'optimizer.lr_delay_steps': 4})
+        system = MipNeRFSystem(hp, precision="bf16")
+        system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        system = system.to(DEV)
+        system.fused_adam = True
+        (opt,), (sch,) = system.configure_optimizers()
+        return system, opt, sch["scheduler"]
+    res = {}
+    for mode in ("graph", "eager", "hooks"):
+        system, opt, sch = make()
+        losses = []
+        if mode == "hooks":
+            for it in range(5):
+                opt.zero_grad()
+                losses.append(float(system.training_step_native((rays, gt), it)))
+                opt.step()
+                sch.step()
+        else:
+            step = GraphedTrainStep(system, opt, B, torch.device(DEV), use_graph=(mode == "graph"))
+            for dst, src in zip(step.rays, rays):
+                dst.copy_(src)
+            step.gt.copy_(gt)
+            for it in range(5):
+                losses.append(float(step()[0]))
+                sch.step()
+            assert opt.steps == 5 and int(opt._dev_step.item()) == 5
+        with torch.no_grad():
+            out = system.mip_nerf(rays, False, True)[1][0].clone()      # uses the re-packed weight streams
+        res[mode] = (losses, torch.cat([p.detach().reshape(-1) for p in system.mip_nerf.parameters()]).clone(), out)
+    assert res["graph"][0] == res["eager"][0], (res["graph"][0], res["eager"][0])
+    assert torch.equal(res["graph"][1], res["eager"][1]) and torch.equal(res["graph"][2], res["eager"][2])
+    assert res["graph"][0][-1] < res["graph"][0][0]           # it trains
+    for a, b in zip(res["graph"][0], res["hooks"][0]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b))
+    G.record("graphed_train_step", hooks_vs_graph_params=G.maxdiff(res["graph"][1], res["hooks"][1]))
+    assert G.maxdiff(res["graph"][1], res["hooks"][1]) <= 1e-6

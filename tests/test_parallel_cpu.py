@@ -47,6 +47,12 @@ def _worker(rank, world, port, out):
         want = torch.arange(mlp._flat_grad.numel(), dtype=torch.float32) * 1.5
         ok = ok and mlp._flat_grad.data_ptr() == ptr and torch.allclose(mlp._flat_grad, want)
         ok = ok and torch.allclose(model.mlp.color_layer.bias.grad, want[-3:])     # .grad are views of the reduced buffer
+        # asynchronous form (what GraphedTrainStep / bench use): SUM only, the mean is folded into the Adam kernel
+        mlp._flat_grad.copy_(torch.arange(mlp._flat_grad.numel(), dtype=torch.float32) * (rank + 1))
+        work = FlatGradAllReduce(list(model.parameters()), mlp=mlp).start()
+        ok = ok and work is not None
+        work.wait()
+        ok = ok and mlp._flat_grad.data_ptr() == ptr and torch.allclose(mlp._flat_grad, want * 2)
         # rendering: shard 11 rays, "render" = 2*origin, gather
         n = 11
         rays = Rays(*[torch.arange(n * k, dtype=torch.float32).reshape(n, k) for k in (3, 3, 3, 1, 1, 1, 1)])
