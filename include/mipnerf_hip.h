@@ -123,6 +123,11 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out);
 int mipnerf_destroy(mipnerf_ctx* ctx);
 /* Writes the MLP shape the library was compiled for into *cfg (other fields defaulted). */
 int mipnerf_compiled_arch(mipnerf_config* cfg);
+/* The library carries tables (+ a bf16 inference kernel) for a fixed list of MLP shapes ("variants", csrc/gen_mlp_bf16.py
+ * VARIANTS); variant 0 is the shipped shape and the only one with bf16 TRAINING kernels, the others train in fp32.
+ * mipnerf_create picks the variant that matches cfg or fails with MIPNERF_E_UNSUPPORTED listing them. */
+int mipnerf_num_variants(void);
+int mipnerf_variant_arch(int variant, mipnerf_config* cfg, int* has_bf16_training);
 
 /* (Re)pack the fp32 master parameters into the MFMA operand streams (bf16 fragment stream,
  * fp32 fragment stream, bias tables).  `params` is a HOST array of
@@ -322,6 +327,7 @@ int mipnerf_mlp_launch_stats(mipnerf_ctx* ctx, double* total_ms, int64_t* launch
  * pack table, 1 = bias table, 2 = fp32 stream pack table (flat parameter indices, -1 = 0),
  * 3 = dgrad (W^T) stream pack table, 4 = wgrad partial -> parameter index table, 5 = wgrad job table.
  * Return the element count; copy only when cap is large enough. */
+int64_t mipnerf_debug_table_variant(int variant, int which, int32_t* out_host, int64_t cap);   /* which: 0 bf16 pack, 1 bias, 2 fp32 pack */
 int64_t mipnerf_debug_table(int which, int32_t* out_host, int64_t cap);
 int64_t mipnerf_debug_f32net(int32_t* out_host, int64_t cap);
 

@@ -50,6 +50,8 @@ SIGNATURES = {
     "mipnerf_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "mipnerf_destroy": (C.c_int, [_P]),
     "mipnerf_compiled_arch": (C.c_int, [C.POINTER(Config)]),
+    "mipnerf_num_variants": (C.c_int, []),
+    "mipnerf_variant_arch": (C.c_int, [C.c_int, C.POINTER(Config), C.POINTER(C.c_int)]),
     "mipnerf_set_params": (C.c_int, [_P, C.POINTER(_P), _P]),
     "mipnerf_workspace_bytes": (_SZ, [_P, _I64]),
     "mipnerf_forward": (C.c_int, [_P, _I64, C.POINTER(RaysPtrs), _P, _P, _P, C.c_uint32, C.c_int, _P, _SZ,
@@ -88,6 +90,7 @@ SIGNATURES = {
     "mipnerf_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
     "mipnerf_mlp_launch_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "mipnerf_debug_table": (_I64, [C.c_int, _P, _I64]),
+    "mipnerf_debug_table_variant": (_I64, [C.c_int, C.c_int, _P, _I64]),
     "mipnerf_debug_f32net": (_I64, [_P, _I64]),
 }
 

@@ -38,8 +38,7 @@ int fail(int code, const char* fmt, ...) {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-using mip::plan::kOps;
-using mip::plan::kNumOps;
+using mip::plan::PlanDesc;
 
 // ---- plan expansion (mirror of mlp_plan.Plan.pack_table / bias_table / pack_table_f32) ----------
 struct Tables {
@@ -47,6 +46,7 @@ struct Tables {
     std::vector<int32_t> bias;        // [kNumTiles*32]
     std::vector<int32_t> pack_f32;    // [kNumChunks*512]
     std::vector<int> tensor_off;      // flat offset of each parameter tensor
+    int total_params = 0;
     mip::F32Net net;
 };
 
@@ -56,14 +56,17 @@ int kmap(int kind, int ksl, int hi, int j) {
     return 32 * t + 8 * (2 * u + (j >> 2)) + 4 * hi + (j & 3);
 }
 
-void build_tables(Tables& T) {
+void build_tables(Tables& T, const PlanDesc& P) {
     using namespace mip::plan;
-    T.tensor_off.resize(kNumParamTensors);
+    const OpDesc* kOps = P.ops;
+    const int kNumOps = P.num_ops, kNetWidth = P.net_width, kXyzDim = P.xyz_dim;
+    T.tensor_off.resize(P.num_param_tensors);
     int off = 0;
-    for (int i = 0; i < kNumParamTensors; ++i) { T.tensor_off[i] = off; off += kParamNumel[i]; }
-    T.pack_bf16.assign((size_t)kNumChunks * 512, -1);
-    T.pack_f32.assign((size_t)kNumChunks * 512, -1);
-    T.bias.assign((size_t)kNumTiles * 32, -1);
+    for (int i = 0; i < P.num_param_tensors; ++i) { T.tensor_off[i] = off; off += P.param_numel[i]; }
+    T.total_params = off;
+    T.pack_bf16.assign((size_t)P.num_chunks * 512, -1);      // includes the zero padding chunks at the end of the stream
+    T.pack_f32.assign((size_t)P.num_chunks * 512, -1);
+    T.bias.assign((size_t)P.num_tiles * 32, -1);
     size_t ci = 0;
     auto fill_chunk = [&](const OpDesc& op, int ti, int ks) {
         const TileDesc& tile = op.tiles[ti];
@@ -105,14 +108,18 @@ void build_tables(Tables& T) {
                             T.tensor_off[op.tiles[t].bt] + op.tiles[t].row0 + row;
                 }
     }
-    // fp32 stream: [op][tile][kb], natural column order
+    // fp32 stream: [op][tile][kb], natural column order; LDS layout of kernels_mlp_f32.hip: [buffer B | buffer A | encoding]
     mip::F32Net& net = T.net;
     memset(&net, 0, sizeof net);
     net.nlayers = kNumOps;
     net.width = kNetWidth;
     net.xyz_dim = kXyzDim;
-    net.ldx = kNetWidth + (kXyzDim > 32 ? kXyzDim : 32) + 4;
+    const int ecols = kXyzDim > 32 ? kXyzDim : 32;
+    net.enc_col = 2 * kNetWidth;
+    net.dens_col = 2 * kNetWidth + ecols;
+    net.ldx = 2 * kNetWidth + ecols + 4;
     size_t cf = 0;
+    int cur_col = -1;                  // LDS column of the buffer that holds the current activation (mlp_plan.f32_layers)
     for (int oi = 0; oi < kNumOps; ++oi) {
         const OpDesc& op = kOps[oi];
         std::vector<int> colmap;
@@ -121,13 +128,21 @@ void build_tables(Tables& T) {
                 colmap.push_back(c < op.segs[s].ncols ? op.segs[s].col0 + c : -1);
         const int kb = (int)colmap.size() / 16;
         mip::F32Layer& L = net.layers[oi];
-        L.x_in = op.xcol_in;
-        L.kb = kb;
+        const int out_col = cur_col == kNetWidth ? 0 : kNetWidth;    // write the buffer that is not being read
+        const int prev_out = cur_col;
+        auto seg_col = [&](const SegDesc& sg) { return sg.kind == 0 ? net.enc_col : prev_out; };   // natural = encoding / view
+        L.x_in0 = seg_col(op.segs[0]);
+        L.kb0 = op.segs[0].nk;
+        L.x_in1 = op.nsegs > 1 ? seg_col(op.segs[1]) : 0;
+        L.kb1 = op.nsegs > 1 ? op.segs[1].nk : 0;
+        L.x_out = out_col;
         L.ntiles = op.ntiles;
         L.first_tile = op.first_tile;
         L.relu = op.relu;
         L.kind = op.kind;
         L.chunk0 = (int)cf;
+        L.stage_view = (op.kind == 1 && P.use_viewdirs) ? 1 : 0;
+        if (op.kind == 0 || (op.kind == 1 && op.ntiles > 1)) cur_col = out_col;     // a density-only head moves nothing
         for (int t = 0; t < op.ntiles; ++t)
             for (int k = 0; k < kb; ++k) {
                 const TileDesc& tile = op.tiles[t];
@@ -146,9 +161,7 @@ void build_tables(Tables& T) {
 
 bool max_deg_span_is_16(const mipnerf_config& cfg) { return cfg.max_deg_point - cfg.min_deg_point == 16 && cfg.min_deg_point >= 0 && cfg.max_deg_point <= 31; }
 
-int off_total(const Tables& T) {
-    return T.tensor_off.back() + mip::plan::kParamNumel[mip::plan::kNumParamTensors - 1];
-}
+int off_total(const Tables& T) { return T.total_params; }
 
 // flat index -> (tensor << 20 | offset) as consumed by k_pack
 std::vector<int32_t> encode(const std::vector<int32_t>& flat, const std::vector<int>& toff) {
@@ -187,6 +200,7 @@ bool train_tables(TrainTables& T) {
 
 struct mipnerf_ctx {
     mipnerf_config cfg;
+    const PlanDesc* P = nullptr;     // the generated architecture variant this context runs (mlp_plan_gen.hpp kPlans)
     Tables tab;
     int32_t* d_pack_bf16 = nullptr;
     int32_t* d_pack_f32 = nullptr;
@@ -218,6 +232,21 @@ struct mipnerf_ctx {
 };
 
 namespace {
+// the bf16 inference kernel generated for this context's architecture variant
+hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* viewenc, float* rgb_sigma, float* raw, int64_t M, int N,
+                               bool dma, const mip::RayInputs* rays, hipStream_t st) {
+    typedef hipError_t (*Fn)(const void*, const float*, const void*, const void*, float*, float*, int64_t, int, float, float, int, bool,
+                             const mip::RayInputs*, const float*, float, hipStream_t);
+    static const Fn table[mip::plan::kNumVariants] = {mip::launch_mlp_bf16, mip::launch_mlp_bf16_v1, mip::launch_mlp_bf16_v2};
+    return table[c->P->variant](c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
+                                c->grid_limit, dma, rays, c->dnoise, c->cfg.density_noise, st);
+}
+
+#define NEED_BF16_TRAIN(what)                                                                                               \
+    if (!c->P->has_bf16_train)                                                                                               \
+        return fail(MIPNERF_E_UNSUPPORTED, what ": the bf16 training kernels are generated for the shipped architecture only " \
+                                                "(variant 0); train this shape in fp32 precision")
+
 struct TrainWs {                   // carve-up of the caller's workspace (all 256-byte aligned)
     char* base;
     size_t off = 0;
@@ -236,15 +265,27 @@ int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host);
 const char* mipnerf_last_error(void) { return g_err.c_str(); }
 int mipnerf_abi_version(void) { return MIPNERF_ABI_VERSION; }
 
+static void variant_to_cfg(const PlanDesc& P, mipnerf_config* cfg) {
+    memset(cfg, 0, sizeof *cfg);
+    cfg->num_samples = 128; cfg->num_levels = 2; cfg->min_deg_point = 0; cfg->max_deg_point = P.xyz_dim / 6;
+    cfg->deg_view = (P.view_dim - 3) / 6; cfg->use_viewdirs = P.use_viewdirs; cfg->net_depth = P.net_depth; cfg->net_width = P.net_width;
+    cfg->net_depth_condition = P.net_depth_cond; cfg->net_width_condition = P.net_width_cond; cfg->skip_index = P.skip_index;
+    cfg->num_rgb_channels = P.num_rgb; cfg->num_density_channels = P.num_density;
+    cfg->resample_padding = 0.01f; cfg->density_bias = -1.0f; cfg->rgb_padding = 0.001f; cfg->density_noise = 0.0f;
+}
+
 int mipnerf_compiled_arch(mipnerf_config* cfg) {
     if (!cfg) return fail(MIPNERF_E_INVALID, "cfg is null");
-    using namespace mip::plan;
-    memset(cfg, 0, sizeof *cfg);
-    cfg->num_samples = 128; cfg->num_levels = 2; cfg->min_deg_point = 0; cfg->max_deg_point = kXyzDim / 6;
-    cfg->deg_view = (kViewDim - 3) / 6; cfg->use_viewdirs = 1; cfg->net_depth = kNetDepth; cfg->net_width = kNetWidth;
-    cfg->net_depth_condition = kNetDepthCond; cfg->net_width_condition = kNetWidthCond; cfg->skip_index = kSkipIndex;
-    cfg->num_rgb_channels = kNumRgb; cfg->num_density_channels = kNumDensity;
-    cfg->resample_padding = 0.01f; cfg->density_bias = -1.0f; cfg->rgb_padding = 0.001f; cfg->density_noise = 0.0f;
+    variant_to_cfg(mip::plan::kPlans[0], cfg);
+    return MIPNERF_OK;
+}
+
+int mipnerf_num_variants(void) { return mip::plan::kNumVariants; }
+
+int mipnerf_variant_arch(int variant, mipnerf_config* cfg, int* has_bf16_training) {
+    if (!cfg || variant < 0 || variant >= mip::plan::kNumVariants) return fail(MIPNERF_E_INVALID, "variant_arch: bad argument");
+    variant_to_cfg(mip::plan::kPlans[variant], cfg);
+    if (has_bf16_training) *has_bf16_training = mip::plan::kPlans[variant].has_bf16_train;
     return MIPNERF_OK;
 }
 
@@ -254,24 +295,41 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
     if (cfg->num_samples < 1 || cfg->num_samples > MIPNERF_MAX_SAMPLES)
         return fail(MIPNERF_E_INVALID, "num_samples must be in [1, %d]", MIPNERF_MAX_SAMPLES);
     if (cfg->num_levels < 1 || cfg->num_levels > 2) return fail(MIPNERF_E_UNSUPPORTED, "num_levels must be 1 or 2");
-    if (!cfg->use_viewdirs)
-        return fail(MIPNERF_E_UNSUPPORTED, "use_viewdirs=False is not implemented (the reference MLP would feed a "
-                                           "net_width tensor to color_layer(net_width_condition))");
-    if (cfg->net_depth != kNetDepth || cfg->net_width != kNetWidth || cfg->net_depth_condition != kNetDepthCond ||
-        cfg->net_width_condition != kNetWidthCond || cfg->skip_index != kSkipIndex ||
-        cfg->num_rgb_channels != kNumRgb || cfg->num_density_channels != kNumDensity ||
-        6 * (cfg->max_deg_point - cfg->min_deg_point) != kXyzDim || 3 + 6 * cfg->deg_view != kViewDim)
-        return fail(MIPNERF_E_UNSUPPORTED,
-                    "MLP shape differs from the one the MFMA kernels were generated for (depth %d width %d cond %dx%d "
-                    "skip %d xyz %d view %d); regenerate with gen_mlp_bf16.py",
-                    kNetDepth, kNetWidth, kNetDepthCond, kNetWidthCond, kSkipIndex, kXyzDim, kViewDim);
+    if (!cfg->use_viewdirs && cfg->net_width_condition != cfg->net_width)
+        return fail(MIPNERF_E_UNSUPPORTED, "use_viewdirs=False feeds the trunk output (net_width=%d) to color_layer, which has "
+                                           "net_width_condition=%d inputs: the reference MLP fails on this shape too "
+                                           "(models/mip_nerf.py:99-110)", cfg->net_width, cfg->net_width_condition);
+    const PlanDesc* P = nullptr;
+    for (int v = 0; v < kNumVariants && !P; ++v) {
+        const PlanDesc& q = kPlans[v];
+        if (cfg->net_depth == q.net_depth && cfg->net_width == q.net_width && cfg->net_depth_condition == q.net_depth_cond &&
+            cfg->net_width_condition == q.net_width_cond && cfg->skip_index == q.skip_index && cfg->num_rgb_channels == q.num_rgb &&
+            cfg->num_density_channels == q.num_density && 6 * (cfg->max_deg_point - cfg->min_deg_point) == q.xyz_dim &&
+            3 + 6 * cfg->deg_view == q.view_dim && (cfg->use_viewdirs != 0) == (q.use_viewdirs != 0))
+            P = &q;
+    }
+    if (!P) {
+        std::string have;
+        for (int v = 0; v < kNumVariants; ++v) {
+            char b[160];
+            snprintf(b, sizeof b, "%s[depth %d width %d cond %dx%d skip %d xyz %d view %d viewdirs %d]", v ? ", " : "", kPlans[v].net_depth,
+                     kPlans[v].net_width, kPlans[v].net_depth_cond, kPlans[v].net_width_cond, kPlans[v].skip_index, kPlans[v].xyz_dim,
+                     kPlans[v].view_dim, kPlans[v].use_viewdirs);
+            have += b;
+        }
+        return fail(MIPNERF_E_UNSUPPORTED, "no kernels / tables were generated for this MLP shape; generated: %s.  Add the shape to "
+                                           "VARIANTS in csrc/gen_mlp_bf16.py and rebuild", have.c_str());
+    }
+    if (P->num_param_tensors != MIPNERF_NUM_PARAM_TENSORS)
+        return fail(MIPNERF_E_UNSUPPORTED, "variant has %d parameter tensors, the ABI passes %d", P->num_param_tensors, MIPNERF_NUM_PARAM_TENSORS);
     mipnerf_ctx* c = new mipnerf_ctx();
     c->cfg = *cfg;
-    build_tables(c->tab);
+    c->P = P;
+    build_tables(c->tab, *P);
     const std::vector<int32_t> e_bf16 = encode(c->tab.pack_bf16, c->tab.tensor_off);
     const std::vector<int32_t> e_f32 = encode(c->tab.pack_f32, c->tab.tensor_off);
     const std::vector<int32_t> e_bias = encode(c->tab.bias, c->tab.tensor_off);
-    const size_t nst = (size_t)kNumChunks * 512;
+    const size_t nst = (size_t)P->num_chunks * 512;
     hipError_t er = hipSuccess;
     auto chk = [&](hipError_t e) { if (er == hipSuccess) er = e; };
     chk(hipMalloc(&c->d_pack_bf16, nst * 4));
@@ -293,12 +351,12 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
         c->grid_limit = cus;
-    // ---- training tables ----
-    if (!train_tables(c->tt) || c->tt.nparams != off_total(c->tab)) {
+    // ---- training tables (bf16 training kernels exist for variant 0 only) ----
+    if (P->has_bf16_train && (!train_tables(c->tt) || c->tt.nparams != off_total(c->tab))) {
         mipnerf_destroy(c);
         return fail(MIPNERF_E_INVALID, "mipnerf_create: embedded training tables are inconsistent with the compiled plan");
     }
-    {
+    if (P->has_bf16_train) {
         const TrainTables& tt = c->tt;
         const std::vector<int32_t> flat(tt.bpack, tt.bpack + (size_t)tt.n_bchunks * 512);
         const std::vector<int32_t> e_dg = encode(flat, c->tab.tensor_off);
@@ -319,7 +377,7 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
             return fail(MIPNERF_E_HIP, "mipnerf_create (training tables): %s", hipGetErrorString(er));
         }
     }
-    {
+    if (P->has_bf16_train) {
         const int rc = mipnerf_set_wgrad_splits(c, nullptr);
         if (rc) { mipnerf_destroy(c); return rc; }
     }
@@ -350,20 +408,22 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
 }
 
 int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* stream) {
-    using namespace mip::plan;
     if (!c || !params_host) return fail(MIPNERF_E_INVALID, "null argument");
+    const PlanDesc& P = *c->P;
     mip::ParamPtrs pp;
     memset(&pp, 0, sizeof pp);
-    for (int i = 0; i < kNumParamTensors; ++i) {
+    for (int i = 0; i < P.num_param_tensors; ++i) {
         if (!params_host[i]) return fail(MIPNERF_E_INVALID, "parameter tensor %d is null", i);
         pp.p[i] = params_host[i];
     }
-    const int64_t nst = (int64_t)kNumChunks * 512;
+    const int64_t nst = (int64_t)P.num_chunks * 512;
     HIP_TRY(mip::launch_pack(c->d_pack_bf16, nst, pp, c->d_stream_bf16, true, S(stream)));
     HIP_TRY(mip::launch_pack(c->d_pack_f32, nst, pp, c->d_stream_f32, false, S(stream)));
-    HIP_TRY(mip::launch_pack(c->d_bias_idx, (int64_t)kNumTiles * 32, pp, c->d_bias, false, S(stream)));
-    HIP_TRY(mip::launch_pack(c->d_pack_dgrad, (int64_t)c->tt.n_bchunks * 512, pp, c->d_stream_dgrad, true, S(stream)));
-    HIP_TRY(mip::launch_transpose_sq(kNetWidth, pp.p[2 * kNetDepth + 2], c->d_extra_wT, S(stream)));
+    HIP_TRY(mip::launch_pack(c->d_bias_idx, (int64_t)P.num_tiles * 32, pp, c->d_bias, false, S(stream)));
+    if (P.has_bf16_train) {
+        HIP_TRY(mip::launch_pack(c->d_pack_dgrad, (int64_t)c->tt.n_bchunks * 512, pp, c->d_stream_dgrad, true, S(stream)));
+        HIP_TRY(mip::launch_transpose_sq(P.net_width, pp.p[2 * P.net_depth + 2], c->d_extra_wT, S(stream)));
+    }
     c->pp = pp;
     c->params_set = true;
     return MIPNERF_OK;
@@ -414,9 +474,7 @@ int mipnerf_mlp_forward(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, c
     if (!c || M < 1 || N < 1 || !enc || !viewenc || !rgb_sigma) return fail(MIPNERF_E_INVALID, "mlp_forward: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward: mipnerf_set_params has not been called");
     if (precision == MIPNERF_PREC_BF16) {
-        HIP_TRY(mip::launch_mlp_bf16(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias,
-                                     c->cfg.rgb_padding, c->grid_limit, c->mlp_dma != 0, nullptr, c->dnoise, c->cfg.density_noise,
-                                     S(stream)));
+        HIP_TRY(launch_bf16_variant(c, enc, viewenc, rgb_sigma, raw, M, N, c->mlp_dma != 0, nullptr, S(stream)));
     } else if (precision == MIPNERF_PREC_FP32) {
         HIP_TRY(mip::launch_mlp_f32(c->tab.net, c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
                                     rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, c->dnoise,
@@ -506,6 +564,7 @@ int mipnerf_distloss(int64_t B, int32_t N, const float* weights, const float* t,
 int mipnerf_mlp_train_sizes(const mipnerf_ctx* c, int64_t M, size_t* act_bytes, size_t* mask_bytes, size_t* delta_bytes,
                             size_t* partial_bytes) {
     if (!c || M < 1) return fail(MIPNERF_E_INVALID, "mlp_train_sizes: bad argument");
+    NEED_BF16_TRAIN("mlp_train_sizes");
     const size_t n_wt = (size_t)((M + 255) / 256) * 8;          // wave tiles (32 samples) of whole workgroup tiles
     if (act_bytes) *act_bytes = n_wt * c->tt.NH * 2048;
     if (mask_bytes) *mask_bytes = n_wt * c->tt.NMASK * 1024;
@@ -518,6 +577,7 @@ int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* 
                               float* raw, void* act, void* masks, void* stream) {
     if (!c || M < 1 || N < 1 || !enc || !viewenc || !rgb_sigma || !raw || !act || !masks)
         return fail(MIPNERF_E_INVALID, "mlp_forward_train: bad argument");
+    NEED_BF16_TRAIN("mlp_forward_train");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train: mipnerf_set_params has not been called");
     HIP_TRY(mip::launch_mlp_bf16_trainfwd(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, act, masks, M, N,
                                           c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, nullptr, c->dnoise,
@@ -527,6 +587,7 @@ int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* 
 
 int mipnerf_mlp_dgrad(mipnerf_ctx* c, int64_t M, const float* d_raw, const void* masks, void* delta, void* stream) {
     if (!c || M < 1 || !d_raw || !masks || !delta) return fail(MIPNERF_E_INVALID, "mlp_dgrad: bad argument");
+    NEED_BF16_TRAIN("mlp_dgrad");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_dgrad: mipnerf_set_params has not been called");
     HIP_TRY(mip::launch_mlp_bf16_dgrad(c->d_stream_dgrad, d_raw, masks, delta, M, c->grid_limit, S(stream)));
     return MIPNERF_OK;
@@ -535,6 +596,7 @@ int mipnerf_mlp_dgrad(mipnerf_ctx* c, int64_t M, const float* d_raw, const void*
 int mipnerf_mlp_wgrad(mipnerf_ctx* c, int64_t M, const void* act, const void* delta, float* partials, float* grad_flat,
                       int32_t accumulate, void* stream) {
     if (!c || M < 1 || !act || !delta || !partials) return fail(MIPNERF_E_INVALID, "mlp_wgrad: bad argument");
+    NEED_BF16_TRAIN("mlp_wgrad");
     const int64_t n_wt = ((M + 255) / 256) * 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->time_mlp == 2) {          // option 2 = 2: time the weight-gradient launches (bench.py --mode train roofline)
@@ -595,6 +657,7 @@ int mipnerf_adam_step_scheduled(int64_t n, float* param, const float* grad, floa
 // NOT produced -- timing experiments only).  NULL restores the default (CUs / njobs workgroups per job).
 int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host) {
     if (!c) return fail(MIPNERF_E_INVALID, "ctx is null");
+    NEED_BF16_TRAIN("set_wgrad_splits");
     const TrainTables& tt = c->tt;
     std::vector<int> sp(tt.njobs);
     if (splits_host) {
@@ -630,11 +693,12 @@ int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host) {
 // ---- parity-mode (fp32) MLP training: fused forward that saves every layer output + GEMM-based backward ------------
 // `save` = 10 slots of [M, 256] fp32 (layers 0..7 outputs, bottleneck, view-layer output [M,128] in slot 9).
 size_t mipnerf_mlp_train_f32_bytes(const mipnerf_ctx* c, int64_t M, size_t* save_bytes, size_t* workspace_bytes) {
-    using namespace mip::plan;
     if (!c || M < 1) return 0;
-    const size_t save = (size_t)(kNetDepth + 2) * M * kNetWidth * 4;
+    const PlanDesc& P = *c->P;
+    const size_t save = (size_t)P.num_ops * M * P.net_width * 4;          // one [M, width] slot per layer (op) of the plan
     const int splits = 64;
-    const size_t ws = 2 * (size_t)M * kNetWidth * 4 + (size_t)splits * kNetWidth * (kNetWidth + kXyzDim) * 4 + 1024;
+    const size_t wmax = P.net_width > P.net_width_cond ? P.net_width : P.net_width_cond;
+    const size_t ws = 2 * (size_t)M * wmax * 4 + (size_t)splits * wmax * (wmax + P.xyz_dim + 32) * 4 + 1024;
     if (save_bytes) *save_bytes = save;
     if (workspace_bytes) *workspace_bytes = ws;
     return save + ws;
@@ -652,26 +716,28 @@ int mipnerf_mlp_forward_train_f32(mipnerf_ctx* c, int64_t M, int32_t N, const fl
 
 int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* d_raw, const float* enc, const float* viewenc,
                              const float* save, void* workspace, float* grad_flat, int32_t accumulate, void* stream) {
-    using namespace mip::plan;
     if (!c || M < 1 || N < 1 || !d_raw || !enc || !viewenc || !save || !workspace || !grad_flat)
         return fail(MIPNERF_E_INVALID, "mlp_backward_f32: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_backward_f32: mipnerf_set_params has not been called");
     if (M > 0x7fffffff) return fail(MIPNERF_E_INVALID, "mlp_backward_f32: too many samples");
-    const int W = kNetWidth, Wc = kNetWidthCond, E = kXyzDim, D = kNetDepth, V = kViewDim;
+    const PlanDesc& PL = *c->P;
+    if (PL.net_depth_cond != 1) return fail(MIPNERF_E_UNSUPPORTED, "mlp_backward_f32: one view layer (net_depth_condition = 1) only");
+    const int W = PL.net_width, Wc = PL.net_width_cond, E = PL.xyz_dim, D = PL.net_depth, V = PL.view_dim, RGB = PL.num_rgb;
+    const bool views = PL.use_viewdirs != 0;
     const int splits = 64, Mi = (int)M;
     hipStream_t st = S(stream);
+    const size_t wmax = W > Wc ? W : Wc;
     float* g0 = reinterpret_cast<float*>(workspace);
-    float* g1 = g0 + (size_t)M * W;
-    float* part = g1 + (size_t)M * W;
+    float* g1 = g0 + (size_t)M * wmax;
+    float* part = g1 + (size_t)M * wmax;
     const bool acc = accumulate != 0;
+    // `save` slot of op L (k_mlp_f32): [M, 32 * hidden tiles] fp32 at offset L * M * W
     auto slot = [&](int L) { return save + (size_t)L * M * W; };
     auto P = [&](int t) { return c->pp.p[t]; };                       // fp32 master parameter t (state_dict order)
     auto G = [&](int t) { return grad_flat + c->tab.tensor_off[t]; }; // its gradient
     const int tDensW = 2 * D, tDensB = 2 * D + 1, tExW = 2 * D + 2, tExB = 2 * D + 3, tVW = 2 * D + 4, tVB = 2 * D + 5,
               tCW = 2 * D + 6, tCB = 2 * D + 7;
-    const float* hv = slot(D + 1);     // [M, Wc]
-    const float* bott = slot(D);       // [M, W]
-    const float* x8 = slot(D - 1);
+    const float* x8 = slot(D - 1);     // trunk output [M, W]
     // wgrad / bias helpers: dW[out, ldw] (cols [col0, col0+n)) (+)= dY[M, out]^T X[M, n];  db[out] (+)= dY^T 1
     auto wgrad = [&](const float* dY, int64_t ldy, int nout, const float* X, int64_t ldx, int rowdiv, int ncols, float* dW, int64_t ldw) {
         return mip::launch_gemm_f32(true, nout, ncols, M, dY, ldy, X, ldx, rowdiv, false, dW, ldw, acc, splits, part, st);
@@ -679,31 +745,49 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
     auto bgrad = [&](const float* dY, int64_t ldy, int nout, float* db) {
         return mip::launch_gemm_f32(true, nout, 1, M, dY, ldy, nullptr, 0, 1, true, db, 1, acc, splits, part, st);
     };
-    // colour layer (mip_nerf.py:110): d_rgb = d_raw[:, 0:3]
-    HIP_TRY(wgrad(d_raw, 4, kNumRgb, hv, Wc, 1, Wc, G(tCW), Wc));
-    HIP_TRY(bgrad(d_raw, 4, kNumRgb, G(tCB)));
-    // g_hv = (d_rgb Wc) * relu'   [M, Wc] in g0
-    HIP_TRY(mip::launch_gemm_f32(false, Mi, Wc, kNumRgb, d_raw, 4, P(tCW), Wc, 1, false, g0, Wc, false, 1, nullptr, st));
-    HIP_TRY(mip::launch_relu_mask((int64_t)M * Wc, hv, g0, st));
-    // view layer (mip_nerf.py:106-109): input [bottleneck | view encoding of the sample's ray]
-    HIP_TRY(wgrad(g0, Wc, Wc, bott, W, 1, W, G(tVW), W + V));
-    HIP_TRY(wgrad(g0, Wc, Wc, viewenc, 32, N, V, G(tVW) + W, W + V));
-    HIP_TRY(bgrad(g0, Wc, Wc, G(tVB)));
-    // g_bott = g_hv Wv[:, :W]   [M, W] in g1
-    HIP_TRY(mip::launch_gemm_f32(false, Mi, W, Wc, g0, Wc, P(tVW), W + V, 1, false, g1, W, false, 1, nullptr, st));
-    // bottleneck (extra_layer, :102) and density head (:100)
-    HIP_TRY(wgrad(g1, W, W, x8, W, 1, W, G(tExW), W));
-    HIP_TRY(bgrad(g1, W, W, G(tExB)));
-    HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W));
-    HIP_TRY(bgrad(d_raw + 3, 4, 1, G(tDensB)));
-    // g8 = (g_bott We + d_den Wd) * relu'(x8)   in g0
-    HIP_TRY(mip::launch_gemm_f32(false, Mi, W, W, g1, W, P(tExW), W, 1, false, g0, W, false, 1, nullptr, st));
-    HIP_TRY(mip::launch_gemm_f32(false, Mi, W, 1, d_raw + 3, 4, P(tDensW), W, 1, false, g0, W, true, 1, nullptr, st));
+    if (views) {
+        const float* hv = slot(D + 1);     // view-layer output [M, Wc]
+        const float* bott = slot(D);       // bottleneck [M, W]
+        // colour layer (mip_nerf.py:110): d_rgb = d_raw[:, 0:3]
+        HIP_TRY(wgrad(d_raw, 4, RGB, hv, Wc, 1, Wc, G(tCW), Wc));
+        HIP_TRY(bgrad(d_raw, 4, RGB, G(tCB)));
+        // g_hv = (d_rgb Wc) * relu'   [M, Wc] in g0
+        HIP_TRY(mip::launch_gemm_f32(false, Mi, Wc, RGB, d_raw, 4, P(tCW), Wc, 1, false, g0, Wc, false, 1, nullptr, st));
+        HIP_TRY(mip::launch_relu_mask((int64_t)M * Wc, hv, g0, st));
+        // view layer (mip_nerf.py:106-109): input [bottleneck | view encoding of the sample's ray]
+        HIP_TRY(wgrad(g0, Wc, Wc, bott, W, 1, W, G(tVW), W + V));
+        HIP_TRY(wgrad(g0, Wc, Wc, viewenc, 32, N, V, G(tVW) + W, W + V));
+        HIP_TRY(bgrad(g0, Wc, Wc, G(tVB)));
+        // g_bott = g_hv Wv[:, :W]   [M, W] in g1
+        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, Wc, g0, Wc, P(tVW), W + V, 1, false, g1, W, false, 1, nullptr, st));
+        // bottleneck (extra_layer, :102) and density head (:100)
+        HIP_TRY(wgrad(g1, W, W, x8, W, 1, W, G(tExW), W));
+        HIP_TRY(bgrad(g1, W, W, G(tExB)));
+        HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W));
+        HIP_TRY(bgrad(d_raw + 3, 4, 1, G(tDensB)));
+        // g8 = (g_bott We + d_den Wd) * relu'(x8)   in g0
+        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, W, g1, W, P(tExW), W, 1, false, g0, W, false, 1, nullptr, st));
+        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, 1, d_raw + 3, 4, P(tDensW), W, 1, false, g0, W, true, 1, nullptr, st));
+    } else {
+        // MLP.forward(x, None) (mip_nerf.py:99-110): colour and density heads both read the trunk output; extra_layer and
+        // view_layers are unused parameters (autograd leaves their .grad None; here: zero unless accumulating)
+        HIP_TRY(wgrad(d_raw, 4, RGB, x8, W, 1, W, G(tCW), Wc));
+        HIP_TRY(bgrad(d_raw, 4, RGB, G(tCB)));
+        HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W));
+        HIP_TRY(bgrad(d_raw + 3, 4, 1, G(tDensB)));
+        if (!acc) {
+            const int unused[4] = {tExW, tExB, tVW, tVB};
+            for (int u = 0; u < 4; ++u)
+                HIP_TRY(hipMemsetAsync(G(unused[u]), 0, (size_t)PL.param_numel[unused[u]] * 4, st));
+        }
+        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, RGB, d_raw, 4, P(tCW), Wc, 1, false, g0, W, false, 1, nullptr, st));
+        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, 1, d_raw + 3, 4, P(tDensW), W, 1, false, g0, W, true, 1, nullptr, st));
+    }
     HIP_TRY(mip::launch_relu_mask((int64_t)M * W, x8, g0, st));
     float* g = g0;          // delta of layer i (gradient w.r.t. its pre-activation)
     float* gn = g1;
     for (int i = D - 1; i >= 0; --i) {
-        const int ld = kParamNumel[2 * i] / W;                       // in_features of layer i
+        const int ld = PL.param_numel[2 * i] / W;                    // in_features of layer i
         const float* xin = i == 0 ? enc : slot(i - 1);
         const int nin = i == 0 ? E : W;
         HIP_TRY(wgrad(g, W, W, xin, nin, 1, nin, G(2 * i), ld));
@@ -722,12 +806,12 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
 // MipNeRFSystem.training_step (nerf_system.py:95-111) = MipNerf.forward(randomized) + loss, followed by what
 // loss.backward() does to the 24 MLP parameters -- native kernels only, no autograd graph, graph-capturable.
 size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
-    if (!c || B < 1) return 0;
+    if (!c || B < 1 || !c->P->has_bf16_train) return 0;
     const size_t N = c->cfg.num_samples, M = (size_t)B * N, L = c->cfg.num_levels;
     size_t act, masks, delta, partials;
     if (mipnerf_mlp_train_sizes(c, (int64_t)M, &act, &masks, &delta, &partials)) return 0;
     size_t per_level = align256(B * (N + 1) * 4) + align256(B * N * 4) + align256(B * 3 * 4) + 2 * align256(B * 4) +   // t, w, rgb, dist, acc
-                       align256(M * mip::plan::kXyzDim * 2) + 2 * align256(M * 16) +                                    // enc, rgb_sigma, raw
+                       align256(M * c->P->xyz_dim * 2) + 2 * align256(M * 16) +                                    // enc, rgb_sigma, raw
                        align256(act) + align256(masks) + align256(B * 4) + align256(B * N * 4) + align256(B * 3 * 4);   // act, masks, ray_loss, d_w, g_rgb
     return 256 + L * per_level + align256(B * 32 * 2) + align256(delta) + align256(partials) + align256(M * 16) + 256;
 }
@@ -738,6 +822,7 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
                        int32_t accumulate, float* out_scalars, const mipnerf_level_out* out, void* stream) {
     if (!c || !rays || !gt_rgb || !workspace || !grad_flat || !out_scalars || B < 1)
         return fail(MIPNERF_E_INVALID, "train_step: bad argument");
+    NEED_BF16_TRAIN("train_step");
     if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->radii || !rays->near || !rays->far || !rays->lossmult)
         return fail(MIPNERF_E_INVALID, "train_step: a Rays field is null");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "train_step: mipnerf_set_params has not been called");
@@ -756,7 +841,7 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     for (int l = 0; l < L; ++l) {
         lv[l].t = ws.take<float>(B * (N + 1) * 4); lv[l].w = ws.take<float>(B * N * 4); lv[l].rgb = ws.take<float>(B * 3 * 4);
         lv[l].dist = ws.take<float>(B * 4); lv[l].acc = ws.take<float>(B * 4);
-        lv[l].enc = ws.take<char>(M * mip::plan::kXyzDim * 2);
+        lv[l].enc = ws.take<char>(M * c->P->xyz_dim * 2);
         lv[l].rgb_sigma = ws.take<float>(M * 16); lv[l].raw = ws.take<float>(M * 16);
         lv[l].act = ws.take<char>(act_b); lv[l].masks = ws.take<char>(mask_b);
         lv[l].ray_loss = ws.take<float>(B * 4); lv[l].d_w = ws.take<float>(B * N * 4); lv[l].g_rgb = ws.take<float>(B * 3 * 4);
@@ -827,7 +912,7 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
 size_t mipnerf_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
     if (!c || B < 1) return 0;
     const size_t M = (size_t)B * (size_t)c->cfg.num_samples;
-    return align256(M * mip::plan::kXyzDim * 4) + align256((size_t)B * 32 * 4) + align256(M * 16) + 256;
+    return align256(M * c->P->xyz_dim * 4) + align256((size_t)B * 32 * 4) + align256(M * 16) + 256;
 }
 
 int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* t_rand, const float* u_rand,
@@ -847,8 +932,8 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
     const size_t M = (size_t)B * N;
     char* ws = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     void* enc = ws;
-    void* viewenc = ws + align256(M * mip::plan::kXyzDim * 4);
-    float* rgb_sigma = reinterpret_cast<float*>(ws + align256(M * mip::plan::kXyzDim * 4) + align256((size_t)B * 32 * 4));
+    void* viewenc = ws + align256(M * c->P->xyz_dim * 4);
+    float* rgb_sigma = reinterpret_cast<float*>(ws + align256(M * c->P->xyz_dim * 4) + align256((size_t)B * 32 * 4));
     const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
     const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
     int rc;
@@ -886,9 +971,7 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
                 return fail(MIPNERF_E_UNSUPPORTED, "fused IPE is generated for max_deg-min_deg == 16");
             const mip::RayInputs ri = {o.t_samples, rays->origins, rays->directions, rays->radii, cfg.min_deg_point,
                                        cfg.disable_integration};
-            HIP_TRY(mip::launch_mlp_bf16(c->d_stream_bf16, c->d_bias, nullptr, viewenc, rgb_sigma, nullptr, (int64_t)M, N,
-                                         cfg.density_bias, cfg.rgb_padding, c->grid_limit, true, &ri, c->dnoise, cfg.density_noise,
-                                         S(stream)));
+            HIP_TRY(launch_bf16_variant(c, nullptr, viewenc, rgb_sigma, nullptr, (int64_t)M, N, true, &ri, S(stream)));
         } else if ((rc = mipnerf_mlp_forward(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream))) {
             return rc;
         }
@@ -946,6 +1029,15 @@ int mipnerf_selftest(void* stream) {
 
 // Host-only debug export of the plan tables (flat parameter indices), used by the CPU tests to prove the
 // C++ expansion equals mlp_plan.py.  which: 0 bf16 pack, 1 bias, 2 fp32 pack.  Returns element count.
+int64_t mipnerf_debug_table_variant(int variant, int which, int32_t* out_host, int64_t cap) {
+    if (variant < 0 || variant >= mip::plan::kNumVariants || which < 0 || which > 2) return -1;
+    Tables T;
+    build_tables(T, mip::plan::kPlans[variant]);
+    const std::vector<int32_t>& v = which == 0 ? T.pack_bf16 : (which == 1 ? T.bias : T.pack_f32);
+    if (out_host && cap >= (int64_t)v.size()) memcpy(out_host, v.data(), v.size() * 4);
+    return (int64_t)v.size();
+}
+
 int64_t mipnerf_debug_table(int which, int32_t* out_host, int64_t cap) {
     if (which >= 3 && which <= 5) {
         TrainTables tt;
@@ -956,22 +1048,23 @@ int64_t mipnerf_debug_table(int which, int32_t* out_host, int64_t cap) {
         return n;
     }
     Tables T;
-    build_tables(T);
+    build_tables(T, mip::plan::kPlans[0]);
     const std::vector<int32_t>& v = which == 0 ? T.pack_bf16 : (which == 1 ? T.bias : T.pack_f32);
     if (out_host && cap >= (int64_t)v.size()) memcpy(out_host, v.data(), v.size() * 4);
     return (int64_t)v.size();
 }
 
-// Host-only: fp32 layer descriptors (x_in, kb, ntiles, first_tile, relu, kind, chunk0, ldx) x nlayers
+// Host-only: fp32 layer descriptors (x_in0, kb0, x_in1, kb1, x_out, ntiles, first_tile, relu, kind, chunk0, stage_view, ldx) x nlayers
 int64_t mipnerf_debug_f32net(int32_t* out_host, int64_t cap) {
     Tables T;
-    build_tables(T);
+    build_tables(T, mip::plan::kPlans[0]);
     const int n = T.net.nlayers;
-    if (out_host && cap >= (int64_t)n * 8)
+    if (out_host && cap >= (int64_t)n * 12)
         for (int i = 0; i < n; ++i) {
             const mip::F32Layer& L = T.net.layers[i];
-            const int32_t row[8] = {L.x_in, L.kb, L.ntiles, L.first_tile, L.relu, L.kind, L.chunk0, T.net.ldx};
-            memcpy(out_host + i * 8, row, sizeof row);
+            const int32_t row[12] = {L.x_in0, L.kb0, L.x_in1, L.kb1, L.x_out, L.ntiles, L.first_tile, L.relu, L.kind, L.chunk0,
+                                     L.stage_view, T.net.ldx};
+            memcpy(out_host + i * 12, row, sizeof row);
         }
     return n;
 }

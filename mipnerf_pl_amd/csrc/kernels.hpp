@@ -71,6 +71,15 @@ hipError_t launch_mlp_bf16(const void* stream_w, const float* bias_tab, const vo
                            float rgb_padding, int grid_limit, bool dma, const RayInputs* rays, const float* dnoise,
                            float dnoise_scale, hipStream_t st);
 
+// architecture variants (gen_mlp_bf16.VARIANTS): mlp_bf16_gen_v<i>.hip
+#define MIP_DECL_BF16_VARIANT(name)                                                                                          \
+    hipError_t name(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc, float* rgb_sigma,       \
+                    float* raw_out, int64_t M, int num_samples, float density_bias, float rgb_padding, int grid_limit, bool dma, \
+                    const RayInputs* rays, const float* dnoise, float dnoise_scale, hipStream_t st)
+MIP_DECL_BF16_VARIANT(launch_mlp_bf16_v1);
+MIP_DECL_BF16_VARIANT(launch_mlp_bf16_v2);
+#undef MIP_DECL_BF16_VARIANT
+
 // ---- mlp_bf16_trainfwd_gen.hip / mlp_bf16_dgrad_gen.hip (generated by gen_mlp_train.py) -------
 int mlp_trainfwd_lds_bytes();
 hipError_t launch_mlp_bf16_trainfwd(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,
@@ -107,20 +116,25 @@ hipError_t launch_wgrad_reduce(const float* partials, const int32_t* otab, const
 // ---- kernels_mlp_f32.hip ----------------------------------------------------------------------
 constexpr int kF32MaxLayers = 16;
 struct F32Layer {
-    int x_in;        // first LDS column of the layer input
-    int kb;          // number of 16-wide k blocks
+    int x_in0, kb0;  // K segment 0: first LDS column, number of 16-wide k blocks (the activation buffer, or the encoding for layer 0)
+    int x_in1, kb1;  // K segment 1 (encoding of the skip concat / view features), kb1 = 0 when absent
+    int x_out;       // first LDS column of the output buffer
     int ntiles;      // out tiles (32 rows each)
     int first_tile;  // global tile index (bias table row)
     int relu;
-    int kind;        // 0: write tiles to X[:, 0:32*ntiles]; 1: head (last tile = density); 2: colour
+    int kind;        // 0: write tiles to X[:, x_out + 32 t]; 1: head (last tile = density); 2: colour
     int chunk0;      // first 2-KiB chunk of this layer in the fp32 stream
+    int stage_view;  // 1: load the view encoding into the encoding columns during this layer
     int pad;
 };
 struct F32Net {
     int nlayers;
-    int width;       // net_width (column where the encoding / view features live)
+    int width;       // net_width
     int xyz_dim;
-    int ldx;         // LDS row stride in floats
+    int ldx;         // LDS row stride in floats: 2 * width + max(xyz_dim, 32) + 4
+    int enc_col;     // 2 * width
+    int dens_col;    // spare column that carries the raw density from the head to the colour layer
+    int pad[2];
     F32Layer layers[kF32MaxLayers];
 };
 hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float* bias_tab, const float* enc,

@@ -38,6 +38,7 @@ import numpy as np
 import os
 
 CHAIN = os.environ.get("MLP_CHAIN", "0") == "1"   # weight-stream order knob (inference kernel experiments)
+RING_MULTIPLE = 64  # chunks: 2 ring slots x 32-chunk groups (gen_mlp_bf16.py)
 TILE = 32          # MFMA M/N
 KSTEP = 16         # MFMA K (bf16 32x32x16)
 NATURAL, DLAYOUT = 0, 1
@@ -91,6 +92,11 @@ class Arch:
     num_density: int = 1
     xyz_dim: int = 96
     view_dim: int = 27
+    use_viewdirs: bool = True      # False: MLP.forward(x, None) -- colour head on the trunk output (mip_nerf.py:99-110)
+
+    def key(self):
+        return (self.net_depth, self.net_width, self.net_depth_condition, self.net_width_condition, self.skip_index,
+                self.num_rgb, self.num_density, self.xyz_dim, self.view_dim, int(self.use_viewdirs))
 
     def param_shapes(self):
         shapes = []
@@ -123,8 +129,9 @@ def _ceil(a, b):
 class Plan:
     arch: Arch
     ops: List[Op] = field(default_factory=list)
-    chunks: List[Tuple[int, int, int]] = field(default_factory=list)   # (op, tile_in_op, ks)
+    chunks: List[Tuple[int, int, int]] = field(default_factory=list)   # (op, tile_in_op, ks); op = -1: zero padding
     n_tiles: int = 0
+    n_real_chunks: int = 0
 
     # ---- construction -----------------------------------------------------------------
     @staticmethod
@@ -136,6 +143,9 @@ class Plan:
             raise NotImplementedError("unsupported encoding / head size for the MFMA kernels")
         if a.net_depth >= 2 and (a.net_depth - 1) % a.skip_index == 0 and a.net_depth - 1 > 0:
             raise NotImplementedError("skip concat after the last trunk layer (reference would fail too)")
+        if not a.use_viewdirs and a.net_width_condition != a.net_width:
+            raise NotImplementedError("use_viewdirs=False feeds the trunk output (net_width) to color_layer "
+                                      "(net_width_condition inputs): the reference fails unless the two widths are equal")
         p = Plan(a)
         names = [n for n, _ in a.param_shapes()]
         pid = {n: i for i, n in enumerate(names)}
@@ -156,14 +166,16 @@ class Plan:
                      for t in range(W // TILE)]
             p.ops.append(Op(f"layer{i}", segs, tiles, True, other))
             cur, other = other, ("Y" if other == "X" else "X")
-        # head: bottleneck (no activation) + density row as an extra tile
+        # head: bottleneck (no activation) + density row as an extra tile; without view directions only the density row
+        # (extra_layer and view_layers stay unused parameters, mip_nerf.py:99-110)
         tiles = [TileSrc(pid["extra_layer.weight"], pid["extra_layer.bias"], t * TILE, TILE, W)
-                 for t in range(W // TILE)]
+                 for t in range(W // TILE)] if a.use_viewdirs else []
         tiles.append(TileSrc(pid["density_layer.weight"], pid["density_layer.bias"], 0, a.num_density, W))
         p.ops.append(Op("head", [Seg(cur, DLAYOUT, W // KSTEP, 0, W)], tiles, False, other))
-        cur, other = other, cur
+        if a.use_viewdirs:
+            cur, other = other, cur
         Wc = a.net_width_condition
-        for i in range(a.net_depth_condition):
+        for i in range(a.net_depth_condition if a.use_viewdirs else 0):
             if i == 0:
                 segs = [Seg(cur, DLAYOUT, W // KSTEP, 0, W), Seg("view", NATURAL, 2, W, a.view_dim)]
                 ld = W + a.view_dim
@@ -195,6 +207,10 @@ class Plan:
                     if t1 is not None:
                         p.chunks.append((oi, t1, ks))
         p.n_tiles = gt
+        # the kernel streams whole ring groups and needs a stable tile-to-tile ring phase: pad the stream with zero chunks
+        p.n_real_chunks = len(p.chunks)
+        while len(p.chunks) % RING_MULTIPLE:
+            p.chunks.append((-1, 0, 0))
         return p
 
     @staticmethod
@@ -240,6 +256,8 @@ class Plan:
         offs, _ = self.param_offsets()
         tab = np.full((len(self.chunks), 64, 8), -1, dtype=np.int32)
         for ci, (oi, ti, ks) in enumerate(self.chunks):
+            if oi < 0:
+                continue
             op = self.ops[oi]
             tile = op.tiles[ti]
             seg, ksl = self.seg_of(op, ks)
@@ -269,26 +287,29 @@ class Plan:
 
     # ---- fp32 kernel layout (natural k order, activations in LDS) -----------------------
     def f32_layers(self):
-        """Per layer of the LDS-resident fp32 kernel: dict(x_in, kb, tiles, x_out, relu, kind).
-        LDS row layout per sample: cols [0,W) current activation, [W, W+xyz) the encoding
-        (kept for the skip), later overwritten by the padded view features."""
+        """Per layer of the LDS-resident fp32 kernel (kernels_mlp_f32.hip): K segments (x_in0, kb0), (x_in1, kb1), the
+        output column x_out, tiles, relu, kind.  LDS row layout per sample: cols [0,W) activation buffer B, [W,2W) buffer A
+        (layers alternate: layer i writes A when i is even), [2W, 2W+max(xyz,32)) the encoding, later the padded view
+        features; `runs` = (x_col0, w_col0, ncols) per segment in k order."""
         a = self.arch
-        W, E = a.net_width, a.xyz_dim
+        W = a.net_width
+        enc_col = 2 * W
         layers = []
-        for op in self.ops:
-            cols = []   # list of (x_col0, w_col0, ncols) runs in natural order
+        cur = None                      # LDS column of the buffer holding the current activation
+        for oi, op in enumerate(self.ops):
+            out_col = 0 if cur == W else W
+            cols = []
             for s in op.segs:
-                if s.regset == "enc":
-                    cols.append((W, s.col0, s.ncols))
-                elif s.regset == "view":
-                    cols.append((W, s.col0, s.ncols))
-                else:
-                    cols.append((0, s.col0, s.ncols))
-            x_in = cols[0][0]
-            # runs are contiguous in LDS by construction ([0,W) then [W, W+..))
+                cols.append((enc_col if s.regset in ("enc", "view") else cur, s.col0, s.ncols))
             ktot = sum(_ceil(c[2], KSTEP) * KSTEP for c in cols)
-            layers.append(dict(name=op.name, x_in=x_in, kb=ktot // KSTEP, tiles=op.tiles, relu=op.relu,
-                               runs=cols, first_tile=op.first_tile))
+            segs = [(c[0], _ceil(c[2], KSTEP)) for c in cols] + [(0, 0)]
+            kind = 1 if op.name == "head" else (2 if op.out == "rgb" else 0)
+            layers.append(dict(name=op.name, x_in0=segs[0][0], kb0=segs[0][1], x_in1=segs[1][0], kb1=segs[1][1],
+                               x_out=out_col, kb=ktot // KSTEP, tiles=op.tiles, relu=op.relu, runs=cols,
+                               first_tile=op.first_tile, x_in=segs[0][0], kind=kind,
+                               stage_view=int(kind == 1 and a.use_viewdirs)))
+            if kind == 0 or (kind == 1 and len(op.tiles) > 1):
+                cur = out_col           # a head that is only the density row leaves the trunk output where it is
         return layers
 
     def pack_table_f32(self) -> np.ndarray:
@@ -372,16 +393,17 @@ def emulate_wave(plan: Plan, flat_params: np.ndarray, enc: np.ndarray, view: np.
                             acc[t, hi * 32:(hi + 1) * 32, r] += D[Plan.drow(hi, r), :]
         if op.relu:
             acc = np.maximum(acc, 0)
-        if op.out in ("X", "Y"):
+        if op.out in ("X", "Y") or op.name == "head":
             ntile_out = nt - (1 if op.name == "head" else 0)
             newreg = np.zeros((2 * ntile_out, 64, 8), np.float32)
             for t in range(ntile_out):
                 newreg[2 * t] = acc[t, :, 0:8]
                 newreg[2 * t + 1] = acc[t, :, 8:16]
-            regs[op.out] = rnd(newreg)
+            if ntile_out:
+                regs[op.out] = rnd(newreg)
             if op.name == "head":
                 result["density"] = acc[nt - 1, 0:32, 0].copy()     # lanes hi=0, register 0 -> row 0
         else:
             result["rgb"] = np.stack([acc[0, 0:32, r] for r in range(plan.arch.num_rgb)], axis=-1)
-    assert ci == len(plan.chunks)
+    assert ci == plan.n_real_chunks and all(c[0] < 0 for c in plan.chunks[ci:])
     return result["rgb"], result["density"]

@@ -241,8 +241,9 @@ class MLP(torch.nn.Module):
 
     def forward(self, x, view_direction=None, precision: Optional[int] = None, return_activated: bool = False):
         """x: [B, N, xyz_dim] encodings, view_direction: [B, view_dim] -> (raw_rgb [B,N,3], raw_density [B,N,1])."""
-        if view_direction is None:
-            raise NotImplementedError("use_viewdirs=False is not supported (mipnerf_create explains why)")
+        if (view_direction is None) != (not self._cfg_extra.get("use_viewdirs", 1)):
+            raise ValueError("MLP.forward: view_direction must be given exactly when the model was built with use_viewdirs=True "
+                             "(the native context is specialised on it)")
         prec = self.precision if precision is None else precision
         dt = torch.bfloat16 if prec == L.PREC_BF16 else torch.float32
         if not x.is_cuda:
@@ -253,13 +254,15 @@ class MLP(torch.nn.Module):
             # kernels, or torch's fp32 Linear ops in parity mode (autograd.py)
             from .autograd import mlp_native, mlp_native_f32
             venc = torch.zeros(B, 32, device=x.device, dtype=dt)
-            venc[:, :view_direction.shape[-1]] = view_direction.to(dt)
+            if view_direction is not None:
+                venc[:, :view_direction.shape[-1]] = view_direction.to(dt)
             raw = mlp_native(self, x.to(dt), venc) if prec == L.PREC_BF16 else mlp_native_f32(self, x.to(dt), venc)
             return raw[..., :3], raw[..., 3:4]
         ctx = self.native(x.device)
         enc = x.to(dt).contiguous()
         venc = torch.zeros(B, 32, device=x.device, dtype=dt)
-        venc[:, :view_direction.shape[-1]] = view_direction.to(dt)
+        if view_direction is not None:
+            venc[:, :view_direction.shape[-1]] = view_direction.to(dt)
         rgb_sigma = torch.empty(B, N, 4, device=x.device, dtype=torch.float32)
         raw = torch.empty_like(rgb_sigma)
         L.check(L.lib().mipnerf_mlp_forward(ctx.handle, B * N, N, enc.data_ptr(), venc.data_ptr(), prec,
@@ -305,8 +308,10 @@ class MipNerf(torch.nn.Module):
             raise NotImplementedError  # mip_nerf.py:165,170
         if not stop_resample_grad:
             raise NotImplementedError("stop_resample_grad=False is not implemented")
-        if not use_viewdirs:
-            raise NotImplementedError("use_viewdirs=False is not implemented")
+        if not use_viewdirs and mlp_net_width_condition != mlp_net_width:
+            # MLP.forward(x, None) feeds the trunk output to color_layer (mip_nerf.py:99-110): a shape error in the reference
+            raise NotImplementedError("use_viewdirs=False needs mlp_net_width_condition == mlp_net_width "
+                                      "(color_layer reads the trunk output; the reference fails on other shapes too)")
         mlp_xyz_dim = (max_deg_point - min_deg_point) * 3 * 2
         mlp_view_dim = deg_view * 3 * 2
         mlp_view_dim = mlp_view_dim + 3 if append_identity else mlp_view_dim

@@ -146,6 +146,44 @@ def noise_case(name, batch, num_samples, param_seed, gain, ray_seed, torch_seed,
     print(f"wrote {name}.npz (noise moves the fine rgb by up to {moved:.3f})")
 
 
+def variant_case(name, batch, num_samples, param_seed, gain, ray_seed, **ctor):
+    """Reference-legal constructor variants (mip_nerf.py:117-141): another MLP width, use_viewdirs=False.  Forward outputs
+    (deterministic, white background) + the training loss of nerf_system.py:99-111 and its gradients (l2, sum, samples) --
+    parameters the forward never touches (extra_layer / view_layers without view directions) have grad None there: stored
+    as zeros."""
+    arch = dict(net_width=ctor.get("mlp_net_width", 256), net_width_condition=ctor.get("mlp_net_width_condition", 128))
+    rays = orc.synthetic_rays(batch, seed=ray_seed, multiscale=True)
+    R = to_ref_rays(rays)
+    params = orc.make_params(seed=param_seed, density_gain=gain, **arch)
+    model = RefMipNerf(num_samples=num_samples, **ctor)
+    load_params(model, params)
+    gt = np.random.default_rng(3).uniform(0, 1, size=(batch, 3)).astype(np.float32)
+    rgbs = torch.from_numpy(gt)
+    ret = model(R, False, True)
+    mask = R.lossmult
+    losses, dls = [], []
+    for (rgb, _, _, w, t) in ret:
+        losses.append((mask * (rgb - rgbs[..., :3]) ** 2).sum() / mask.sum())
+        dls.append(refmip.distloss(w, t))
+    loss = 0.1 * (losses[0] + 0.01 * dls[0]) + losses[1] + 0.01 * dls[-1]
+    loss.backward()
+    out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain, gt=gt,
+               loss=np.float32(loss.item()), net_width=arch["net_width"], net_width_condition=arch["net_width_condition"],
+               use_viewdirs=int(ctor.get("use_viewdirs", True)))
+    out.update(ret_dict(ret, prefix="wb1_"))
+    for k, p in model.named_parameters():
+        g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().ravel()
+        stride = max(1, g.size // 64)
+        key = k.replace("mlp.", "")
+        out["g_l2_" + key] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["g_sum_" + key] = np.float64(g.astype(np.float64).sum())
+        out["g_smp_" + key] = g[::stride][:64].copy()
+    oret = orc.mipnerf_forward(params, rays, False, True, num_samples=num_samples, use_viewdirs=ctor.get("use_viewdirs", True))
+    check_oracle(name, ret, oret, 2e-4)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz loss={loss.item():.6f}")
+
+
 def stage_case(name, batch, num_samples, param_seed, gain, ray_seed):
     """Per-function goldens: every free function of models/mip.py on the hot path,
     called directly on the reference."""
@@ -364,14 +402,15 @@ TRAJ = dict(batch=256, num_samples=32, steps=300, nbatches=300, lr_init=2e-3, lr
             lr_delay_steps=30, lr_delay_mult=0.01, heldout=1024, param_seed=11, ray_seed=1000, rng_seed=4321)
 
 
-def trajectory_case(name, randomized, threads=None, save=True):
+def trajectory_case(name, randomized, threads=None, save=True, overrides=None, self_check=True):
     """K-step TRAINING trajectory of the unmodified reference: MipNerf + the loss of nerf_system.py:99-111 +
     torch.optim.Adam (nerf_system.py:71-72) + the reference's MipLRDecay (utils/lr_schedule.py:5-59), on fixed seeded
     batches.  Stored: loss / lr per step, held-out render PSNR, parameter norms at the end.  The randomized variant seeds
     torch's CPU generator with rng_seed + step before every forward, so a test can replay the two draws
     (mip.py:159 torch.rand, mip.py:201 uniform_) on the CPU and inject them."""
     from utils.lr_schedule import MipLRDecay as RefMipLRDecay
-    T = TRAJ
+    T = dict(TRAJ)
+    T.update(overrides or {})
     if threads is not None:
         torch.set_num_threads(threads)
     params = orc.make_params(seed=T["param_seed"], density_gain=1.0)
@@ -414,10 +453,15 @@ def trajectory_case(name, randomized, threads=None, save=True):
         out["pnorm_" + k] = np.float64(p.detach().double().norm().item())
     if not save:
         return out
+    if not self_check:
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(f"wrote {name}.npz  loss {losses[0]:.5f} -> {losses[-1]:.5f}, held-out PSNR {hpsnr:.3f} dB (train PSNR last 5: "
+              f"{[round(x, 2) for x in psnrs[-5:]]})")
+        return out
     # How far do two LEGITIMATE runs of the unmodified reference drift apart?  Same code, same seeds, 1 CPU thread instead
     # of all: only the summation order inside the GEMMs changes.  Training is chaotic (Adam divides by sqrt(v)), so this
     # self-divergence -- not fp32 epsilon -- is the resolution at which a loss CURVE can be compared after hundreds of steps.
-    alt = trajectory_case(name, randomized, threads=1, save=False)
+    alt = trajectory_case(name, randomized, threads=1, save=False, overrides=overrides)
     torch.set_num_threads(os.cpu_count())
     rel = np.abs(alt["loss"] - out["loss"]) / np.abs(out["loss"])
     out["self_rel_first20"] = np.float64(rel[:20].max())
@@ -432,6 +476,10 @@ def trajectory_case(name, randomized, threads=None, save=True):
 
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
+    if "--only-variants" in sys.argv:       # round 2: other reference-legal MLP shapes
+        variant_case("var_w128_48x64", 48, 64, param_seed=12, gain=20.0, ray_seed=12, mlp_net_width=128, mlp_net_width_condition=128)
+        variant_case("var_noview_48x64", 48, 64, param_seed=13, gain=20.0, ray_seed=13, mlp_net_width_condition=256, use_viewdirs=False)
+        sys.exit(0)
     if "--only-noise" in sys.argv:          # round 2: density_noise > 0
         noise_case("fwd_noise_48x64_trained", 48, 64, param_seed=9, gain=4.0, ray_seed=9, torch_seed=77, density_noise=1.0)
         sys.exit(0)
@@ -442,6 +490,10 @@ if __name__ == "__main__":
     if "--only-trajectory" in sys.argv:     # round 2: K-step training trajectories of the reference
         trajectory_case("traj_256x32_det", randomized=False)
         trajectory_case("traj_256x32_rand", randomized=True)
+        sys.exit(0)
+    if "--only-trajectory-long" in sys.argv:   # converged run: the LR decays 100x, the PSNR curve flattens (bf16 acceptance: 0.1 dB)
+        trajectory_case("traj_256x32_long", randomized=True, self_check=False,
+                        overrides=dict(steps=1500, nbatches=1500, max_steps=1500, lr_init=2e-3, lr_final=2e-5, lr_delay_steps=50))
         sys.exit(0)
     if "--only-metrics" in sys.argv:
         metrics_case("metrics_45x70")

@@ -69,17 +69,24 @@ def test_host_plan_tables_match_python_plan(lib, which, ref):
 def test_f32_layer_descriptors(lib):
     plan = Plan.build()
     n = lib.mipnerf_debug_f32net(None, 0)
-    buf = np.empty((n, 8), np.int32)
+    buf = np.empty((n, 12), np.int32)
     lib.mipnerf_debug_f32net(buf.ctypes.data, buf.size)
     layers = plan.f32_layers()
     assert n == len(layers)
     chunk0 = 0
-    for row, Ly in zip(buf, layers):
-        assert row[0] == Ly["x_in"] and row[1] == Ly["kb"] and row[2] == len(Ly["tiles"])
-        assert row[3] == Ly["first_tile"] and row[4] == int(Ly["relu"]) and row[6] == chunk0
+    W = plan.arch.net_width
+    for i, (row, Ly) in enumerate(zip(buf, layers)):
+        assert tuple(row[:5]) == (Ly["x_in0"], Ly["kb0"], Ly["x_in1"], Ly["kb1"], Ly["x_out"])
+        assert row[5] == len(Ly["tiles"]) and row[6] == Ly["first_tile"] and row[7] == int(Ly["relu"]) and row[8] == Ly["kind"]
+        assert row[9] == chunk0 and row[10] == int(Ly["kind"] == 1)
         chunk0 += len(Ly["tiles"]) * Ly["kb"]
-        assert row[7] == 356
-    assert [r[5] for r in buf] == [0] * 8 + [1, 0, 2]
+        assert row[11] == 2 * W + 96 + 4
+        # double buffering: a layer never writes the buffer it (or its second segment) reads
+        assert row[4] != row[0] and (row[3] == 0 or row[2] == 2 * W)
+        if i > 0 and Ly["kb0"] * 16 == W:
+            assert row[0] == buf[i - 1][4]                     # reads what the previous layer wrote
+    assert [r[8] for r in buf] == [0] * 8 + [1, 0, 2]
+    assert (buf[5][0], buf[5][1], buf[5][2], buf[5][3]) == (W, 16, 2 * W, 6)     # skip concat: [x | encoding]
 
 
 def test_register_dataflow_emulation_matches_oracle():
@@ -99,3 +106,57 @@ def test_register_dataflow_emulation_matches_oracle():
     rr, dd = orc.mlp_forward(params, enc[:, None, :], v27)
     np.testing.assert_allclose(rgb, rr[:, 0], atol=5e-6)
     np.testing.assert_allclose(dens, dd[:, 0, 0], atol=2e-5)
+
+
+def _variants():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "gen_mlp_bf16", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mipnerf_pl_amd", "csrc", "gen_mlp_bf16.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.VARIANTS
+
+
+def test_architecture_variants_exported(lib):
+    """Every MLP shape of gen_mlp_bf16.VARIANTS is carried by the library (mipnerf_variant_arch) and the C++ table
+    expansion of each equals mlp_plan.py (bf16 stream incl. its zero padding, bias table, fp32 stream)."""
+    variants = _variants()
+    assert lib.mipnerf_num_variants() == len(variants) == 3
+    for v, arch in enumerate(variants):
+        cfg, has_train = L.Config(), C.c_int(-1)
+        assert lib.mipnerf_variant_arch(v, C.byref(cfg), C.byref(has_train)) == 0
+        assert (cfg.net_depth, cfg.net_width, cfg.net_depth_condition, cfg.net_width_condition, cfg.skip_index,
+                bool(cfg.use_viewdirs)) == (arch.net_depth, arch.net_width, arch.net_depth_condition, arch.net_width_condition,
+                                            arch.skip_index, arch.use_viewdirs)
+        assert has_train.value == int(v == 0)
+        plan = Plan.build(arch)
+        for which, ref in ((0, "pack_table"), (1, "bias_table"), (2, "pack_table_f32")):
+            want = getattr(plan, ref)().astype(np.int32).ravel()
+            n = lib.mipnerf_debug_table_variant(v, which, None, 0)
+            got = np.empty(n, np.int32)
+            assert lib.mipnerf_debug_table_variant(v, which, got.ctypes.data, n) == n
+            if which == 2:      # the C++ table is sized like the bf16 stream; the fp32 stream fills its real chunks
+                assert n >= want.size and (got[want.size:] == -1).all()
+                got = got[:want.size]
+            np.testing.assert_array_equal(got, want)
+
+
+def test_variant_dataflow_emulation_matches_oracle():
+    """Register dataflow of the generated bf16 kernels for the non-default shapes (half-width trunk; no view directions:
+    density-only head, colour head on the trunk output), emulated in fp32, against the oracle MLP."""
+    for arch in _variants()[1:]:
+        plan = Plan.build(arch)
+        params = orc.make_params(seed=21, density_gain=10.0, net_width=arch.net_width, net_width_condition=arch.net_width_condition)
+        names = [n for n, _ in arch.param_shapes()]
+        assert names == list(params.keys())
+        flat = np.concatenate([params[n].ravel() for n in names])
+        rng = np.random.default_rng(1)
+        enc = rng.uniform(-1, 1, (32, 96)).astype(np.float32)
+        v27 = rng.uniform(-1, 1, (32, 27)).astype(np.float32)
+        view = np.zeros((32, 32), np.float32)
+        view[:, :27] = v27
+        rgb, dens = emulate_wave(plan, flat, enc, view)
+        rr, dd = orc.mlp_forward(params, enc[:, None, :], v27 if arch.use_viewdirs else None)
+        np.testing.assert_allclose(rgb, rr[:, 0], atol=5e-6)
+        np.testing.assert_allclose(dens, dd[:, 0, 0], atol=2e-5)

@@ -182,3 +182,65 @@ def test_density_noise_matches_reference(G, precision):
     with torch.no_grad():
         det0 = model0(rays, False, True)
     assert G.maxdiff(det[1][0], det0[1][0]) == 0.0
+
+
+VARIANT_KW = {"var_w128_48x64": dict(mlp_net_width=128, mlp_net_width_condition=128),
+              "var_noview_48x64": dict(mlp_net_width_condition=256, use_viewdirs=False)}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANT_KW))
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_constructor_variants_forward(G, name, precision):
+    """Reference-legal constructor values besides the shipped ones (mip_nerf.py:117-141): a 128-wide trunk, and
+    use_viewdirs=False (colour head on the trunk output, extra_layer / view_layers unused) -- goldens from the reference."""
+    g = G.load_golden(name)
+    arch = dict(net_width=int(g["net_width"]), net_width_condition=int(g["net_width_condition"]))
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]), **arch)
+    model = G.make_model(params, int(g["num_samples"]), precision, **VARIANT_KW[name])
+    with torch.no_grad():
+        ret = model(G.to_dev(G.rays_of(g)), False, True)
+    tol = G.TOL_FP32 if precision == "fp32" else G.TOL_BF16
+    errs = {}
+    for lvl in range(2):
+        for nm, val in zip(G.NAMES, ret[lvl]):
+            errs[f"l{lvl}_{nm}"] = G.maxdiff(val, g[f"wb1_l{lvl}_{nm}"])
+    G.record(f"variant {name} {precision}", **errs)
+    for k, e in errs.items():
+        assert e <= tol[k.split("_", 1)[1]], f"{name} {precision} {k}: {e}"
+
+
+@pytest.mark.parametrize("name", sorted(VARIANT_KW))
+def test_constructor_variants_train_fp32(G, name):
+    """Training of the non-default shapes runs in fp32 (fused fp32 MFMA forward + GEMM backward): loss and every parameter
+    gradient against the reference's autograd; the bf16 training kernels exist for the shipped shape only and must say so."""
+    from mipnerf_pl_amd.system import MipNeRFSystem, DEFAULT_HPARAMS
+    g = G.load_golden(name)
+    arch = dict(net_width=int(g["net_width"]), net_width_condition=int(g["net_width_condition"]))
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]), **arch)
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({'nerf.num_samples': int(g["num_samples"]), 'train.randomized': False, 'nerf.mlp.net_width': arch["net_width"],
+               'nerf.mlp.net_width_condition': arch["net_width_condition"], 'nerf.use_viewdirs': bool(int(g["use_viewdirs"]))})
+    rays, gt = G.to_dev(G.rays_of(g)), torch.from_numpy(g["gt"]).to(G.DEV)
+    system = MipNeRFSystem(hp, precision="fp32")
+    system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    system = system.to(G.DEV)
+    loss = system.training_step((rays, gt), 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-5 * max(1.0, float(g["loss"]))
+    worst = 0.0
+    for k, p in system.mip_nerf.mlp.named_parameters():
+        grad = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu().numpy().ravel()
+        l2 = float(g["g_l2_" + k])
+        stride = max(1, grad.size // 64)
+        smp = grad[::stride][:64]
+        scale = max(float(np.abs(g["g_smp_" + k]).max()), l2 / np.sqrt(grad.size), 1e-12)
+        err = float(np.max(np.abs(smp - g["g_smp_" + k]))) / scale
+        worst = max(worst, err)
+        assert abs(float(np.sqrt((grad.astype(np.float64) ** 2).sum())) - l2) <= 2e-3 * max(l2, 1e-9), k
+        assert err <= 2e-3, (k, err)
+    G.record(f"variant {name} fp32 train", worst_grad_rel=worst)
+    bsys = MipNeRFSystem(hp, precision="bf16")
+    bsys.load_state_dict(system.state_dict())
+    bsys = bsys.to(G.DEV)
+    with pytest.raises(NotImplementedError, match="bf16 training kernels"):
+        bsys.training_step((rays, gt), 0)
