@@ -204,6 +204,23 @@ int mipnerf_sorted_piecewise_constant_pdf(int64_t num_rays, int32_t num_bins, co
 int mipnerf_generate_rays(int64_t num_rays, const float* cameras, const int32_t* cam_idx,
                           const int32_t* pix_idx, const mipnerf_rays_out* out, void* stream);
 
+/* ---- unbounded scenes (mip-NeRF 360) --------------------------------------------------------------------------------
+ * Correct versions of what the reference's dead code aims at (models/mip.py:106-124 sample_along_rays_360, :38-47 full
+ * lift_gaussian, :424-447 contract / parameterization, :292-319 integrated_pos_enc_360); they follow Barron et al.,
+ * "Mip-NeRF 360" (CVPR 2022), see csrc/raymath360.hpp.  Parity: against oracle/mipnerf360_oracle.py ("parity unpinned":
+ * the reference code is broken and has no outputs to pin against).
+ * sample_along_rays_360: fence posts uniform in normalised inverse depth, t = 1 / (s / far + (1 - s) / near); t_rand [B,N+1]
+ *   (NULL = deterministic) jitters between midpoints in inverse-depth space.  Outputs t_inv, t_samples [B,N+1].
+ * cast_ipe_360: t [B,N+1] -> conical-frustum Gaussians with FULL covariance -> scene contraction of mean and covariance
+ *   (contracted != 0) -> off-axis IPE on 21 basis directions and frequencies 2^l, l in [min_deg, max_deg):
+ *   enc [B*N, 2*21*(max_deg-min_deg)] (fp32 or bf16; feature = half*21L + l*21 + basis).  means [B*N,3] / covs [B*N,3,3]
+ *   (both or neither; may be the only outputs, enc = NULL) receive the (contracted) Gaussians. */
+int mipnerf_sample_along_rays_360(int64_t num_rays, int32_t num_samples, const float* near, const float* far,
+                                  const float* t_rand, float* t_inv, float* t_samples, void* stream);
+int mipnerf_cast_ipe_360(int64_t num_rays, int32_t num_samples, int32_t min_deg, int32_t max_deg, int32_t contracted,
+                         const float* t_samples, const float* origins, const float* directions, const float* radii,
+                         void* enc, int out_dtype, float* means, float* covs, void* stream);
+
 /* ---- evaluation metrics: eval_errors (utils/metrics.py:191-197) on one frame: pred, gt [H,W,3] fp32 in [0,1];
  * out[0] = PSNR (metrics.py:182-188), out[1] = mean SSIM, 11x11 Gaussian window sigma 1.5, zero padding
  * (metrics.py:44-126).  workspace: mipnerf_eval_workspace_floats(H, W) floats. */

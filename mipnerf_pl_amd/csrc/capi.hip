@@ -511,6 +511,25 @@ int mipnerf_sorted_piecewise_constant_pdf(int64_t B, int32_t nbins, const float*
     return MIPNERF_OK;
 }
 
+// ---- unbounded scenes (mip-NeRF 360): what the reference's dead code at mip.py:106-124, 292-319, 424-447 aims at ----
+int mipnerf_sample_along_rays_360(int64_t B, int32_t N, const float* nearp, const float* farp, const float* t_rand,
+                                  float* t_inv, float* t_samples, void* stream) {
+    if (B < 1 || N < 1 || !nearp || !farp || !t_inv || !t_samples) return fail(MIPNERF_E_INVALID, "sample_along_rays_360: bad argument");
+    HIP_TRY(mip::launch_sample_along_rays_360(B, N, nearp, farp, t_rand, t_inv, t_samples, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_cast_ipe_360(int64_t B, int32_t N, int32_t min_deg, int32_t max_deg, int32_t contracted, const float* t,
+                         const float* origins, const float* dirs, const float* radii, void* enc, int out_dtype, float* means,
+                         float* covs, void* stream) {
+    if (B < 1 || N < 1 || !t || !origins || !dirs || !radii || (!enc && !means) || ((means == nullptr) != (covs == nullptr)))
+        return fail(MIPNERF_E_INVALID, "cast_ipe_360: bad argument");
+    if (min_deg < 0 || max_deg <= min_deg || max_deg > 31) return fail(MIPNERF_E_INVALID, "cast_ipe_360: need 0 <= min_deg < max_deg <= 31");
+    HIP_TRY(mip::launch_cast_ipe_360(B, N, min_deg, max_deg, contracted, t, origins, dirs, radii, enc,
+                                     out_dtype == MIPNERF_PREC_BF16, means, covs, S(stream)));
+    return MIPNERF_OK;
+}
+
 // ---- device-side ray generation (datasets/datasets.py:116-168, 214-263) ---------------------------------------
 int mipnerf_generate_rays(int64_t n, const float* cameras, const int32_t* cam_idx, const int32_t* pix_idx,
                           const mipnerf_rays_out* out, void* stream) {

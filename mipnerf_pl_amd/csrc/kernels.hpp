@@ -37,6 +37,13 @@ hipError_t launch_generate_rays(int64_t n, const float* cams, const int32_t* cam
                                 float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
                                 float* nearp, float* farp, hipStream_t st);
 
+// ---- kernels_360.hip (unbounded scenes: s-space sampling, contraction, off-axis IPE; raymath360.hpp) ----
+hipError_t launch_sample_along_rays_360(int64_t B, int N, const float* nearp, const float* farp, const float* t_rand,
+                                        float* t_inv, float* t, hipStream_t st);
+hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int contracted, const float* t, const float* origins,
+                               const float* dirs, const float* radii, void* enc, bool bf16, float* means, float* covs,
+                               hipStream_t st);
+
 // ---- kernels_train.hip ------------------------------------------------------------------------
 // dnoise (nullable): standard-normal draws [M]; the density pre-activation becomes raw + dnoise_scale * dnoise (mip_nerf.py:232-233)
 hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, const float* dnoise,

@@ -1,0 +1,92 @@
+// Unbounded-scene (mip-NeRF 360) ray path for gfx950: s-space sampling and the fused
+// frustum -> full-covariance Gaussian -> contraction -> off-axis integrated positional encoding kernel
+// (see raymath360.hpp for the math and why it follows the paper rather than the reference's dead code,
+// models/mip.py:106-124, 292-319, 424-447).  HBM-bound elementwise work: one thread per (sample, basis direction),
+// a wave writes runs of 21 consecutive features per frequency.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "raymath360.hpp"
+
+namespace mip {
+
+// fence posts uniform in normalised inverse depth (paper eq. (11)-(13), g(t) = 1/t); t_rand: stratified jitter
+// between the midpoints in inverse-depth space (models/mip.py:113-118)
+__global__ void __launch_bounds__(256)
+k_sample_along_rays_360(int64_t B, int N, const float* __restrict__ nearp, const float* __restrict__ farp,
+                        const float* __restrict__ t_rand, float* __restrict__ t_inv_out, float* __restrict__ t_out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * (int64_t)(N + 1)) return;
+    const int64_t b = gid / (N + 1);
+    const int i = (int)(gid - b * (N + 1));
+    const float ni = 1.0f / nearp[b], fi = 1.0f / farp[b];
+    auto post = [&](int k) {
+        const float s = torch_linspace_at(0.0f, 1.0f, N + 1, k);
+        return fi * s + (1.0f - s) * ni;
+    };
+    float ti = post(i);
+    if (t_rand) {
+        const float lo = i == 0 ? ti : 0.5f * (ti + post(i - 1));
+        const float up = i == N ? ti : 0.5f * (post(i + 1) + ti);
+        ti = lo + (up - lo) * t_rand[gid];
+    }
+    t_inv_out[gid] = ti;
+    t_out[gid] = 1.0f / ti;
+}
+
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+k_cast_ipe_360(int64_t B, int N, int min_deg, int L, int contracted, const float* __restrict__ t,
+               const float* __restrict__ origins, const float* __restrict__ dirs, const float* __restrict__ radii,
+               OutT* __restrict__ enc, float* __restrict__ means_out, float* __restrict__ covs_out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid / kBasis360N;
+    const int j = (int)(gid - s * kBasis360N);
+    if (s >= B * (int64_t)N) return;
+    const int64_t b = s / N;
+    const int i = (int)(s - b * N);
+    const float d[3] = {dirs[b * 3], dirs[b * 3 + 1], dirs[b * 3 + 2]};
+    const float o[3] = {origins[b * 3], origins[b * 3 + 1], origins[b * 3 + 2]};
+    GaussFull g = conical_frustum_to_gaussian_full(t[b * (N + 1) + i], t[b * (N + 1) + i + 1], d, o, radii[b]);
+    if (contracted) contract_gaussian(g);
+    if (j == 0 && means_out) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) means_out[s * 3 + a] = g.mean[a];
+        const float full[9] = {g.cov[0], g.cov[1], g.cov[2], g.cov[1], g.cov[3], g.cov[4], g.cov[2], g.cov[4], g.cov[5]};
+#pragma unroll
+        for (int a = 0; a < 9; ++a) covs_out[s * 9 + a] = full[a];
+    }
+    if (!enc) return;
+    float y, var;
+    project_360(g, j, y, var);
+    OutT* row = enc + s * (int64_t)(2 * kBasis360N * L);
+    for (int l = 0; l < L; ++l) {
+        row[l * kBasis360N + j] = (OutT)ipe360_feature(y, var, 0, l, min_deg);
+        row[(L + l) * kBasis360N + j] = (OutT)ipe360_feature(y, var, 1, l, min_deg);
+    }
+}
+
+hipError_t launch_sample_along_rays_360(int64_t B, int N, const float* nearp, const float* farp, const float* t_rand,
+                                        float* t_inv, float* t, hipStream_t st) {
+    const int64_t n = B * (int64_t)(N + 1);
+    hipLaunchKernelGGL(k_sample_along_rays_360, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, N, nearp, farp, t_rand,
+                       t_inv, t);
+    return hipGetLastError();
+}
+
+hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int contracted, const float* t, const float* origins,
+                               const float* dirs, const float* radii, void* enc, bool bf16, float* means, float* covs,
+                               hipStream_t st) {
+    const int64_t n = B * (int64_t)N * kBasis360N;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const int L = max_deg - min_deg;
+    if (bf16)
+        hipLaunchKernelGGL((k_cast_ipe_360<__bf16>), grid, block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii,
+                           (__bf16*)enc, means, covs);
+    else
+        hipLaunchKernelGGL((k_cast_ipe_360<float>), grid, block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii,
+                           (float*)enc, means, covs);
+    return hipGetLastError();
+}
+
+}  // namespace mip

@@ -1,0 +1,116 @@
+"""CPU oracle of the unbounded-scene (mip-NeRF 360) ray path  --  TEST INFRASTRUCTURE ONLY.
+
+Parity status: **PARITY UNPINNED.**  The reference's code for this path (models/mip.py:106-124
+`sample_along_rays_360`, :22-47 `lift_gaussian(diagonal=False)`, :292-319 `integrated_pos_enc_360`, :424-447
+`contract` / `parameterization`) is dead and cannot serve as ground truth: it is never called from MipNerf.forward,
+`parameterization` needs functorch names that are not imported (`vmap`, `jacrev`), REPLACES the covariance by the
+Jacobian instead of transforming it (mip.py:445), the full-covariance lift uses `t_var` for the perpendicular term
+(mip.py:43) and the off-axis encoding has no frequency scales (mip.py:316-319).  What is restated here is therefore the
+PUBLISHED algorithm the dead code aims at -- Barron et al., "Mip-NeRF 360: Unbounded Anti-Aliased Neural Radiance
+Fields", CVPR 2022 -- each function citing the paper equation it follows and the reference line it replaces:
+
+  sample_along_rays_360   s-space (normalised inverse depth) sampling, eq. (11)-(13) with g(t) = 1/t   [mip.py:106-124]
+  lift_gaussian_full      mu = d t_mu, Sigma = t_var d d^T + r_var (I - d d^T/|d|^2), mip-NeRF eq. (8)    [mip.py:38-47]
+  contract / contract_gaussian   eq. (10) and its linearisation f(mu), J_f(mu) Sigma J_f(mu)^T, eq. (9)  [mip.py:424-447]
+  integrated_pos_enc_360  off-axis IPE on the 21 directions of a twice-tessellated icosahedron (the same table the
+                          reference lists at mip.py:293-313), all frequencies 2^l, section "off-axis positional encoding"
+                          of the paper's supplement                                                        [mip.py:292-319]
+
+All arithmetic float32 like the rest of the path.
+"""
+import numpy as np
+
+from oracle.mipnerf_oracle import F32, _f32, expected_sin_mean, torch_linspace
+
+# mip.py:293-313: the 21 non-antipodal vertices of a twice-tessellated icosahedron (rows), transposed to [3, 21]
+BASIS_360 = np.array([[0.8506508, 0, 0.5257311], [0.809017, 0.5, 0.309017], [0.5257311, 0.8506508, 0], [1, 0, 0],
+                      [0.809017, 0.5, -0.309017], [0.8506508, 0, -0.5257311], [0.309017, 0.809017, -0.5],
+                      [0, 0.5257311, -0.8506508], [0.5, 0.309017, -0.809017], [0, 1, 0], [-0.5257311, 0.8506508, 0],
+                      [-0.309017, 0.809017, -0.5], [0, 0.5257311, 0.8506508], [-0.309017, 0.809017, 0.5],
+                      [0.309017, 0.809017, 0.5], [0.5, 0.309017, 0.809017], [0.5, -0.309017, 0.809017], [0, 0, 1],
+                      [-0.5, 0.309017, 0.809017], [-0.809017, 0.5, 0.309017], [-0.809017, 0.5, -0.309017]], dtype=F32).T
+
+
+def conical_frustum_moments(t0, t1, base_radius):
+    """t_mean, t_var, r_var of a conical frustum (mip-NeRF eq. (7), stable form; same expressions as mip.py:65-72)."""
+    t0, t1 = _f32(t0), _f32(t1)
+    mu = (t0 + t1) / F32(2)
+    hw = (t1 - t0) / F32(2)
+    den = F32(3) * mu ** 2 + hw ** 2
+    t_mean = mu + (F32(2) * mu * hw ** 2) / den
+    t_var = (hw ** 2) / F32(3) - F32(4 / 15) * ((hw ** 4 * (F32(12) * mu ** 2 - hw ** 2)) / den ** 2)
+    r_var = _f32(base_radius) ** 2 * ((mu ** 2) / F32(4) + F32(5 / 12) * hw ** 2 - F32(4 / 15) * (hw ** 4) / den)
+    return t_mean.astype(F32), t_var.astype(F32), r_var.astype(F32)
+
+
+def lift_gaussian_full(directions, t_mean, t_var, r_var):
+    """mip-NeRF eq. (8): mean = d t_mean, cov = t_var d d^T + r_var (I - d d^T / |d|^2)  -> ([B,N,3], [B,N,3,3])."""
+    d = _f32(directions)
+    mean = d[:, None, :] * t_mean[..., None]
+    d_outer = d[:, :, None] * d[:, None, :]
+    dn = np.sum(d ** 2, axis=-1, keepdims=True, dtype=F32) + F32(1e-10)
+    null_outer = np.eye(3, dtype=F32)[None] - d_outer / dn[..., None]
+    cov = t_var[..., None, None] * d_outer[:, None] + r_var[..., None, None] * null_outer[:, None]
+    return mean.astype(F32), cov.astype(F32)
+
+
+def sample_along_rays_360(origins, directions, radii, num_samples, near, far, randomized, t_rand=None):
+    """Paper eq. (11)-(13), g(t) = 1/t: fence posts uniform in s in [0, 1], t = 1 / (s / far + (1 - s) / near);
+    randomized: stratified jitter between the midpoints in inverse-depth space (as mip.py:113-118).
+    Returns (t_inv [B,N+1], t [B,N+1], (means [B,N,3], covs [B,N,3,3]))."""
+    near, far = _f32(near), _f32(far)
+    B = near.shape[0]
+    s = torch_linspace(0.0, 1.0, num_samples + 1)[None, :]
+    t_inv = (F32(1) / far) * s + (F32(1) - s) * (F32(1) / near)
+    if randomized:
+        mids = F32(0.5) * (t_inv[:, 1:] + t_inv[:, :-1])
+        upper = np.concatenate([mids, t_inv[:, -1:]], -1)
+        lower = np.concatenate([t_inv[:, :1], mids], -1)
+        t_inv = lower + (upper - lower) * _f32(t_rand)
+    t_inv = np.broadcast_to(t_inv, (B, num_samples + 1)).astype(F32)
+    t = (F32(1) / t_inv).astype(F32)
+    t_mean, t_var, r_var = conical_frustum_moments(t[:, :-1], t[:, 1:], _f32(radii))
+    mean, cov = lift_gaussian_full(directions, t_mean, t_var, r_var)
+    return t_inv, t, ((mean + _f32(origins)[:, None, :]).astype(F32), cov)
+
+
+def contract(x):
+    """Paper eq. (10): x if |x| <= 1 else (2 - 1/|x|) x / |x|."""
+    x = _f32(x)
+    n = np.sqrt(np.sum(x * x, axis=-1, keepdims=True, dtype=F32))
+    safe = np.maximum(n, F32(1e-30))
+    return np.where(n > 1, (F32(2) - F32(1) / safe) * x / safe, x).astype(F32)
+
+
+def contract_gaussian(mean, cov):
+    """Paper eq. (9)/(10): the Gaussian pushed through the contraction by linearisation, f(mu), J Sigma J^T, with
+    J = ((2|x| - 1)/|x|^2) (I - u u^T) + (1/|x|^2) u u^T, u = x/|x|, for |x| > 1 and J = I inside the unit ball."""
+    mean, cov = _f32(mean), _f32(cov)
+    n2 = np.sum(mean * mean, axis=-1, keepdims=True, dtype=F32)
+    n = np.sqrt(n2)
+    safe_n2 = np.maximum(n2, F32(1e-30))
+    u = mean / np.maximum(n, F32(1e-30))
+    uu = u[..., :, None] * u[..., None, :]
+    a = ((F32(2) * n - F32(1)) / safe_n2)[..., None]
+    b = (F32(1) / safe_n2)[..., None]
+    eye = np.eye(3, dtype=F32)
+    J = a * (eye - uu) + b * uu
+    outside = (n > 1)[..., None]
+    J = np.where(outside, J, eye).astype(F32)
+    cov_c = np.einsum("...ij,...jk,...lk->...il", J, cov, J).astype(F32)
+    return contract(mean), cov_c
+
+
+def integrated_pos_enc_360(means_covs, min_deg, max_deg, contracted=True):
+    """Off-axis integrated positional encoding: y = P^T mu, var = diag(P^T Sigma P) for the 21 basis directions P, every
+    frequency 2^l, l in [min_deg, max_deg); features [sin half | cos half], each half l-major then basis: [.., 2*21*L]."""
+    mean, cov = means_covs
+    if contracted:
+        mean, cov = contract_gaussian(mean, cov)
+    P = BASIS_360
+    y = (mean @ P).astype(F32)                                                  # [..., 21]
+    y_var = np.sum((cov @ P) * P, axis=-2, dtype=F32)                           # diag(P^T cov P)
+    scales = np.array([2.0 ** i for i in range(min_deg, max_deg)], dtype=F32)
+    yl = (y[..., None, :] * scales[:, None]).reshape(y.shape[:-1] + (-1,))
+    vl = (y_var[..., None, :] * scales[:, None] ** 2).reshape(y.shape[:-1] + (-1,))
+    return expected_sin_mean(np.concatenate([yl, yl + F32(0.5 * np.pi)], -1), np.concatenate([vl, vl], -1))
