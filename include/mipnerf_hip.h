@@ -291,7 +291,7 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* ctx, int64_t num_points, int32_t num_s
  * torch.optim.Adam(lr) + MipLRDecay of the reference (nerf_system.py:70-76, utils/lr_schedule.py:51-59).
  * *step_count (device int64, starts at 0) is incremented to t; the step runs with lr = MipLRDecay(last_epoch = t - 1)
  * (constant_lr > 0 overrides the schedule), bias corrections of step t, and grad * grad_scale (1 / world_size after a SUM
- * all-reduce).  hyper_out (device float[4]) receives lr, 1-beta1^t, sqrt(1-beta2^t), grad_scale (the `lr` that
+ * all-reduce).  hyper_out (device float[4]) receives lr, lr/(1-beta1^t), sqrt(1-beta2^t), grad_scale (the `lr` that
  * nerf_system.py:117 logs). */
 typedef struct mipnerf_lr_schedule {
     double lr_init, lr_final, lr_delay_mult, constant_lr;

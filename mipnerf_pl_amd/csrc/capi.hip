@@ -117,6 +117,7 @@ void build_tables(Tables& T, const PlanDesc& P) {
     const int ecols = kXyzDim > 32 ? kXyzDim : 32;
     net.enc_col = 2 * kNetWidth;
     net.dens_col = 2 * kNetWidth + ecols;
+    net.num_rgb = P.num_rgb;
     net.ldx = 2 * kNetWidth + ecols + 4;
     size_t cf = 0;
     int cur_col = -1;                  // LDS column of the buffer that holds the current activation (mlp_plan.f32_layers)
@@ -240,6 +241,17 @@ hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* view
     static const Fn table[mip::plan::kNumVariants] = {mip::launch_mlp_bf16, mip::launch_mlp_bf16_v1, mip::launch_mlp_bf16_v2};
     return table[c->P->variant](c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
                                 c->grid_limit, dma, rays, c->dnoise, c->cfg.density_noise, st);
+}
+
+// the fp32 kernel evaluates the two thin heads (density, colour) on the VALU straight from the fp32 master parameters
+mip::F32Net f32net_with_heads(const mipnerf_ctx* c) {
+    mip::F32Net net = c->tab.net;
+    const int D = c->P->net_depth, Dc = c->P->net_depth_cond;
+    net.dens_w = c->pp.p[2 * D];
+    net.dens_b = c->pp.p[2 * D + 1];
+    net.col_w = c->pp.p[2 * D + 4 + 2 * Dc];
+    net.col_b = c->pp.p[2 * D + 5 + 2 * Dc];
+    return net;
 }
 
 #define NEED_BF16_TRAIN(what)                                                                                               \
@@ -476,7 +488,7 @@ int mipnerf_mlp_forward(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, c
     if (precision == MIPNERF_PREC_BF16) {
         HIP_TRY(launch_bf16_variant(c, enc, viewenc, rgb_sigma, raw, M, N, c->mlp_dma != 0, nullptr, S(stream)));
     } else if (precision == MIPNERF_PREC_FP32) {
-        HIP_TRY(mip::launch_mlp_f32(c->tab.net, c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
+        HIP_TRY(mip::launch_mlp_f32(f32net_with_heads(c), c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
                                     rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, c->dnoise,
                                     c->cfg.density_noise, S(stream)));
     } else {
@@ -728,7 +740,7 @@ int mipnerf_mlp_forward_train_f32(mipnerf_ctx* c, int64_t M, int32_t N, const fl
     if (!c || M < 1 || N < 1 || !enc || !viewenc || !rgb_sigma || !raw || !save)
         return fail(MIPNERF_E_INVALID, "mlp_forward_train_f32: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train_f32: mipnerf_set_params has not been called");
-    HIP_TRY(mip::launch_mlp_f32(c->tab.net, c->d_stream_f32, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias,
+    HIP_TRY(mip::launch_mlp_f32(f32net_with_heads(c), c->d_stream_f32, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias,
                                 c->cfg.rgb_padding, save, nullptr, 0.0f, S(stream)));
     return MIPNERF_OK;
 }

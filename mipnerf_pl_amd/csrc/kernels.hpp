@@ -140,8 +140,13 @@ struct F32Net {
     int xyz_dim;
     int ldx;         // LDS row stride in floats: 2 * width + max(xyz_dim, 32) + 4
     int enc_col;     // 2 * width
-    int dens_col;    // spare column that carries the raw density from the head to the colour layer
-    int pad[2];
+    int dens_col;    // first spare column behind the encoding
+    int num_rgb;
+    int pad;
+    const float* dens_w;   // fp32 master parameters of the two thin heads (device pointers, set per launch):
+    const float* dens_b;   //   density_layer.weight [1, W] / .bias, color_layer.weight [num_rgb, K] / .bias
+    const float* col_w;
+    const float* col_b;
     F32Layer layers[kF32MaxLayers];
 };
 hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float* bias_tab, const float* enc,

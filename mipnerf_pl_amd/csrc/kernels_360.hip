@@ -47,8 +47,7 @@ k_cast_ipe_360(int64_t B, int N, int min_deg, int L, int contracted, const float
     const int i = (int)(s - b * N);
     const float d[3] = {dirs[b * 3], dirs[b * 3 + 1], dirs[b * 3 + 2]};
     const float o[3] = {origins[b * 3], origins[b * 3 + 1], origins[b * 3 + 2]};
-    GaussFull g = conical_frustum_to_gaussian_full(t[b * (N + 1) + i], t[b * (N + 1) + i + 1], d, o, radii[b]);
-    if (contracted) contract_gaussian(g);
+    const GaussFull g = conical_frustum_to_gaussian_full(t[b * (N + 1) + i], t[b * (N + 1) + i + 1], d, o, radii[b], contracted != 0);
     if (j == 0 && means_out) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) means_out[s * 3 + a] = g.mean[a];

@@ -16,8 +16,11 @@
 // Layers are computed swapped, D[out, sample] = W[out, k] * X^T[k, sample]: the A operand is
 // a pre-packed 2-KiB chunk of the weight (32 out-rows x 16 k, 8 fp32 per lane, read straight
 // from L2 with two dwordx4 loads, the next chunk in flight during the 16 MFMAs of the current one),
-// the B operand two ds_read_b128 of X per 32 samples.  Wave w owns out-tile w (and tile w + 8, the
-// density row of the head) and both 32-sample halves.
+// the B operand two ds_read_b128 of X per 32 samples.  Wave w owns out-tile w and both 32-sample halves.
+// The two THIN heads -- density (1 output row) and colour (3 rows) -- would each occupy a whole 32-row MFMA tile (97 %
+// zero rows) and serialise the workgroup behind one wave; they run on the VALU instead: wave w accumulates the k-slice
+// [K w / 8, K (w+1) / 8) of every sample's dot products as plain fp32 fma chains (weights by scalar loads from the fp32
+// master parameters), the partials meet in spare LDS columns and are summed in wave order.
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
@@ -29,7 +32,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kF32TileSamples = 64;
 constexpr int kF32Waves = 8;
-constexpr int kF32Rounds = 2;   // ceil(9 tiles / 8 waves); up to 16 tiles
+constexpr int kF32Rounds = 1;   // hidden tiles per wave: widths up to 256 (8 tiles); the thin heads run on the VALU
 
 __global__ void __launch_bounds__(kF32Waves * 64)
 k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __restrict__ bias_tab,
@@ -62,15 +65,15 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
         }
         __syncthreads();
 
-        float dens[2] = {0.0f, 0.0f};
         for (int L = 0; L < net.nlayers; ++L) {
             const F32Layer ly = net.layers[L];
             const int kbt = ly.kb0 + ly.kb1;
+            const int mfma_tiles = ly.kind == 2 ? 0 : (ly.kind == 1 ? ly.ntiles - 1 : ly.ntiles);   // thin heads: VALU below
             f32x16 acc[kF32Rounds][2];
 #pragma unroll
             for (int rd = 0; rd < kF32Rounds; ++rd) {
                 const int t = rd * kF32Waves + wave;             // wave-uniform
-                if (t < ly.ntiles) {
+                if (t < mfma_tiles) {
                     // accumulators start at the bias: lane (hi, .) register r <-> row (r&3)+8(r>>2)+4hi
                     const float* bp = bias_tab + ((size_t)(ly.first_tile + t) * 2 + hi) * 16;
 #pragma unroll
@@ -106,50 +109,47 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                         a1 = n1;
                     }
                     // ---- this tile's results: the OTHER activation buffer (nobody reads it during this layer)
-                    const bool is_density = (ly.kind == 1) && (t == ly.ntiles - 1);
-                    if (ly.kind == 2) {
-                        // colour head: rows 0..2 of tile 0 = lanes hi==0, registers 0..2 (wave 0 only)
-                        if (hi == 0) {
 #pragma unroll
-                            for (int nt = 0; nt < 2; ++nt) {
-                                const int64_t s = s0 + nt * 32 + n;
-                                if (s < M) {
-                                    const float r0 = acc[rd][nt][0], r1 = acc[rd][nt][1], r2 = acc[rd][nt][2];
-                                    const float dn = X[(nt * 32 + n) * ldx + net.dens_col];
-                                    // mip_nerf.py:232-233: raw_density += density_noise * randn, before the activation
-                                    const float nd = dnoise ? dn + dnoise_scale * dnoise[s] : dn;
-                                    rgb_sigma[s] = make_float4(rgb_activation(r0, rgb_padding),
-                                                               rgb_activation(r1, rgb_padding),
-                                                               rgb_activation(r2, rgb_padding),
-                                                               density_activation(nd, density_bias));
-                                    if (raw_out) raw_out[s] = make_float4(r0, r1, r2, dn);
-                                }
+                    for (int nt = 0; nt < 2; ++nt) {
+                        float* xo = X + (nt * 32 + n) * ldx + ly.x_out + t * 32 + hi * 4;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float4 v = make_float4(acc[rd][nt][4 * g], acc[rd][nt][4 * g + 1],
+                                                   acc[rd][nt][4 * g + 2], acc[rd][nt][4 * g + 3]);
+                            if (ly.relu) {
+                                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                                v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                             }
-                        }
-                    } else if (is_density) {
-                        // row 0 of the density tile (lanes hi == 0, register 0): parked in a spare LDS column until the
-                        // colour head (a different wave) needs it
-                        if (hi == 0) {
-                            X[n * ldx + net.dens_col] = acc[rd][0][0];
-                            X[(32 + n) * ldx + net.dens_col] = acc[rd][1][0];
-                        }
-                    } else {
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            float* xo = X + (nt * 32 + n) * ldx + ly.x_out + t * 32 + hi * 4;
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                float4 v = make_float4(acc[rd][nt][4 * g], acc[rd][nt][4 * g + 1],
-                                                       acc[rd][nt][4 * g + 2], acc[rd][nt][4 * g + 3]);
-                                if (ly.relu) {
-                                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                                    v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                                }
-                                *reinterpret_cast<float4*>(xo + 8 * g) = v;
-                            }
+                            *reinterpret_cast<float4*>(xo + 8 * g) = v;
                         }
                     }
                 }
+            }
+            if (ly.kind != 0) {
+                // ---- thin head on the VALU: lane = sample, wave = k-slice; nout = 1 (density, kind 1) or num_rgb (colour)
+                const int nout = ly.kind == 1 ? 1 : net.num_rgb;
+                const int K = ly.kb0 * 16;                          // in_features of the head (net_width / net_width_cond)
+                const int ks = K / kF32Waves;                       // k-slice of this wave (K is a multiple of 32)
+                const float* wrow = (ly.kind == 1 ? net.dens_w : net.col_w) + wave * ks;
+                const float* xr = X + lane * ldx + ly.x_in0 + wave * ks;
+                float part[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < ks; k += 4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xr + k);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < nout) {
+                            const float* wc = wrow + c * K + k;     // wave-uniform address: scalar loads
+                            part[c] = fmaf(xv.x, wc[0], part[c]);
+                            part[c] = fmaf(xv.y, wc[1], part[c]);
+                            part[c] = fmaf(xv.z, wc[2], part[c]);
+                            part[c] = fmaf(xv.w, wc[3], part[c]);
+                        }
+                }
+                // partials: spare encoding columns [ecol + 32, ecol + 32 + 8 * 4) of the sample's row (the view encoding uses
+                // [ecol, ecol + 32); the integrated encoding's last reader is behind a barrier); density keeps slot 4*w + 3
+                float* pr = X + lane * ldx + ecol + 32 + wave * 4;
+                if (ly.kind == 1) pr[3] = part[0];
+                else { pr[0] = part[0]; pr[1] = part[1]; pr[2] = part[2]; }
             }
             if (ly.stage_view) {
                 // the encoding has had its last reader (the skip layer is behind a barrier): put the (32-padded) view
@@ -164,6 +164,25 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                 }
             }
             __syncthreads();     // this layer's outputs are visible; its input buffer is free
+            if (ly.kind == 2 && wave == 0) {
+                // finalise: sum the 8 k-slice partials in wave order, add the biases, activations (mip_nerf.py:232-238)
+                const int64_t s = s0 + lane;
+                if (s < M) {
+                    const float* pr = X + lane * ldx + ecol + 32;
+                    float r[3] = {0.f, 0.f, 0.f}, dn = 0.f;
+#pragma unroll
+                    for (int w = 0; w < kF32Waves; ++w) {
+                        r[0] += pr[4 * w]; r[1] += pr[4 * w + 1]; r[2] += pr[4 * w + 2]; dn += pr[4 * w + 3];
+                    }
+                    const float r0 = r[0] + net.col_b[0], r1 = r[1] + net.col_b[1], r2 = r[2] + net.col_b[2];
+                    dn += net.dens_b[0];
+                    // mip_nerf.py:232-233: raw_density += density_noise * randn, before the activation
+                    const float nd = dnoise ? dn + dnoise_scale * dnoise[s] : dn;
+                    rgb_sigma[s] = make_float4(rgb_activation(r0, rgb_padding), rgb_activation(r1, rgb_padding),
+                                               rgb_activation(r2, rgb_padding), density_activation(nd, density_bias));
+                    if (raw_out) raw_out[s] = make_float4(r0, r1, r2, dn);
+                }
+            }
             if (save && ly.kind != 2) {
                 // training (parity mode): keep this layer's output -- slot L of `save` is [M, width] fp32, width =
                 // 32 x (hidden tiles); the density tile of the head is not part of the bottleneck.  The next layer
@@ -183,10 +202,14 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
     }
 }
 
-hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float* bias_tab, const float* enc,
+hipError_t launch_mlp_f32(const F32Net& net_in, const float* stream_w, const float* bias_tab, const float* enc,
                           const float* viewenc, float* rgb_sigma, float* raw_out, int64_t M, int num_samples,
                           float density_bias, float rgb_padding, float* save, const float* dnoise, float dnoise_scale,
                           hipStream_t st) {
+    const F32Net& net = net_in;
+    if (!net.dens_w || !net.dens_b || !net.col_w || !net.col_b || net.num_rgb > 3 || net.width > 32 * kF32Waves * kF32Rounds ||
+        net.ldx - net.enc_col - 4 < 64)      // VALU-head partials live in encoding columns [32, 64)
+        return hipErrorInvalidValue;
     const int ntiles = (int)((M + kF32TileSamples - 1) / kF32TileSamples);
     const int lds = kF32TileSamples * net.ldx * (int)sizeof(float);
     static int attr_lds = 0;

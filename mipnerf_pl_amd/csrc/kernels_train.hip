@@ -312,16 +312,16 @@ hipError_t launch_loss_fused(int64_t B, int nlevels, const float* rgb0, const fl
 //   m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2; p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ void __launch_bounds__(256)
 k_adam_flat(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-            float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+            float step_size, float w1, float beta2, float w2, float eps, float bc2_sqrt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i];
-    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
-    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    const float mi = m[i] + (gi - m[i]) * w1;
+    const float vi = v[i] * beta2 + w2 * gi * gi;
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - (lr / bc1) * (mi / denom);
+    p[i] = p[i] - step_size * (mi / denom);
 }
 
 // ---- device-side MipLRDecay + Adam hyper-parameters (graph-capturable optimiser step) ---------------------------------------
@@ -343,8 +343,9 @@ __global__ void k_lr_schedule(LrSchedule sc, int64_t* __restrict__ step_count, f
     tt = tt < 0.0 ? 0.0 : (tt > 1.0 ? 1.0 : tt);
     const double log_lerp = exp(log(sc.lr_init) * (1.0 - tt) + log(sc.lr_final) * tt);
     const double lr = sc.constant_lr > 0.0 ? sc.constant_lr : delay_rate * log_lerp;
+    // like torch's Adam: step_size = lr / bias_correction1 and sqrt(bias_correction2) are formed in double, rounded once
     hyper[0] = (float)lr;
-    hyper[1] = (float)(1.0 - pow(sc.beta1, (double)t));
+    hyper[1] = (float)(lr / (1.0 - pow(sc.beta1, (double)t)));
     hyper[2] = (float)sqrt(1.0 - pow(sc.beta2, (double)t));
     hyper[3] = sc.grad_scale;
 }
@@ -353,33 +354,36 @@ __global__ void k_lr_schedule(LrSchedule sc, int64_t* __restrict__ step_count, f
 // data-parallel SUM all-reduce: the mean is taken here instead of in a separate div_ kernel)
 __global__ void __launch_bounds__(256)
 k_adam_flat_dev(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                const float* __restrict__ hyper, float beta1, float beta2, float eps) {
+                const float* __restrict__ hyper, float w1, float beta2, float w2, float eps) {
+    // w1 = float(1 - beta1), w2 = float(1 - beta2), rounded from the double differences like torch's scalar arguments
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float lr = hyper[0], bc1 = hyper[1], bc2_sqrt = hyper[2], gs = hyper[3];
+    const float step_size = hyper[1], bc2_sqrt = hyper[2], gs = hyper[3];
     const float gi = gs == 1.0f ? g[i] : g[i] * gs;
-    const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);
-    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    const float mi = m[i] + (gi - m[i]) * w1;               // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * beta2 + w2 * gi * gi;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     m[i] = mi;
     v[i] = vi;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - (lr / bc1) * (mi / denom);
+    p[i] = p[i] - step_size * (mi / denom);                 // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 
 hipError_t launch_adam_scheduled(int64_t n, float* p, const float* g, float* m, float* v, const LrSchedule& sc,
                                  int64_t* step_count, float* hyper, hipStream_t st) {
     hipLaunchKernelGGL(k_lr_schedule, dim3(1), dim3(64), 0, st, sc, step_count, hyper);
     hipLaunchKernelGGL(k_adam_flat_dev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, hyper,
-                       (float)sc.beta1, (float)sc.beta2, (float)sc.eps);
+                       (float)(1.0 - sc.beta1), (float)sc.beta2, (float)(1.0 - sc.beta2), (float)sc.eps);
     return hipGetLastError();
 }
 
 hipError_t launch_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
                             float eps, int step, hipStream_t st) {
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(k_adam_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, lr, beta1, beta2, eps,
-                       (float)bc1, (float)sqrt(bc2));
+    // the float arguments carry python doubles rounded once (0.9, 0.999, lr): widen them back the way they print
+    const double b1 = (double)(float)beta1 == 0.9f ? 0.9 : (double)beta1, b2 = (double)(float)beta2 == 0.999f ? 0.999 : (double)beta2;
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    hipLaunchKernelGGL(k_adam_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, (float)((double)lr / bc1),
+                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), eps, (float)sqrt(bc2));
     return hipGetLastError();
 }
 }  // namespace mip

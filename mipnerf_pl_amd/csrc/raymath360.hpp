@@ -29,9 +29,29 @@ static const float kBasis360[kBasis360N][3] = {
     {0.309017f, 0.809017f, 0.5f}, {0.5f, 0.309017f, 0.809017f}, {0.5f, -0.309017f, 0.809017f}, {0.f, 0.f, 1.f},
     {-0.5f, 0.309017f, 0.809017f}, {-0.809017f, 0.5f, 0.309017f}, {-0.809017f, 0.5f, -0.309017f}};
 
-// mip-NeRF eq. (7) (stable form, as raymath.hpp) + eq. (8) with the FULL covariance:
-//   mean = d t_mean + o,   cov = t_var d d^T + r_var (I - d d^T / |d|^2)
-MIP_HD GaussFull conical_frustum_to_gaussian_full(float t0, float t1, const float d[3], const float o[3], float radius) {
+// Jacobian of contract() at x, |x| > 1 (symmetric): J = a (I - u u^T) + b u u^T, u = x/|x|, a = (2|x| - 1)/|x|^2, b = 1/|x|^2
+struct ContractJ {
+    float u[3], a, b, mean_scale;
+};
+MIP_HD ContractJ contract_jacobian(const float m[3], float n2) {
+    ContractJ c;
+    const float n = sqrtf(n2);
+    c.u[0] = m[0] / n; c.u[1] = m[1] / n; c.u[2] = m[2] / n;
+    c.a = (2.0f * n - 1.0f) / n2;
+    c.b = 1.0f / n2;
+    c.mean_scale = (2.0f - 1.0f / n) / n;
+    return c;
+}
+
+// mip-NeRF eq. (7) (stable form, as raymath.hpp) + eq. (8) with the FULL covariance
+//   mean = d t_mean + o,   cov = t_var d d^T + r_var (I - d d^T / |d|^2),
+// and, when `contracted`, the paper's eq. (9)/(10): mean' = contract(mean), cov' = J cov J^T.  The structure of cov is
+// used instead of a generic 3x3 triple product: with v = J d,
+//   cov' = t_var v v^T + r_var (J J^T - v v^T / |d|^2),   J J^T = a^2 (I - u u^T) + b^2 u u^T,
+// every term a well-scaled outer product (a generic J C J^T in fp32 loses ~1e-4 of the largest entry at |x| ~ 1e3,
+// where J's radial and tangential scales differ by |x| and C's by (t_var / r_var)).
+MIP_HD GaussFull conical_frustum_to_gaussian_full(float t0, float t1, const float d[3], const float o[3], float radius,
+                                                  bool contracted = false) {
     const float mu = (t0 + t1) / 2.0f;
     const float hw = (t1 - t0) / 2.0f;
     const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
@@ -41,37 +61,54 @@ MIP_HD GaussFull conical_frustum_to_gaussian_full(float t0, float t1, const floa
     const float r_var = (radius * radius) * (mu2 / 4.0f + (float)(5.0 / 12.0) * hw2 - (float)(4.0 / 15.0) * hw4 / den);
     const float dn = (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) + 1e-10f;
     GaussFull g;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g.mean[a] = d[a] * t_mean + o[a];
+    const float n2 = (g.mean[0] * g.mean[0] + g.mean[1] * g.mean[1]) + g.mean[2] * g.mean[2];
+    if (contracted && n2 > 1.0f) {
+        const ContractJ c = contract_jacobian(g.mean, n2);
+        const float ud = (c.u[0] * d[0] + c.u[1] * d[1]) + c.u[2] * d[2];
+        float v[3];                                   // v = J d = a d + (b - a) (u . d) u
+#pragma unroll
+        for (int a = 0; a < 3; ++a) v[a] = c.a * d[a] + ((c.b - c.a) * ud) * c.u[a];
+        const float a2 = c.a * c.a, b2a2 = c.b * c.b - a2;
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i; j < 3; ++j) {
+                const float vv = v[i] * v[j];
+                const float jj = (i == j ? a2 : 0.0f) + b2a2 * (c.u[i] * c.u[j]);       // (J J^T)_ij
+                g.cov[k++] = t_var * vv + r_var * (jj - vv / dn);
+            }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g.mean[a] *= c.mean_scale;
+        return g;
+    }
     int k = 0;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        g.mean[a] = d[a] * t_mean + o[a];
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = a; b < 3; ++b) {
             const float dd = d[a] * d[b];
             const float null_outer = (a == b ? 1.0f : 0.0f) - dd / dn;
             g.cov[k++] = t_var * dd + r_var * null_outer;
         }
-    }
     return g;
 }
 
-// Paper eq. (10) contract(x) = x (|x| <= 1), (2 - 1/|x|) x/|x| (|x| > 1), applied to a Gaussian by linearisation
-// (eq. (9)): mean' = contract(mean), cov' = J cov J^T with the (symmetric) Jacobian
-//   J = a (I - u u^T) + b u u^T,  u = x/|x|,  a = (2|x| - 1)/|x|^2,  b = 1/|x|^2.
+// contract() of an ARBITRARY Gaussian (paper eq. (9)/(10)): mean' = contract(mean), cov' = J cov J^T (generic triple
+// product; conditioned like |x| -- prefer the fused form above when the Gaussian comes from a conical frustum).
 MIP_HD void contract_gaussian(GaussFull& g) {
-    const float x = g.mean[0], y = g.mean[1], z = g.mean[2];
-    const float n2 = x * x + y * y + z * z;
+    const float n2 = (g.mean[0] * g.mean[0] + g.mean[1] * g.mean[1]) + g.mean[2] * g.mean[2];
     if (!(n2 > 1.0f)) return;
-    const float n = sqrtf(n2);
-    const float u[3] = {x / n, y / n, z / n};
-    const float a = (2.0f * n - 1.0f) / n2, b = 1.0f / n2;
+    const ContractJ c = contract_jacobian(g.mean, n2);
     float J[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const float uu = u[i] * u[j];
-            J[i][j] = a * ((i == j ? 1.0f : 0.0f) - uu) + b * uu;
+            const float uu = c.u[i] * c.u[j];
+            J[i][j] = c.a * ((i == j ? 1.0f : 0.0f) - uu) + c.b * uu;
         }
     const float C[3][3] = {{g.cov[0], g.cov[1], g.cov[2]}, {g.cov[1], g.cov[3], g.cov[4]}, {g.cov[2], g.cov[4], g.cov[5]}};
     float T[3][3];      // J C
@@ -84,8 +121,8 @@ MIP_HD void contract_gaussian(GaussFull& g) {
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = i; j < 3; ++j) g.cov[k++] = (T[i][0] * J[j][0] + T[i][1] * J[j][1]) + T[i][2] * J[j][2];   // (J C J^T)_ij
-    const float sc = (2.0f - 1.0f / n) / n;
-    g.mean[0] = x * sc; g.mean[1] = y * sc; g.mean[2] = z * sc;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g.mean[a] *= c.mean_scale;
 }
 
 // projection on basis direction j: y = p . mean, var = p^T cov p

@@ -243,3 +243,53 @@ def selftest() -> str:
     if rc != 0:
         raise RuntimeError(f"gfx950 self-test failed (code {rc:#x}): {msg}")
     return msg
+
+
+# ---- unbounded scenes (mip-NeRF 360) -------------------------------------------------------------------------------------
+# Working versions of the reference's dead functions (models/mip.py:106-124, 292-319, 424-447); they follow the paper the
+# dead code aims at (Barron et al., "Mip-NeRF 360", CVPR 2022) -- csrc/raymath360.hpp explains what is wrong upstream.
+def sample_t_360(num_samples, near, far, randomized, t_rand=None):
+    """Fence posts uniform in normalised inverse depth: (t_inv [B,N+1], t [B,N+1]) (mip.py:106-121)."""
+    near, far = _f32c(near, "near"), _f32c(far, "far")
+    B = near.shape[0]
+    if randomized and t_rand is None:
+        t_rand = torch.rand(B, num_samples + 1, device=near.device)
+    tr = _f32c(t_rand, "t_rand") if randomized else None
+    t_inv = torch.empty(B, num_samples + 1, device=near.device, dtype=torch.float32)
+    t = torch.empty_like(t_inv)
+    L.check(L.lib().mipnerf_sample_along_rays_360(B, num_samples, _ptr(near), _ptr(far), _ptr(tr), _ptr(t_inv), _ptr(t),
+                                                  _stream()), "sample_along_rays_360")
+    return t_inv, t
+
+
+def cast_rays_360(t_samples, origins, directions, radii, contracted=False):
+    """Conical frustums -> Gaussians with FULL covariance, optionally contracted: (means [B,N,3], covs [B,N,3,3])."""
+    t_samples = _f32c(t_samples, "t_samples")
+    B, N1 = t_samples.shape
+    means = torch.empty(B, N1 - 1, 3, device=t_samples.device, dtype=torch.float32)
+    covs = torch.empty(B, N1 - 1, 3, 3, device=t_samples.device, dtype=torch.float32)
+    o, d, r = _f32c(origins, "origins"), _f32c(directions, "directions"), _f32c(radii, "radii")
+    L.check(L.lib().mipnerf_cast_ipe_360(B, N1 - 1, 0, 1, int(bool(contracted)), _ptr(t_samples), _ptr(o), _ptr(d), _ptr(r), None,
+                                         L.PREC_FP32, _ptr(means), _ptr(covs), _stream()), "cast_rays_360")
+    return means, covs
+
+
+def sample_along_rays_360(origins, directions, radii, num_samples, near, far, randomized, disparity=False, ray_shape="cone",
+                          t_rand=None):
+    """models/mip.py:106-124 (same signature and return): (t_inv [B,N+1], (means [B,N,3], covs [B,N,3,3]))."""
+    if ray_shape != "cone":
+        raise NotImplementedError
+    t_inv, t = sample_t_360(num_samples, near, far, randomized, t_rand)
+    return t_inv, cast_rays_360(t, origins, directions, radii, contracted=False)
+
+
+def cast_ipe_360(t_samples, origins, directions, radii, min_deg, max_deg, contracted=True, precision=L.PREC_FP32):
+    """Fused frustum -> full-covariance Gaussian -> contraction -> off-axis IPE: [B, N, 2*21*(max_deg-min_deg)]; what
+    `integrated_pos_enc_360(parameterization(cast_rays(...)))` of the reference is meant to compute (mip.py:292-319, 431-447)."""
+    t_samples = _f32c(t_samples, "t_samples")
+    B, N1 = t_samples.shape
+    enc = torch.empty(B, N1 - 1, 42 * (max_deg - min_deg), device=t_samples.device, dtype=_torch_dtype(precision))
+    o, d, r = _f32c(origins, "origins"), _f32c(directions, "directions"), _f32c(radii, "radii")
+    L.check(L.lib().mipnerf_cast_ipe_360(B, N1 - 1, min_deg, max_deg, int(bool(contracted)), _ptr(t_samples), _ptr(o), _ptr(d),
+                                         _ptr(r), _ptr(enc), precision, None, None, _stream()), "cast_ipe_360")
+    return enc

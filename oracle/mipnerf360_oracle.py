@@ -16,7 +16,10 @@ Fields", CVPR 2022 -- each function citing the paper equation it follows and the
                           reference lists at mip.py:293-313), all frequencies 2^l, section "off-axis positional encoding"
                           of the paper's supplement                                                        [mip.py:292-319]
 
-All arithmetic float32 like the rest of the path.
+Arithmetic is float32 like the rest of the path, EXCEPT the contraction of the covariance (J Sigma J^T), which is
+evaluated in float64 and rounded: for far samples the Jacobian's radial and tangential scales differ by |x| (up to 1e3)
+and a float32 triple product loses ~1e-4 of the largest entry to cancellation, so a float32 restatement would be no
+ground truth for that step.
 """
 import numpy as np
 
@@ -54,7 +57,36 @@ def lift_gaussian_full(directions, t_mean, t_var, r_var):
     return mean.astype(F32), cov.astype(F32)
 
 
-def sample_along_rays_360(origins, directions, radii, num_samples, near, far, randomized, t_rand=None):
+def cast_rays_360(t_samples, origins, directions, radii, contracted):
+    """Conical frustums [t_i, t_i+1] -> Gaussians (mean [B,N,3], full cov [B,N,3,3]), optionally pushed through the scene
+    contraction (paper eq. (9)/(10)).  Evaluated end to end in float64 and rounded once: it is the ground truth the fused
+    kernel is held to (a float32 route through a rounded covariance is ~1e-4-conditioned at |x| ~ 1e3, see the header)."""
+    t = np.asarray(t_samples, np.float64)
+    t0, t1 = t[:, :-1], t[:, 1:]
+    mu, hw = (t0 + t1) / 2, (t1 - t0) / 2
+    den = 3 * mu ** 2 + hw ** 2
+    t_mean = mu + 2 * mu * hw ** 2 / den
+    t_var = hw ** 2 / 3 - (4 / 15) * (hw ** 4 * (12 * mu ** 2 - hw ** 2)) / den ** 2
+    r_var = np.asarray(radii, np.float64) ** 2 * (mu ** 2 / 4 + (5 / 12) * hw ** 2 - (4 / 15) * hw ** 4 / den)
+    d = np.asarray(directions, np.float64)
+    dn = (d ** 2).sum(-1, keepdims=True) + 1e-10
+    mean = d[:, None, :] * t_mean[..., None] + np.asarray(origins, np.float64)[:, None, :]
+    dout = d[:, :, None] * d[:, None, :]
+    cov = t_var[..., None, None] * dout[:, None] + r_var[..., None, None] * (np.eye(3)[None] - dout / dn[..., None])[:, None]
+    if contracted:
+        n2 = (mean ** 2).sum(-1, keepdims=True)
+        n = np.sqrt(n2)
+        u = mean / np.maximum(n, 1e-300)
+        uu = u[..., :, None] * u[..., None, :]
+        J = ((2 * n - 1) / np.maximum(n2, 1e-300))[..., None] * (np.eye(3) - uu) + (1 / np.maximum(n2, 1e-300))[..., None] * uu
+        outside = n2 > 1
+        J = np.where(outside[..., None], J, np.eye(3))
+        cov = np.einsum("...ij,...jk,...lk->...il", J, cov, J)
+        mean = np.where(outside, mean * ((2 - 1 / np.maximum(n, 1e-300)) / np.maximum(n, 1e-300)), mean)
+    return mean.astype(F32), cov.astype(F32)
+
+
+def sample_along_rays_360(origins, directions, radii, num_samples, near, far, randomized, t_rand=None, contracted=False):
     """Paper eq. (11)-(13), g(t) = 1/t: fence posts uniform in s in [0, 1], t = 1 / (s / far + (1 - s) / near);
     randomized: stratified jitter between the midpoints in inverse-depth space (as mip.py:113-118).
     Returns (t_inv [B,N+1], t [B,N+1], (means [B,N,3], covs [B,N,3,3]))."""
@@ -69,43 +101,43 @@ def sample_along_rays_360(origins, directions, radii, num_samples, near, far, ra
         t_inv = lower + (upper - lower) * _f32(t_rand)
     t_inv = np.broadcast_to(t_inv, (B, num_samples + 1)).astype(F32)
     t = (F32(1) / t_inv).astype(F32)
-    t_mean, t_var, r_var = conical_frustum_moments(t[:, :-1], t[:, 1:], _f32(radii))
-    mean, cov = lift_gaussian_full(directions, t_mean, t_var, r_var)
-    return t_inv, t, ((mean + _f32(origins)[:, None, :]).astype(F32), cov)
+    return t_inv, t, cast_rays_360(t, origins, directions, radii, contracted)
 
 
 def contract(x):
     """Paper eq. (10): x if |x| <= 1 else (2 - 1/|x|) x / |x|."""
     x = _f32(x)
-    n = np.sqrt(np.sum(x * x, axis=-1, keepdims=True, dtype=F32))
+    n2 = np.sum(x * x, axis=-1, keepdims=True, dtype=F32)
+    n = np.sqrt(n2)
     safe = np.maximum(n, F32(1e-30))
-    return np.where(n > 1, (F32(2) - F32(1) / safe) * x / safe, x).astype(F32)
+    return np.where(n2 > 1, x * ((F32(2) - F32(1) / safe) / safe), x).astype(F32)
 
 
 def contract_gaussian(mean, cov):
     """Paper eq. (9)/(10): the Gaussian pushed through the contraction by linearisation, f(mu), J Sigma J^T, with
     J = ((2|x| - 1)/|x|^2) (I - u u^T) + (1/|x|^2) u u^T, u = x/|x|, for |x| > 1 and J = I inside the unit ball."""
     mean, cov = _f32(mean), _f32(cov)
-    n2 = np.sum(mean * mean, axis=-1, keepdims=True, dtype=F32)
+    m64, c64 = mean.astype(np.float64), cov.astype(np.float64)
+    n2 = np.sum(m64 * m64, axis=-1, keepdims=True)
     n = np.sqrt(n2)
-    safe_n2 = np.maximum(n2, F32(1e-30))
-    u = mean / np.maximum(n, F32(1e-30))
+    safe_n2 = np.maximum(n2, 1e-300)
+    u = m64 / np.maximum(n, 1e-300)
     uu = u[..., :, None] * u[..., None, :]
-    a = ((F32(2) * n - F32(1)) / safe_n2)[..., None]
-    b = (F32(1) / safe_n2)[..., None]
-    eye = np.eye(3, dtype=F32)
+    a = ((2.0 * n - 1.0) / safe_n2)[..., None]
+    b = (1.0 / safe_n2)[..., None]
+    eye = np.eye(3)
     J = a * (eye - uu) + b * uu
-    outside = (n > 1)[..., None]
-    J = np.where(outside, J, eye).astype(F32)
-    cov_c = np.einsum("...ij,...jk,...lk->...il", J, cov, J).astype(F32)
+    outside = (np.sum(mean * mean, axis=-1, keepdims=True, dtype=F32) > 1)[..., None]     # the fp32 test the kernels make
+    J = np.where(outside, J, eye)
+    cov_c = np.einsum("...ij,...jk,...lk->...il", J, c64, J).astype(F32)
     return contract(mean), cov_c
 
 
-def integrated_pos_enc_360(means_covs, min_deg, max_deg, contracted=True):
+def integrated_pos_enc_360(means_covs, min_deg, max_deg, contracted=False):
     """Off-axis integrated positional encoding: y = P^T mu, var = diag(P^T Sigma P) for the 21 basis directions P, every
     frequency 2^l, l in [min_deg, max_deg); features [sin half | cos half], each half l-major then basis: [.., 2*21*L]."""
     mean, cov = means_covs
-    if contracted:
+    if contracted:          # contract here (generic J Sigma J^T); Gaussians from cast_rays_360(contracted=True) already are
         mean, cov = contract_gaussian(mean, cov)
     P = BASIS_360
     y = (mean @ P).astype(F32)                                                  # [..., 21]

@@ -2,6 +2,7 @@
 // kernels) with g++ so the per-sample formulas can be checked against the oracle without a GPU.
 // Build: g++ -O2 -ffp-contract=off -shared -fPIC hostmath.cpp -o _hostmath.so
 #include "../../mipnerf_pl_amd/csrc/raymath.hpp"
+#include "../../mipnerf_pl_amd/csrc/raymath360.hpp"
 
 extern "C" {
 void hm_cast(int n, const float* t0, const float* t1, const float* d, const float* o, const float* radius,
@@ -34,5 +35,24 @@ void hm_act(int n, const float* raw_rgb, const float* raw_density, float rgb_pad
 }
 void hm_linspace(float start, float end, int steps, float* out) {
     for (int i = 0; i < steps; ++i) out[i] = mip::torch_linspace_at(start, end, steps, i);
+}
+// mip-NeRF 360 path: frustum -> full-covariance Gaussian [-> contraction] -> off-axis IPE (raymath360.hpp)
+void hm_cast_ipe_360(int n, const float* t0, const float* t1, const float* d, const float* o, const float* radius, int contracted,
+                     int min_deg, int L, float* means, float* covs, float* enc) {
+    for (int i = 0; i < n; ++i) {
+        mip::GaussFull g = mip::conical_frustum_to_gaussian_full(t0[i], t1[i], d + 3 * i, o + 3 * i, radius[i], contracted == 1);
+        if (contracted == 2) mip::contract_gaussian(g);      // generic triple product (any covariance)
+        for (int a = 0; a < 3; ++a) means[3 * i + a] = g.mean[a];
+        const float full[9] = {g.cov[0], g.cov[1], g.cov[2], g.cov[1], g.cov[3], g.cov[4], g.cov[2], g.cov[4], g.cov[5]};
+        for (int a = 0; a < 9; ++a) covs[9 * i + a] = full[a];
+        for (int j = 0; j < mip::kBasis360N; ++j) {
+            float y, var;
+            mip::project_360(g, j, y, var);
+            for (int l = 0; l < L; ++l) {
+                enc[(size_t)i * 2 * 21 * L + l * 21 + j] = mip::ipe360_feature(y, var, 0, l, min_deg);
+                enc[(size_t)i * 2 * 21 * L + (L + l) * 21 + j] = mip::ipe360_feature(y, var, 1, l, min_deg);
+            }
+        }
+    }
 }
 }
