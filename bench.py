@@ -227,12 +227,14 @@ def run_train(args, e):
     system.mip_nerf.load_state_dict(model0.state_dict())
     system = system.to(e.dev)
     model = system.mip_nerf
-    system.fused_adam = not args.torch_adam         # FlatAdam: flat parameter / gradient buffers, one Adam kernel
+    # FlatAdam: flat parameter / gradient buffers, one Adam kernel (bf16 native path); fp32 parity mode trains through
+    # autograd with the optimiser the reference configures (torch.optim.Adam)
+    system.fused_adam = (not args.torch_adam) and args.precision == "bf16"
     (opt,), (sch,) = system.configure_optimizers()
     reduce_grads = FlatGradAllReduce(list(model.parameters()), mlp=model.mlp)
     gt = torch.rand(B, 3, device=e.dev)
     native = not args.autograd and args.precision == "bf16"
-    graphed = native and not args.torch_adam
+    graphed = native and system.fused_adam
     if graphed:
         # the whole step (draws + forward + loss + backward [+ all-reduce] + scheduled Adam + weight re-pack) replayed from
         # captured hipGraph(s); MipLRDecay runs on the device, the scheduler object only mirrors the epoch on the host
@@ -274,7 +276,7 @@ def run_train(args, e):
            "config": {"workload": (f"training step (randomized forward + loss incl. distloss + backward + one flat gradient all-reduce + "
                                    f"Adam + MipLRDecay), {B} rays x ({N}+{N}) samples per GPU"),
                       "mode": "train", "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
-                      "native_step": native, "fused_adam": not args.torch_adam,
+                      "native_step": native, "fused_adam": bool(system.fused_adam),
                       "hip_graph": bool(graphed and not args.no_graph), "lr_schedule": "device" if graphed else "host",
                       "parallelism": f"data-parallel x{e.world}, one {4 * sum(p.numel() for p in model.parameters())} B all-reduce per step"}}
     return rec
@@ -345,24 +347,35 @@ def cpu_baseline(args, rays_np, params):
     from oracle import ref as oref
     r = oref.load()
     if r is not None:
-        torch.set_num_threads(os.cpu_count())
         model = r.MipNerf(num_samples=N)
         model.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
         model.eval()
         RR = r.Rays(*[torch.from_numpy(np.asarray(a)) for a in rays_np])
         ts = []
         with torch.no_grad():
-            model(r.Rays(*[x[:256] for x in RR]), False, True)      # warm-up (thread pool, allocator)
-            model(RR, False, True)
+            # torch's CPU ops stop scaling long before 256 hardware threads (measured on the 2x64-core EPYC host: 32 threads
+            # 2.2e5 ray-samples/s, 256 threads 1.2e4): give the reference the thread count that is FASTEST for it here
+            sub = r.Rays(*[x[:512] for x in RR])
+            best, best_t = None, None
+            for th in sorted({t for t in (8, 16, 32, 64, os.cpu_count()) if t <= os.cpu_count()}):
+                torch.set_num_threads(th)
+                model(sub, False, True)
+                c0 = time.perf_counter()
+                model(sub, False, True)
+                dt_ = time.perf_counter() - c0
+                if best_t is None or dt_ < best_t:
+                    best, best_t = th, dt_
+            torch.set_num_threads(best)
+            model(RR, False, True)                                   # warm-up on the full batch
             for _ in range(3):
                 c0 = time.perf_counter()
                 model(RR, False, True)
                 ts.append(time.perf_counter() - c0)
         med = sorted(ts)[1]
-        return {"value": round(B * N * 2 / med, 1), "unit": "ray-samples/s", "cores": os.cpu_count(), "kind": "reference",
-                "cpu": cpu, "seconds_per_forward": round(med, 3),
+        return {"value": round(B * N * 2 / med, 1), "unit": "ray-samples/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
+                "kind": "reference", "cpu": cpu, "seconds_per_forward": round(med, 3),
                 "sample": f"median of 3 x the reference's MipNerf.forward (oracle/_ref, torch {torch.__version__} CPU, fp32, no_grad, "
-                          f"{torch.get_num_threads()} threads) on the full {B} rays x {N} samples x 2 levels batch"}
+                          f"{torch.get_num_threads()} threads = the fastest of 8/16/32/64/all on this host) on the full {B} rays x {N} samples x 2 levels batch"}
     from oracle import mipnerf_oracle as orc
     nb = 256
     sub = orc.Rays(*[a[:nb] for a in rays_np])

@@ -769,49 +769,55 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
     const int tDensW = 2 * D, tDensB = 2 * D + 1, tExW = 2 * D + 2, tExB = 2 * D + 3, tVW = 2 * D + 4, tVB = 2 * D + 5,
               tCW = 2 * D + 6, tCB = 2 * D + 7;
     const float* x8 = slot(D - 1);     // trunk output [M, W]
-    // wgrad / bias helpers: dW[out, ldw] (cols [col0, col0+n)) (+)= dY[M, out]^T X[M, n];  db[out] (+)= dY^T 1
-    auto wgrad = [&](const float* dY, int64_t ldy, int nout, const float* X, int64_t ldx, int rowdiv, int ncols, float* dW, int64_t ldw) {
-        return mip::launch_gemm_f32(true, nout, ncols, M, dY, ldy, X, ldx, rowdiv, false, dW, ldw, acc, splits, part, st);
+    // wgrad / bias helpers: dW[out, ldw] (cols [col0, col0+n)) (+)= dY[M, out]^T X[M, n];  db[out] (+)= dY^T 1.
+    // Shapes with >= 64 rows / columns go to the 128 x 128-tile kernel (bias gradient fused into its A-tile staging, ReLU mask
+    // fused into the dgrad epilogue); thin ones (colour / density heads, the 27 view features) to the 64 x 64 kernel.
+    auto wgrad = [&](const float* dY, int64_t ldy, int nout, const float* X, int64_t ldx, int rowdiv, int ncols, float* dW, int64_t ldw,
+                     float* db) -> hipError_t {
+        if (rowdiv == 1 && mip::gemm_f32_big_ok(nout, ncols, M, dY, ldy))
+            return mip::launch_gemm_f32_big(true, nout, ncols, M, dY, ldy, X, ldx, dW, ldw, acc, splits, part, nullptr, db, st);
+        hipError_t e = mip::launch_gemm_f32(true, nout, ncols, M, dY, ldy, X, ldx, rowdiv, false, dW, ldw, acc, splits, part, st);
+        if (e == hipSuccess && db) e = mip::launch_gemm_f32(true, nout, 1, M, dY, ldy, nullptr, 0, 1, true, db, 1, acc, splits, part, st);
+        return e;
     };
-    auto bgrad = [&](const float* dY, int64_t ldy, int nout, float* db) {
-        return mip::launch_gemm_f32(true, nout, 1, M, dY, ldy, nullptr, 0, 1, true, db, 1, acc, splits, part, st);
+    // dX[M, nin] = dY[M, nout] Wt[nout, ldw] (first nin columns), then (optionally) the ReLU mask of the layer input x
+    auto dgrad = [&](const float* dY, int64_t ldy, int nout, const float* Wt, int64_t ldw, int nin, float* dX, int64_t ldxo,
+                     const float* relu_x) -> hipError_t {
+        if (mip::gemm_f32_big_ok(Mi, nin, nout, dY, ldy))
+            return mip::launch_gemm_f32_big(false, Mi, nin, nout, dY, ldy, Wt, ldw, dX, ldxo, false, 1, nullptr, relu_x, nullptr, st);
+        hipError_t e = mip::launch_gemm_f32(false, Mi, nin, nout, dY, ldy, Wt, ldw, 1, false, dX, ldxo, false, 1, nullptr, st);
+        if (e == hipSuccess && relu_x) e = mip::launch_relu_mask((int64_t)M * nin, relu_x, dX, st);
+        return e;
     };
     if (views) {
         const float* hv = slot(D + 1);     // view-layer output [M, Wc]
         const float* bott = slot(D);       // bottleneck [M, W]
         // colour layer (mip_nerf.py:110): d_rgb = d_raw[:, 0:3]
-        HIP_TRY(wgrad(d_raw, 4, RGB, hv, Wc, 1, Wc, G(tCW), Wc));
-        HIP_TRY(bgrad(d_raw, 4, RGB, G(tCB)));
+        HIP_TRY(wgrad(d_raw, 4, RGB, hv, Wc, 1, Wc, G(tCW), Wc, G(tCB)));
         // g_hv = (d_rgb Wc) * relu'   [M, Wc] in g0
-        HIP_TRY(mip::launch_gemm_f32(false, Mi, Wc, RGB, d_raw, 4, P(tCW), Wc, 1, false, g0, Wc, false, 1, nullptr, st));
-        HIP_TRY(mip::launch_relu_mask((int64_t)M * Wc, hv, g0, st));
+        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, Wc, g0, Wc, hv));
         // view layer (mip_nerf.py:106-109): input [bottleneck | view encoding of the sample's ray]
-        HIP_TRY(wgrad(g0, Wc, Wc, bott, W, 1, W, G(tVW), W + V));
-        HIP_TRY(wgrad(g0, Wc, Wc, viewenc, 32, N, V, G(tVW) + W, W + V));
-        HIP_TRY(bgrad(g0, Wc, Wc, G(tVB)));
+        HIP_TRY(wgrad(g0, Wc, Wc, bott, W, 1, W, G(tVW), W + V, G(tVB)));
+        HIP_TRY(wgrad(g0, Wc, Wc, viewenc, 32, N, V, G(tVW) + W, W + V, nullptr));
         // g_bott = g_hv Wv[:, :W]   [M, W] in g1
-        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, Wc, g0, Wc, P(tVW), W + V, 1, false, g1, W, false, 1, nullptr, st));
+        HIP_TRY(dgrad(g0, Wc, Wc, P(tVW), W + V, W, g1, W, nullptr));
         // bottleneck (extra_layer, :102) and density head (:100)
-        HIP_TRY(wgrad(g1, W, W, x8, W, 1, W, G(tExW), W));
-        HIP_TRY(bgrad(g1, W, W, G(tExB)));
-        HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W));
-        HIP_TRY(bgrad(d_raw + 3, 4, 1, G(tDensB)));
+        HIP_TRY(wgrad(g1, W, W, x8, W, 1, W, G(tExW), W, G(tExB)));
+        HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W, G(tDensB)));
         // g8 = (g_bott We + d_den Wd) * relu'(x8)   in g0
-        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, W, g1, W, P(tExW), W, 1, false, g0, W, false, 1, nullptr, st));
+        HIP_TRY(dgrad(g1, W, W, P(tExW), W, W, g0, W, nullptr));
         HIP_TRY(mip::launch_gemm_f32(false, Mi, W, 1, d_raw + 3, 4, P(tDensW), W, 1, false, g0, W, true, 1, nullptr, st));
     } else {
         // MLP.forward(x, None) (mip_nerf.py:99-110): colour and density heads both read the trunk output; extra_layer and
         // view_layers are unused parameters (autograd leaves their .grad None; here: zero unless accumulating)
-        HIP_TRY(wgrad(d_raw, 4, RGB, x8, W, 1, W, G(tCW), Wc));
-        HIP_TRY(bgrad(d_raw, 4, RGB, G(tCB)));
-        HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W));
-        HIP_TRY(bgrad(d_raw + 3, 4, 1, G(tDensB)));
+        HIP_TRY(wgrad(d_raw, 4, RGB, x8, W, 1, W, G(tCW), Wc, G(tCB)));
+        HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W, G(tDensB)));
         if (!acc) {
             const int unused[4] = {tExW, tExB, tVW, tVB};
             for (int u = 0; u < 4; ++u)
                 HIP_TRY(hipMemsetAsync(G(unused[u]), 0, (size_t)PL.param_numel[unused[u]] * 4, st));
         }
-        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, RGB, d_raw, 4, P(tCW), Wc, 1, false, g0, W, false, 1, nullptr, st));
+        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, W, g0, W, nullptr));
         HIP_TRY(mip::launch_gemm_f32(false, Mi, W, 1, d_raw + 3, 4, P(tDensW), W, 1, false, g0, W, true, 1, nullptr, st));
     }
     HIP_TRY(mip::launch_relu_mask((int64_t)M * W, x8, g0, st));
@@ -821,12 +827,10 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
         const int ld = PL.param_numel[2 * i] / W;                    // in_features of layer i
         const float* xin = i == 0 ? enc : slot(i - 1);
         const int nin = i == 0 ? E : W;
-        HIP_TRY(wgrad(g, W, W, xin, nin, 1, nin, G(2 * i), ld));
-        if (ld > nin) HIP_TRY(wgrad(g, W, W, enc, E, 1, E, G(2 * i) + W, ld));      // skip concat (:96-97)
-        HIP_TRY(bgrad(g, W, W, G(2 * i + 1)));
+        HIP_TRY(wgrad(g, W, W, xin, nin, 1, nin, G(2 * i), ld, G(2 * i + 1)));
+        if (ld > nin) HIP_TRY(wgrad(g, W, W, enc, E, 1, E, G(2 * i) + W, ld, nullptr));      // skip concat (:96-97)
         if (i > 0) {
-            HIP_TRY(mip::launch_gemm_f32(false, Mi, W, W, g, W, P(2 * i), ld, 1, false, gn, W, false, 1, nullptr, st));
-            HIP_TRY(mip::launch_relu_mask((int64_t)M * W, slot(i - 1), gn, st));
+            HIP_TRY(dgrad(g, W, W, P(2 * i), ld, W, gn, W, slot(i - 1)));
             float* t = g; g = gn; gn = t;
         }
     }

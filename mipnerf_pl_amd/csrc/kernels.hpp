@@ -158,6 +158,10 @@ hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float*
 hipError_t launch_gemm_f32(bool trans_a, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                            int b_row_div, bool b_ones, float* C, int64_t ldc, bool accumulate, int splits, float* partial,
                            hipStream_t st);
+bool gemm_f32_big_ok(int M, int N, int64_t K, const float* A, int64_t lda);
+hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                               float* C, int64_t ldc, bool accumulate, int splits, float* partial, const float* relu_x,
+                               float* bias_out, hipStream_t st);
 hipError_t launch_relu_mask(int64_t n, const float* x, float* g, hipStream_t st);
 
 // ---- kernels_pack.hip ---------------------------------------------------------------------------

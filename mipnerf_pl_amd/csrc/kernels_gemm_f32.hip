@@ -79,6 +79,142 @@ k_gemm_f32(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda, co
     }
 }
 
+// ---- the big GEMMs of the backward: 128 x 128 output tile per workgroup (4 waves, each 64 x 64 = four 32x32 MFMA tiles),
+// K in blocks of 16 through a double-buffered LDS stage, global loads as float4 one block ahead (registers), so the 32
+// MFMAs (2048 cycles) of a block hide the next block's loads; ~3 workgroups per CU cover each other's barriers.
+//   TA = false (dgrad, dX = dY W):  A(m,k) = A[m*lda + k], rows = samples;   epilogue optionally applies the ReLU mask of the
+//                                   layer input (relu_x[m*ldc + n] <= 0 -> 0), fusing the separate mask pass
+//   TA = true  (wgrad, dW = dY^T X): A(m,k) = A[k*lda + m], contraction over samples, split-K over gridDim.z; the workgroups
+//                                   of column-tile 0 also produce the bias gradient db[m] = sum_k A(m,k) from the staged A tile
+//   B(k,n) = B[k*ldb + n].
+constexpr int GM = 128, GN = 128, GK = 16;
+template <bool TA>
+__global__ void __launch_bounds__(256)
+k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
+               float* __restrict__ C, int64_t ldc, int accumulate, float* __restrict__ partial, const float* __restrict__ relu_x,
+               float* __restrict__ bias_partial, int b_vec) {
+    __shared__ float As[2][GK][GM + 4];
+    __shared__ float Bs[2][GK][GN + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * GM;
+    const int n0 = blockIdx.y * GN;
+    const int64_t kchunk = ((K + gridDim.z - 1) / gridDim.z + GK - 1) / GK * GK;
+    const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+    const int64_t kend = kbeg + kchunk < K ? kbeg + kchunk : K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    // staging assignment: 128 x 16 (A) and 16 x 128 (B) floats = 512 float4 each, two per thread
+    float4 ra[2], rb[2];
+    auto load_tiles = [&](int64_t k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int f = tid + h * 256;              // float4 index in the tile
+            if (TA) {                                 // A(m,k) = A[k*lda + m]: contiguous along m
+                const int kk = f >> 5, mm = (f & 31) * 4;
+                const int64_t k = k0 + kk, m = m0 + mm;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kend) {
+                    const float* src = A + k * lda + m;
+                    if (m + 3 < M) v = *reinterpret_cast<const float4*>(src);
+                    else { if (m < M) v.x = src[0]; if (m + 1 < M) v.y = src[1]; if (m + 2 < M) v.z = src[2]; }
+                }
+                ra[h] = v;
+            } else {                                  // A(m,k) = A[m*lda + k]: contiguous along k
+                const int mm = f >> 2, kk = (f & 3) * 4;
+                const int64_t k = k0 + kk, m = m0 + mm;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < M) {
+                    const float* src = A + m * lda + k;
+                    if (k + 3 < kend) v = *reinterpret_cast<const float4*>(src);
+                    else { if (k < kend) v.x = src[0]; if (k + 1 < kend) v.y = src[1]; if (k + 2 < kend) v.z = src[2]; }
+                }
+                ra[h] = v;
+            }
+            {
+                const int kk = f >> 5, nn = (f & 31) * 4;
+                const int64_t k = k0 + kk;
+                const int n = n0 + nn;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < kend) {
+                    const float* src = B + k * ldb + n;
+                    if (b_vec && n + 3 < N) v = *reinterpret_cast<const float4*>(src);
+                    else { if (n < N) v.x = src[0]; if (n + 1 < N) v.y = src[1]; if (n + 2 < N) v.z = src[2]; if (n + 3 < N) v.w = src[3]; }
+                }
+                rb[h] = v;
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int f = tid + h * 256;
+            if (TA) {
+                const int kk = f >> 5, mm = (f & 31) * 4;
+                *reinterpret_cast<float4*>(&As[buf][kk][mm]) = ra[h];
+            } else {
+                const int mm = f >> 2, kk = (f & 3) * 4;
+                As[buf][kk][mm] = ra[h].x; As[buf][kk + 1][mm] = ra[h].y; As[buf][kk + 2][mm] = ra[h].z; As[buf][kk + 3][mm] = ra[h].w;
+            }
+            const int kk = f >> 5, nn = (f & 31) * 4;
+            *reinterpret_cast<float4*>(&Bs[buf][kk][nn]) = rb[h];
+        }
+    };
+    float bsum = 0.0f;                               // bias gradient: thread t < 128 sums row m0 + t of A over this split's k range
+    const bool want_bias = TA && bias_partial != nullptr && blockIdx.y == 0;
+    int buf = 0;
+    if (kbeg < kend) {
+        load_tiles(kbeg);
+        store_tiles(0);
+    }
+    __syncthreads();
+    for (int64_t k0 = kbeg; k0 < kend; k0 += GK) {
+        const bool more = k0 + GK < kend;
+        if (more) load_tiles(k0 + GK);               // next block's global loads fly during this block's MFMAs
+        if (want_bias && tid < GM) {
+#pragma unroll
+            for (int kk = 0; kk < GK; ++kk) bsum += As[buf][kk][tid];
+        }
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            const float a0 = As[buf][kr][wm * 64 + (lane & 31)], a1 = As[buf][kr][wm * 64 + 32 + (lane & 31)];
+            const float b0 = Bs[buf][kr][wn * 64 + (lane & 31)], b1 = Bs[buf][kr][wn * 64 + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) store_tiles(buf ^ 1);              // the other buffer: its last readers passed the previous barrier
+        __syncthreads();
+        buf ^= 1;
+    }
+    // D tile: lane (hi, n) register r <-> row (r&3) + 8(r>>2) + 4 hi, column n
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m >= M) continue;
+                float v = acc[i][j][r];
+                if (gridDim.z > 1) { partial[((int64_t)blockIdx.z * M + m) * N + n] = v; continue; }
+                if (relu_x && !(relu_x[m * ldc + n] > 0.0f)) v = 0.0f;
+                C[m * ldc + n] = accumulate ? C[m * ldc + n] + v : v;
+            }
+        }
+    if (want_bias && tid < GM && m0 + tid < M) bias_partial[(int64_t)blockIdx.z * M + m0 + tid] = bsum;
+}
+
 __global__ void __launch_bounds__(256)
 k_gemm_reduce(int M, int N, int splits, const float* __restrict__ partial, float* __restrict__ C, int64_t ldc, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -113,6 +249,38 @@ hipError_t launch_gemm_f32(bool trans_a, int M, int N, int64_t K, const float* A
         hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, M, N, splits, partial, C, ldc,
                            accumulate ? 1 : 0);
     }
+    return hipGetLastError();
+}
+
+bool gemm_f32_big_ok(int M, int N, int64_t K, const float* A, int64_t lda) {
+    return M >= 64 && N >= 64 && K >= 64 && lda % 4 == 0 && (uintptr_t)A % 16 == 0;
+}
+
+// Big-GEMM entry: same contract as launch_gemm_f32 plus (a) `relu_x` (dgrad only, splits == 1): C's element is zeroed where
+// relu_x[m*ldc + n] <= 0; (b) `bias_out` (wgrad only): db[m] (+)= sum_k A(m,k), reduced over the splits like C.
+// `partial` must hold splits * M * (N + 1) floats.  Falls back to the 64 x 64 kernel for thin shapes.
+hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                               float* C, int64_t ldc, bool accumulate, int splits, float* partial, const float* relu_x,
+                               float* bias_out, hipStream_t st) {
+    if (splits < 1) splits = 1;
+    if (!gemm_f32_big_ok(M, N, K, A, lda) || (relu_x && splits != 1) || (bias_out && !trans_a)) return hipErrorInvalidValue;
+    const int b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
+    const dim3 grid((unsigned)((M + GM - 1) / GM), (unsigned)((N + GN - 1) / GN), (unsigned)splits);
+    float* bias_partial = bias_out ? partial + (int64_t)splits * M * N : nullptr;
+    if (trans_a)
+        hipLaunchKernelGGL(k_gemm_f32_big<true>, grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0, partial,
+                           relu_x, bias_partial, b_vec);
+    else
+        hipLaunchKernelGGL(k_gemm_f32_big<false>, grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0, partial,
+                           relu_x, bias_partial, b_vec);
+    if (splits > 1) {
+        const int64_t n = (int64_t)M * N;
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, M, N, splits, partial, C, ldc,
+                           accumulate ? 1 : 0);
+    }
+    if (bias_out)
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, 1, splits, bias_partial, bias_out,
+                           (int64_t)1, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 
