@@ -417,7 +417,9 @@ class MipNerf(torch.nn.Module):
                 off += p.numel()
         return scalars, ret
 
-    def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None, density_randn=None):
+    def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None, density_randn=None, out=None):
+        """`out` (optional): preallocated per-level tuples (comp_rgb, distance, acc, weights, t_samples) to write into
+        (contiguous fp32 HIP tensors of the right shapes) instead of fresh tensors."""
         dev = rays.origins.device
         B, N = rays.origins.shape[0], self.num_samples
         ctx = self.mlp.native(dev)
@@ -430,11 +432,17 @@ class MipNerf(torch.nn.Module):
         outs = (L.LevelOut * self.num_levels)()
         ret = []
         for lvl in range(self.num_levels):
-            comp_rgb = torch.empty(B, 3, device=dev)
-            distance = torch.empty(B, device=dev)
-            acc = torch.empty(B, device=dev)
-            weights = torch.empty(B, N, device=dev)
-            t_samples = torch.empty(B, N + 1, device=dev)
+            if out is not None:
+                comp_rgb, distance, acc, weights, t_samples = out[lvl]
+                for t_, shp in ((comp_rgb, (B, 3)), (distance, (B,)), (acc, (B,)), (weights, (B, N)), (t_samples, (B, N + 1))):
+                    if tuple(t_.shape) != shp or t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev:
+                        raise ValueError(f"_forward_native: bad preallocated output {tuple(t_.shape)} (want {shp}, contiguous fp32 on {dev})")
+            else:
+                comp_rgb = torch.empty(B, 3, device=dev)
+                distance = torch.empty(B, device=dev)
+                acc = torch.empty(B, device=dev)
+                weights = torch.empty(B, N, device=dev)
+                t_samples = torch.empty(B, N + 1, device=dev)
             outs[lvl] = L.LevelOut(comp_rgb.data_ptr(), distance.data_ptr(), acc.data_ptr(), weights.data_ptr(),
                                    t_samples.data_ptr())
             ret.append((comp_rgb, distance, acc, weights, t_samples))
@@ -447,47 +455,57 @@ class MipNerf(torch.nn.Module):
         return ret
 
 
-class GraphedForward:
-    """hipGraph replay of `MipNerf.forward(rays, randomized=False, white_bkgd)` for a fixed chunk of rays
-    (BASELINE configs[4]: full-frame rendering = ~79 identical chunk launches; the ~20 kernel launches of one
-    chunk are captured once and replayed).  Inputs are copied into static buffers, outputs are static tensors
-    (valid until the next call); a ragged last chunk is padded with copies of its first ray and sliced."""
+class GraphedFrame:
+    """Whole-frame rendering from ONE captured hipGraph (BASELINE configs[4]: 800 x 800 = 640,000 rays in 8192-ray chunks =
+    79 chunk forwards, ~20 kernels each): every chunk launch reads its slice of a static full-frame ray buffer and writes its
+    slice of static full-frame outputs, so a frame is 7 ray copies + one graph launch -- no per-chunk copies, clones or
+    Python.  `__call__(rays)` takes flattened [n, k] rays and returns (coarse_rgb [n,3], fine_rgb [n,3], distance [n])
+    views of the static outputs (valid until the next call)."""
 
-    def __init__(self, model: "MipNerf", chunk: int, white_bkgd: bool, device: torch.device):
-        self.model, self.chunk, self.white_bkgd = model, int(chunk), bool(white_bkgd)
-        self.static_in = Rays(*[torch.zeros(self.chunk, k, device=device) for k in (3, 3, 3, 1, 1, 1, 1)])
-        for k in ("directions", "viewdirs"):          # valid dummy rays for the warm-up launches
+    def __init__(self, model: "MipNerf", num_rays: int, chunk: int, white_bkgd: bool, device: torch.device):
+        self.model, self.n, self.chunk, self.white_bkgd, self.dev = model, int(num_rays), int(chunk), bool(white_bkgd), device
+        self.static_in = Rays(*[torch.zeros(self.n, k, device=device) for k in (3, 3, 3, 1, 1, 1, 1)])
+        for k in ("directions", "viewdirs"):
             getattr(self.static_in, k)[:, 2] = 1.0
         self.static_in.radii.fill_(1e-3)
         self.static_in.near.fill_(2.0)
         self.static_in.far.fill_(6.0)
-        self.param_key = None
+        L_ = model.num_levels
+        self.rgb = [torch.zeros(self.n, 3, device=device) for _ in range(L_)]
+        self.dist = [torch.zeros(self.n, device=device) for _ in range(L_)]
+        self.acc = [torch.zeros(self.n, device=device) for _ in range(L_)]
         self.graph = None
-        self.static_out = None
+
+    def _run_chunks(self):
+        m, N = self.model, self.model.num_samples
+        scratch = {}
+        for lo in range(0, self.n, self.chunk):
+            hi = min(self.n, lo + self.chunk)
+            b = hi - lo
+            if b not in scratch:      # per-sample outputs nobody reads after the chunk: shared by all chunks of that size
+                scratch[b] = [(torch.empty(b, N, device=self.dev), torch.empty(b, N + 1, device=self.dev)) for _ in range(m.num_levels)]
+            out = [(self.rgb[l][lo:hi], self.dist[l][lo:hi], self.acc[l][lo:hi], scratch[b][l][0], scratch[b][l][1])
+                   for l in range(m.num_levels)]
+            m._forward_native(Rays(*[x[lo:hi] for x in self.static_in]), False, self.white_bkgd, out=out)
+        self._scratch = scratch
 
     def _capture(self):
-        m = self.model
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s), torch.no_grad():     # warm-up on a side stream: lazy init, workspace, packing
-            for _ in range(2):
-                m._forward_native(self.static_in, False, self.white_bkgd)
+        with torch.cuda.stream(s), torch.no_grad():     # warm-up on a side stream: lazy init, workspace growth, packing
+            self.model._forward_native(Rays(*[x[:min(self.n, self.chunk)] for x in self.static_in]), False, self.white_bkgd)
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
-            self.static_out = m._forward_native(self.static_in, False, self.white_bkgd)
+            self._run_chunks()
 
     def __call__(self, rays: Rays):
-        n = rays.origins.shape[0]
-        if n > self.chunk:
-            raise ValueError(f"GraphedForward captured for {self.chunk} rays, got {n}")
-        # the packed weight streams live in the context: re-pack OUTSIDE the graph when a parameter changed
-        self.model.mlp.native(rays.origins.device)
+        if rays.origins.shape[0] != self.n:
+            raise ValueError(f"GraphedFrame captured for {self.n} rays, got {rays.origins.shape[0]}")
+        self.model.mlp.native(self.dev)         # re-pack OUTSIDE the graph when a parameter changed
         if self.graph is None:
             self._capture()
         for dst, src in zip(self.static_in, rays):
-            dst[:n].copy_(src)
-            if n < self.chunk:
-                dst[n:].copy_(src[:1].expand(self.chunk - n, -1))
+            dst.copy_(src)
         self.graph.replay()
-        return [tuple(t[:n] for t in lvl) for lvl in self.static_out]
+        return self.rgb[0], self.rgb[-1], self.dist[-1]

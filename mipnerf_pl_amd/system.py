@@ -225,27 +225,31 @@ class MipNeRFSystem(_Base):
         self._graphed = None
         return self
 
-    def _chunk_forward(self, batch_rays):
-        if getattr(self, "use_hip_graph", False) and not self.val_randomized and batch_rays.origins.is_cuda:
-            from .model import GraphedForward
-            g = getattr(self, "_graphed", None)
-            if g is None or g.chunk != self.val_chunk_size or g.white_bkgd != bool(self.white_bkgd):
-                g = self._graphed = GraphedForward(self.mip_nerf, self.val_chunk_size, self.white_bkgd,
-                                                   batch_rays.origins.device)
-            return g(batch_rays)
-        return self(batch_rays, self.val_randomized, self.white_bkgd)
-
     def render_image(self, batch, return_distance=False):   # nerf_system.py:151-177
         rays, rgbs = batch
         _, height, width, _ = rgbs.shape
+        if getattr(self, "use_hip_graph", False) and not self.val_randomized and rays.origins.is_cuda:
+            # the whole frame = one captured hipGraph over static full-frame buffers (model.GraphedFrame)
+            from .model import GraphedFrame
+            flat = Rays(*[getattr(rays, k).reshape(-1, getattr(rays, k).shape[-1]) for k in Rays_keys])
+            val_mask = rays.lossmult
+            n = flat.origins.shape[0]
+            g = getattr(self, "_graphed", None)
+            if (not isinstance(g, GraphedFrame)) or g.n != n or g.chunk != self.val_chunk_size or g.white_bkgd != bool(self.white_bkgd):
+                g = self._graphed = GraphedFrame(self.mip_nerf, n, self.val_chunk_size, self.white_bkgd, flat.origins.device)
+            c_rgb, f_rgb, dist = g(flat)
+            coarse_rgb, fine_rgb = c_rgb.clone().reshape(1, height, width, -1), f_rgb.clone().reshape(1, height, width, -1)
+            if return_distance:
+                return coarse_rgb, fine_rgb, val_mask, dist.clone().reshape(1, height, width)
+            return coarse_rgb, fine_rgb, val_mask
         single_image_rays, val_mask = rearrange_render_image(rays, self.val_chunk_size)
         coarse_rgb, fine_rgb, distances = [], [], []
         with torch.no_grad():
             for batch_rays in single_image_rays:
-                (c_rgb, _, _, _, _), (f_rgb, distance, _, _, _) = self._chunk_forward(batch_rays)
-                coarse_rgb.append(c_rgb.clone() if getattr(self, "use_hip_graph", False) else c_rgb)
-                fine_rgb.append(f_rgb.clone() if getattr(self, "use_hip_graph", False) else f_rgb)
-                distances.append(distance.clone() if getattr(self, "use_hip_graph", False) else distance)
+                (c_rgb, _, _, _, _), (f_rgb, distance, _, _, _) = self(batch_rays, self.val_randomized, self.white_bkgd)
+                coarse_rgb.append(c_rgb)
+                fine_rgb.append(f_rgb)
+                distances.append(distance)
         coarse_rgb = torch.cat(coarse_rgb, dim=0).reshape(1, height, width, -1)
         fine_rgb = torch.cat(fine_rgb, dim=0).reshape(1, height, width, -1)
         if return_distance:

@@ -1,40 +1,40 @@
 #!/bin/bash
-# Round-end evidence: GPU test suite, inference bench + rocprof kernel stats, train bench + stats, PMC traffic passes
-# (FETCH_SIZE / WRITE_SIZE in separate passes, as the guide prescribes) for the MLP kernels.  usage: gpu_final.sh TAG
+# Round-end evidence (round 2): GPU test suite, the default bench line (headline + train + render sub-records), rocprofv3
+# kernel stats of the same command and of the fp32 / train-only runs, PMC traffic passes (FETCH_SIZE / WRITE_SIZE in
+# separate passes, as the guide prescribes).  usage: gpu_final.sh TAG     (everything lands in gpurun_out/TAG/)
 set -u
-TAG=${1:-r01i}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out
+OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
-rm -f $OUT/parity.jsonl
-timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/pytest_gpu_$TAG.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu_$TAG.log
-timeout 600 python bench.py --steps 50 --warmup 5 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench rc=$?"; cut -c1-300 $OUT/bench_$TAG.json
-timeout 600 python bench.py --mode train --steps 20 --warmup 3 > $OUT/bench_train_$TAG.json 2> /dev/null; cut -c1-200 $OUT/bench_train_$TAG.json
-timeout 600 python bench.py --mode render --steps 5 --warmup 2 --no-graph > $OUT/bench_render_$TAG.json 2> /dev/null; cut -c1-200 $OUT/bench_render_$TAG.json
+rm -f $ROOT/gpurun_out/parity.jsonl
+timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/pytest_gpu.log
+cp $ROOT/gpurun_out/parity.jsonl $OUT/parity.jsonl 2>/dev/null
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cut -c1-400 $OUT/bench.json
+timeout 300 python bench.py --precision fp32 --mode inference --no-cpu-baseline --sustain-seconds 0 --steps 10 > $OUT/bench_fp32.json 2>/dev/null; cut -c1-200 $OUT/bench_fp32.json
+timeout 300 python bench.py --precision fp32 --mode inference --no-cpu-baseline --sustain-seconds 0 --steps 5 --rays 8192 --samples 256 > $OUT/bench_fp32_c4.json 2>/dev/null
+timeout 300 python bench.py --precision fp32 --mode train --no-cpu-baseline --steps 5 --warmup 2 > $OUT/bench_fp32_train.json 2>/dev/null; cut -c1-200 $OUT/bench_fp32_train.json
+timeout 300 python bench.py --mode train --no-graph --steps 30 > $OUT/bench_train_eager.json 2>/dev/null
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/rocprof_$TAG.log 2>&1; echo "rocprof inference rc=$?"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_train_$TAG -o bench -- python $ROOT/bench.py --mode train --steps 7 --warmup 2 > $OUT/rocprof_train_$TAG.log 2>&1; echo "rocprof train rc=$?"
+stats() {  # name, args...
+  local name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o bench -- python $ROOT/bench.py "$@" > $OUT/rocprof_$name.log 2>&1; echo "rocprof $name rc=$?"
+  f=$(find $OUT/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
+  rm -rf $OUT/prof_$name
+}
+stats bench --no-cpu-baseline --sustain-seconds 0 --steps 20
+stats train --mode train --steps 10 --warmup 2 --no-graph
+stats fp32_train --precision fp32 --mode train --steps 3 --warmup 1
 for c in FETCH_SIZE WRITE_SIZE; do
-  # the headline kernel (fused-IPE k_mlp_bf16 launched by mipnerf_forward) as bench.py runs it
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcb_${TAG}_$c -o pmc -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmcb_${TAG}_$c.log 2>&1; echo "pmc bench $c rc=$?"
-  f=$(find $OUT/pmcb_${TAG}_$c -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python - "$f" <<'PY'
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py --mode inference --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 > $OUT/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
+  f=$(find $OUT/pmc_$c -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python - "$f" $c <<'PY' | tee -a $OUT/pmc_summary.txt
 import csv, sys
 v = [float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[1])) if "k_mlp_bf16" in r["Kernel_Name"]]
-print(f"  bench k_mlp_bf16 {sys.argv[1].split('_')[-3] if False else ''} mean per dispatch {sum(v)/max(1,len(v)):.6g} KB (n={len(v)})")
+print(f"{sys.argv[2]} k_mlp_bf16 mean per dispatch {sum(v)/max(1,len(v)):.6g} KB (n={len(v)})")
 PY
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${TAG}_$c -o pmc -- python $ROOT/scripts/prof_train.py --iters 3 > $OUT/pmc_${TAG}_$c.log 2>&1; echo "pmc $c rc=$?"
-  f=$(find $OUT/pmc_${TAG}_$c -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python - "$f" <<'PY'
-import csv, sys, collections
-acc = collections.defaultdict(list)
-for r in csv.DictReader(open(sys.argv[1])):
-    n = r["Kernel_Name"]
-    k = "wgrad" if "k_mlp_wgrad" in n else "trainfwd" if "trainfwd" in n else "dgrad" if "dgrad" in n else "infer" if "k_mlp_bf16" in n else None
-    if k: acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
-for (k, c), v in sorted(acc.items()):
-    print(f"  {k} {c}: mean per dispatch {sum(v)/len(v):.6g} KB (n={len(v)})")
-PY
+  rm -rf $OUT/pmc_$c
 done
+date
