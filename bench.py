@@ -400,10 +400,21 @@ def main():
     recs, inputs = {}, None
     if args.mode in ("all", "inference"):
         recs["inference"], inputs = run_inference(args, e)
+    def sub(name, fn):
+        # a sub-record must not take the headline down with it (mode all); a single-mode run fails loudly
+        if args.mode != "all":
+            return fn(args, e)
+        try:
+            return fn(args, e)
+        except Exception as ex:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return {"value": 0.0, "ms_per_step": None, "steps": 0, "warmup": 0, "scaling": None, "roofline": None,
+                    "config": {"mode": name}, "error": f"{type(ex).__name__}: {ex}"}
     if args.mode in ("all", "train"):
-        recs["train"] = run_train(args, e)
+        recs["train"] = sub("train", run_train)
     if args.mode in ("all", "render"):
-        recs["render"] = run_render(args, e)
+        recs["render"] = sub("render", run_render)
     head_mode = "inference" if "inference" in recs else args.mode
     head = recs.pop(head_mode)
     cpu = None

@@ -113,7 +113,8 @@ class _MLPNative(torch.autograd.Function):
         partials = nctx.scratch("partials", ctx.sizes[3])
         total = sum(int(torch.Size(s).numel()) for s in ctx.shapes)
         mlp = ctx.mlp
-        if mlp.grads_are_flat():
+        hooked = any(getattr(p, "_backward_hooks", None) for p in mlp.ordered_params())     # somebody wants to SEE the gradients
+        if mlp.grads_are_flat() and not hooked:
             # flat mode (MLP.flatten_parameters): the split reduction writes / adds straight into the buffer the
             # parameters' .grad alias -- no per-tensor gradient tensors, no autograd accumulation kernels
             L.check(L.lib().mipnerf_mlp_backward(nctx.handle, ctx.M, d_raw.data_ptr(), act.data_ptr(), masks.data_ptr(),

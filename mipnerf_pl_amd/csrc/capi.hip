@@ -243,6 +243,10 @@ hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* view
                                 c->grid_limit, dma, rays, c->dnoise, c->cfg.density_noise, st);
 }
 
+// split-K factor of the sample-contracted fp32 GEMMs: 2 x 2(3) output tiles x 192 splits = 768+ workgroups = 3 per CU (with
+// 64 splits every CU ran ONE 4-wave workgroup and nothing covered its barriers: 1.24 ms per 256 x 256 x 524288 wgrad)
+constexpr int kF32WgradSplits = 192;
+
 // the fp32 kernel evaluates the two thin heads (density, colour) on the VALU straight from the fp32 master parameters
 mip::F32Net f32net_with_heads(const mipnerf_ctx* c) {
     mip::F32Net net = c->tab.net;
@@ -727,9 +731,12 @@ size_t mipnerf_mlp_train_f32_bytes(const mipnerf_ctx* c, int64_t M, size_t* save
     if (!c || M < 1) return 0;
     const PlanDesc& P = *c->P;
     const size_t save = (size_t)P.num_ops * M * P.net_width * 4;          // one [M, width] slot per layer (op) of the plan
-    const int splits = 64;
+    const int splits = kF32WgradSplits;
     const size_t wmax = P.net_width > P.net_width_cond ? P.net_width : P.net_width_cond;
-    const size_t ws = 2 * (size_t)M * wmax * 4 + (size_t)splits * wmax * (wmax + P.xyz_dim + 32) * 4 + 1024;
+    size_t part = (size_t)splits * wmax * (wmax + P.xyz_dim + 32);                 // split-K partials of the big wgrad GEMMs
+    const size_t thin = (size_t)((M + 2047) / 2048) * 32 * (wmax + 1);              // per-slice partials of the thin ones
+    if (thin > part) part = thin;
+    const size_t ws = 2 * (size_t)M * wmax * 4 + part * 4 + 1024;
     if (save_bytes) *save_bytes = save;
     if (workspace_bytes) *workspace_bytes = ws;
     return save + ws;
@@ -755,7 +762,7 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
     if (PL.net_depth_cond != 1) return fail(MIPNERF_E_UNSUPPORTED, "mlp_backward_f32: one view layer (net_depth_condition = 1) only");
     const int W = PL.net_width, Wc = PL.net_width_cond, E = PL.xyz_dim, D = PL.net_depth, V = PL.view_dim, RGB = PL.num_rgb;
     const bool views = PL.use_viewdirs != 0;
-    const int splits = 64, Mi = (int)M;
+    const int splits = kF32WgradSplits, Mi = (int)M;
     hipStream_t st = S(stream);
     const size_t wmax = W > Wc ? W : Wc;
     float* g0 = reinterpret_cast<float*>(workspace);
@@ -776,6 +783,10 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
                      float* db) -> hipError_t {
         if (rowdiv == 1 && mip::gemm_f32_big_ok(nout, ncols, M, dY, ldy))
             return mip::launch_gemm_f32_big(true, nout, ncols, M, dY, ldy, X, ldx, dW, ldw, acc, splits, part, nullptr, db, st);
+        if (nout <= 4)            // colour / density heads: few output ROWS, wide in the input features
+            return mip::launch_thin_wgrad(M, ncols, nout, X, ldx, dY, ldy, 1, dW, 1, ldw, db, acc, part, st);
+        if (ncols <= 32 && !db)   // the view features: few input COLUMNS (one row of X per ray), wide in the output features
+            return mip::launch_thin_wgrad(M, nout, ncols, dY, ldy, X, ldx, rowdiv, dW, ldw, 1, nullptr, acc, part, st);
         hipError_t e = mip::launch_gemm_f32(true, nout, ncols, M, dY, ldy, X, ldx, rowdiv, false, dW, ldw, acc, splits, part, st);
         if (e == hipSuccess && db) e = mip::launch_gemm_f32(true, nout, 1, M, dY, ldy, nullptr, 0, 1, true, db, 1, acc, splits, part, st);
         return e;

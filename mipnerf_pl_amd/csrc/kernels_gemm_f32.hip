@@ -215,6 +215,53 @@ k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda
     if (want_bias && tid < GM && m0 + tid < M) bias_partial[(int64_t)blockIdx.z * M + m0 + tid] = bsum;
 }
 
+// ---- thin weight gradients (colour / density heads: 1-3 output rows; the 27 view features): HBM-bound reductions, not GEMMs.
+//   out[c * ldo_c + r * ldo_r] (+)= sum_s Xc[s * ldxc + c] * Yr[(s / rowdiv) * ldyr + r],   c < C ("wide", coalesced), r < R <= 32
+// plus, when `bias`, one extra column c == C with Xc == 1 (column sums of Yr -> out_bias[r]).  A workgroup = 64 columns x
+// 4 sample lanes over a slice of the samples; per-slice partials are summed by k_thin_reduce in slice order (deterministic).
+template <int RMAX>
+__global__ void __launch_bounds__(256)
+k_thin_wgrad(int64_t S, int C, int R, const float* __restrict__ Xc, int64_t ldxc, const float* __restrict__ Yr, int64_t ldyr,
+             int rowdiv, int bias, int64_t slice, float* __restrict__ partial) {
+    __shared__ float red[4][64][RMAX + 1];
+    const int col_l = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col_l;
+    const int CC = C + (bias ? 1 : 0);
+    const int64_t s0 = (int64_t)blockIdx.y * slice;
+    const int64_t s1 = s0 + slice < S ? s0 + slice : S;
+    float acc[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) acc[r] = 0.0f;
+    if (c < CC) {
+        for (int64_t s = s0 + sl; s < s1; s += 4) {
+            const float x = c < C ? Xc[s * ldxc + c] : 1.0f;
+            const float* y = Yr + (s / rowdiv) * ldyr;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r)
+                if (r < R) acc[r] = fmaf(x, y[r], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) red[sl][col_l][r] = acc[r];
+    __syncthreads();
+    if (sl == 0 && c < CC)
+        for (int r = 0; r < R; ++r)
+            partial[((int64_t)blockIdx.y * R + r) * CC + c] = ((red[0][col_l][r] + red[1][col_l][r]) + red[2][col_l][r]) + red[3][col_l][r];
+}
+
+__global__ void __launch_bounds__(256)
+k_thin_reduce(int nslices, int C, int R, int bias, const float* __restrict__ partial, float* __restrict__ out, int64_t ldo_c,
+              int64_t ldo_r, float* __restrict__ out_bias, int accumulate) {
+    const int CC = C + (bias ? 1 : 0);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * CC) return;
+    const int r = i / CC, c = i - r * CC;
+    float s = 0.0f;
+    for (int z = 0; z < nslices; ++z) s += partial[((int64_t)z * R + r) * CC + c];
+    float* dst = c < C ? out + c * ldo_c + r * ldo_r : out_bias + r;
+    *dst = accumulate ? *dst + s : s;
+}
+
 __global__ void __launch_bounds__(256)
 k_gemm_reduce(int M, int N, int splits, const float* __restrict__ partial, float* __restrict__ C, int64_t ldc, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,6 +328,25 @@ hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const floa
     if (bias_out)
         hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, 1, splits, bias_partial, bias_out,
                            (int64_t)1, accumulate ? 1 : 0);
+    return hipGetLastError();
+}
+
+// thin weight gradient (see k_thin_wgrad).  `partial` needs ceil(S / 2048) * R * (C + 1) floats.
+hipError_t launch_thin_wgrad(int64_t S, int C, int R, const float* Xc, int64_t ldxc, const float* Yr, int64_t ldyr, int rowdiv,
+                             float* out, int64_t ldo_c, int64_t ldo_r, float* out_bias, bool accumulate, float* partial,
+                             hipStream_t st) {
+    if (R < 1 || R > 32 || C < 1 || S < 1) return hipErrorInvalidValue;
+    const int64_t slice = 2048;
+    const int nslices = (int)((S + slice - 1) / slice);
+    const int bias = out_bias ? 1 : 0;
+    const dim3 grid((unsigned)((C + bias + 63) / 64), (unsigned)nslices);
+    if (R <= 4)
+        hipLaunchKernelGGL(k_thin_wgrad<4>, grid, dim3(256), 0, st, S, C, R, Xc, ldxc, Yr, ldyr, rowdiv, bias, slice, partial);
+    else
+        hipLaunchKernelGGL(k_thin_wgrad<32>, grid, dim3(256), 0, st, S, C, R, Xc, ldxc, Yr, ldyr, rowdiv, bias, slice, partial);
+    const int n = R * (C + bias);
+    hipLaunchKernelGGL(k_thin_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, nslices, C, R, bias, partial, out, ldo_c, ldo_r,
+                       out_bias, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -148,7 +148,14 @@ class MLP(torch.nn.Module):
     # -- flat parameter / gradient storage (opt-in: FlatAdam, FlatGradAllReduce, zero-copy wgrad reduction) -------
     def flatten_parameters(self):
         """Re-home the 24 parameters (and their .grad) as views of ONE flat fp32 buffer each, in state_dict order.
-        Call after the module is on its device.  Names, shapes, leaf-ness and state_dict() are unchanged."""
+        Call after the module is on its device.  Names, shapes, leaf-ness and state_dict() are unchanged.
+
+        Flat mode is for this package's own loop (FlatAdam, FlatGradAllReduce, GraphedTrainStep): the native backward
+        writes the gradient into the flat buffer as a SIDE EFFECT and returns no per-parameter gradients to autograd, so
+        AccumulateGrad nodes, tensor hooks and therefore torch's DistributedDataParallel reducer never fire, and
+        torch.autograd.grad() returns None for these parameters.  Under DDP / Lightning's DDP strategy keep the default
+        (non-flat) mode: there the backward returns ordinary gradients.  A parameter with a tensor hook makes the backward
+        fall back to returned gradients automatically."""
         params = self.ordered_params()
         dev = params[0].device
         total = sum(p.numel() for p in params)
@@ -495,9 +502,16 @@ class GraphedFrame:
         with torch.cuda.stream(s), torch.no_grad():     # warm-up on a side stream: lazy init, workspace growth, packing
             self.model._forward_native(Rays(*[x[:min(self.n, self.chunk)] for x in self.static_in]), False, self.white_bkgd)
         torch.cuda.current_stream().wait_stream(s)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self._run_chunks()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"), torch.no_grad():
+                self._run_chunks()
+            self.graph = graph
+        except RuntimeError as e:
+            import sys
+            print(f"[mipnerf_pl_amd] hipGraph capture of the frame failed ({e}); rendering eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            self.graph = False
 
     def __call__(self, rays: Rays):
         if rays.origins.shape[0] != self.n:
@@ -507,5 +521,9 @@ class GraphedFrame:
             self._capture()
         for dst, src in zip(self.static_in, rays):
             dst.copy_(src)
-        self.graph.replay()
+        if self.graph is False:
+            with torch.no_grad():
+                self._run_chunks()
+        else:
+            self.graph.replay()
         return self.rgb[0], self.rgb[-1], self.dist[-1]

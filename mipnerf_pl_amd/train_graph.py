@@ -83,6 +83,15 @@ class GraphedTrainStep:
         L.check(L.lib().mipnerf_set_params(self.ctx.handle, self._params, ops._stream()), "mipnerf_set_params")
 
     def _capture(self):
+        try:
+            self._capture_impl()
+        except RuntimeError as e:      # e.g. a collective library thread touching the device during a global-mode capture
+            import sys
+            print(f"[mipnerf_pl_amd] hipGraph capture of the training step failed ({e}); running it eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            self.use_graph, self._graphs = False, None
+
+    def _capture_impl(self):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         snap = self._snapshot()
@@ -94,15 +103,16 @@ class GraphedTrainStep:
         self._restore(snap)                 # the warm-up must not count as a training step
         if self.world == 1:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._fwd_bwd()
                 self._update()
             self._graphs = (g,)
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(ga, capture_error_mode="thread_local"):
                 self._fwd_bwd()
-            with torch.cuda.graph(gb):
+            with torch.cuda.graph(gb, capture_error_mode="thread_local"):
                 self._update()
             self._graphs = (ga, gb)
 
@@ -126,7 +136,7 @@ class GraphedTrainStep:
         if not mlp.grads_are_flat():
             raise RuntimeError("GraphedTrainStep: the parameters / gradients are no longer views of the flat buffers")
         if self.use_graph and self._graphs is None:
-            self._capture()
+            self._capture()          # may fall back to eager (sets use_graph False)
         if self.world == 1:
             if self.use_graph:
                 self._graphs[0].replay()

@@ -12,7 +12,7 @@ if [ "${2:-tests}" = "tests" ]; then
   [ -f gpurun_out/parity.jsonl ] && cp gpurun_out/parity.jsonl $OUT/parity.jsonl
 fi
 echo "== bench" ; date
-timeout 600 python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 4000 $OUT/bench.json; tail -5 $OUT/bench.err
+timeout 600 python bench.py --no-cpu-baseline --sustain-seconds 0.5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 4000 $OUT/bench.json; tail -5 $OUT/bench.err
 if [ -n "$3" ] && [ -f "$3" ]; then
   echo "== extra: $3"; date
   OUT=$OUT bash "$3" 2>&1 | tee $OUT/extra.log | tail -60

@@ -109,3 +109,56 @@ def test_flat_adam_state_dict_round_trip():
     assert o2.steps == 7 and o2.param_groups[0]["lr"] == 1e-3
     assert torch.equal(o2.exp_avg, o1.exp_avg) and torch.equal(o2.exp_avg_sq, o1.exp_avg_sq)
     assert o2.exp_avg.data_ptr() != o1.exp_avg.data_ptr()
+
+
+def test_system_derives_from_lightning_module_when_available():
+    """pytorch_lightning is not installed in this image, so the `_HAVE_PL` branch of system.py is exercised with a stand-in
+    that has LightningModule's relevant surface (save_hyperparameters -> self.hparams as an attribute dict, self.log):
+    the class must derive from it, build the same module tree / state_dict keys and run the host-side hooks."""
+    import importlib
+    import sys
+    import types
+    import torch
+
+    class AttributeDict(dict):
+        __getattr__ = dict.__getitem__
+
+    class LightningModule(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self._hparams = AttributeDict()
+            self._logged = {}
+
+        @property
+        def hparams(self):
+            return self._hparams
+
+        def save_hyperparameters(self, hp):
+            self._hparams = AttributeDict(hp)
+
+        def log(self, name, value, **kw):
+            self._logged[name] = value
+
+    stub = types.ModuleType("pytorch_lightning")
+    stub.LightningModule = LightningModule
+    import mipnerf_pl_amd.system as system_mod
+    sys.modules["pytorch_lightning"] = stub
+    try:
+        mod = importlib.reload(system_mod)
+        assert mod._HAVE_PL and issubclass(mod.MipNeRFSystem, LightningModule)
+        s = mod.MipNeRFSystem(dict(mod.DEFAULT_HPARAMS))
+        keys = list(s.state_dict().keys())
+        assert keys[0] == "mip_nerf.mlp.layers.0.0.weight" and keys[-1] == "mip_nerf.mlp.color_layer.bias" and len(keys) == 24
+        assert s.hparams['nerf.num_samples'] == 128
+        (opt,), (sch,) = s.configure_optimizers()           # torch.optim.Adam + MipLRDecay (nerf_system.py:70-76)
+        assert isinstance(opt, torch.optim.Adam) and sch["interval"] == "step"
+        lr0 = opt.param_groups[0]["lr"]
+        opt.step()
+        sch["scheduler"].step()
+        assert opt.param_groups[0]["lr"] > lr0                # warm-up
+        s._log_lr()
+        assert s._logged["lr"] == opt.param_groups[0]["lr"]   # nerf_system.py:117
+    finally:
+        del sys.modules["pytorch_lightning"]
+        importlib.reload(system_mod)
+    assert not system_mod._HAVE_PL
