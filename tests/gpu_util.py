@@ -24,7 +24,9 @@ TOL_FP32 = dict(rgb=5e-5, distance=2e-4, acc=5e-5, weights=5e-5, t_samples=2e-5)
 # ~0.04 and per-bin weights are no longer comparable bin-by-bin (up to 0.07); the rendered values stay close
 # (rgb <= 1.1e-2, acc <= 2.1e-2, distance <= 8e-2) and the PSNR of bf16 vs reference renders is ~75 dB, which
 # is the acceptance criterion (> 51.4 dB keeps a 35 dB render within 0.1 dB).
-TOL_BF16 = dict(rgb=3e-2, distance=0.2, acc=5e-2, weights=0.15, t_samples=0.1)
+# round 2: tightened to ~1.5x the largest value measured over every bf16 case incl. the full-size goldens
+# (rgb 1.1e-2, distance 7.9e-2, acc 2.1e-2, weights 7.1e-2, t_samples 4.0e-2)
+TOL_BF16 = dict(rgb=2e-2, distance=0.12, acc=3e-2, weights=0.1, t_samples=6e-2)
 NAMES = ("rgb", "distance", "acc", "weights", "t_samples")
 
 

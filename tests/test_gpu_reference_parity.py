@@ -73,8 +73,9 @@ def test_full_size_every_ray(G, name, precision):
             assert e <= tol, f"{name} fp32 {k}: {e} > {tol}"
     else:
         assert errs["psnr_l1_rgb"] > 55.0, errs
-        assert errs["l0_rgb"] <= 3e-2 and errs["l1_rgb"] <= 3e-2, errs
-        assert errs["l0_acc"] <= 5e-2 and errs["l1_acc"] <= 5e-2, errs
+        assert errs["l0_rgb"] <= 1e-2 and errs["l1_rgb"] <= 1e-2, errs            # measured 2.6e-3 over 8192 rays
+        assert errs["l0_acc"] <= 1e-2 and errs["l1_acc"] <= 1e-2, errs
+        assert errs["l1_distance"] <= 0.1, errs                                    # measured 2.2e-2
 
 
 # ---- training trajectories ------------------------------------------------------------------------------------------

@@ -223,7 +223,7 @@ def test_native_mlp_backward_equals_bf16_emulation(G, B, N):
     assert worst_em <= 1e-2, worst_em
     # bf16 operands (8-bit mantissa) for activations AND deltas through up to 10 chained layers: measured 0.11-0.13
     # relative L2 on layers.0.weight (the deepest gradient), < 0.05 on the heads
-    assert worst_or <= 0.25, worst_or
+    assert worst_or <= 0.2, worst_or       # measured 0.11-0.16 (white-noise upstream gradients: pure cancellation, the adversarial case)
     assert e_raw <= 2e-2 * max(1.0, float(np.abs(raw_em).max()))
 
 
