@@ -243,9 +243,9 @@ hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* view
                                 c->grid_limit, dma, rays, c->dnoise, c->cfg.density_noise, st);
 }
 
-// split-K factor of the sample-contracted fp32 GEMMs: 2 x 2(3) output tiles x 192 splits = 768+ workgroups = 3 per CU (with
+// split-K factor of the sample-contracted fp32 GEMMs: 1 x 2(3) output tiles (256 x 128) x 256 splits = 512+ eight-wave workgroups (with
 // 64 splits every CU ran ONE 4-wave workgroup and nothing covered its barriers: 1.24 ms per 256 x 256 x 524288 wgrad)
-constexpr int kF32WgradSplits = 192;
+constexpr int kF32WgradSplits = 256;
 
 // the fp32 kernel evaluates the two thin heads (density, colour) on the VALU straight from the fp32 master parameters
 mip::F32Net f32net_with_heads(const mipnerf_ctx* c) {

@@ -79,24 +79,27 @@ k_gemm_f32(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda, co
     }
 }
 
-// ---- the big GEMMs of the backward: 128 x 128 output tile per workgroup (4 waves, each 64 x 64 = four 32x32 MFMA tiles),
+// ---- the big GEMMs of the backward: 256 x 128 output tile per workgroup (8 waves, each 64 x 64 = four 32x32 MFMA tiles),
 // K in blocks of 16 through a double-buffered LDS stage, global loads as float4 one block ahead (registers), so the 32
-// MFMAs (2048 cycles) of a block hide the next block's loads; ~3 workgroups per CU cover each other's barriers.
+// MFMAs (2048 cycles) of a block hide the next block's loads; 3 workgroups per CU cover each other's barriers.
+// Tile shape: at fp32 MFMA rate a CU retires 292 FLOP/cycle; a 128 x 128 tile moves (128 + 128) x 4 B per 2 x 128 x 128 FLOP
+// = 9.1 B/cycle/CU, which IS the ~10 B/cycle/CU a CU can pull through global_load_dwordx4 (measured: 85 TF/s, 0.54);
+// 256 x 128 needs 6.8 B/cycle.
 //   TA = false (dgrad, dX = dY W):  A(m,k) = A[m*lda + k], rows = samples;   epilogue optionally applies the ReLU mask of the
 //                                   layer input (relu_x[m*ldc + n] <= 0 -> 0), fusing the separate mask pass
 //   TA = true  (wgrad, dW = dY^T X): A(m,k) = A[k*lda + m], contraction over samples, split-K over gridDim.z; the workgroups
 //                                   of column-tile 0 also produce the bias gradient db[m] = sum_k A(m,k) from the staged A tile
 //   B(k,n) = B[k*ldb + n].
-constexpr int GM = 128, GN = 128, GK = 16;
+constexpr int GM = 256, GN = 128, GK = 16, GT = 512;      // GT threads = 8 waves
 template <bool TA>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(GT)
 k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                float* __restrict__ C, int64_t ldc, int accumulate, float* __restrict__ partial, const float* __restrict__ relu_x,
                float* __restrict__ bias_partial, int b_vec) {
     __shared__ float As[2][GK][GM + 4];
     __shared__ float Bs[2][GK][GN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;      // wave tile: rows [64 wm, +64), columns [64 wn, +64)
     const int64_t m0 = (int64_t)blockIdx.x * GM;
     const int n0 = blockIdx.y * GN;
     const int64_t kchunk = ((K + gridDim.z - 1) / gridDim.z + GK - 1) / GK * GK;
@@ -109,14 +112,14 @@ k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    // staging assignment: 128 x 16 (A) and 16 x 128 (B) floats = 512 float4 each, two per thread
-    float4 ra[2], rb[2];
+    // staging assignment: A tile 256 x 16 floats = 1024 float4 (two per thread), B tile 16 x 128 = 512 float4 (one per thread)
+    float4 ra[2], rb[1];
     auto load_tiles = [&](int64_t k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int f = tid + h * 256;              // float4 index in the tile
+            const int f = tid + h * GT;               // float4 index in the A tile
             if (TA) {                                 // A(m,k) = A[k*lda + m]: contiguous along m
-                const int kk = f >> 5, mm = (f & 31) * 4;
+                const int kk = f >> 6, mm = (f & 63) * 4;
                 const int64_t k = k0 + kk, m = m0 + mm;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < kend) {
@@ -136,7 +139,10 @@ k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda
                 }
                 ra[h] = v;
             }
+        }
+        {
             {
+                const int h = 0, f = tid;
                 const int kk = f >> 5, nn = (f & 31) * 4;
                 const int64_t k = k0 + kk;
                 const int n = n0 + nn;
@@ -153,17 +159,17 @@ k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int f = tid + h * 256;
+            const int f = tid + h * GT;
             if (TA) {
-                const int kk = f >> 5, mm = (f & 31) * 4;
+                const int kk = f >> 6, mm = (f & 63) * 4;
                 *reinterpret_cast<float4*>(&As[buf][kk][mm]) = ra[h];
             } else {
                 const int mm = f >> 2, kk = (f & 3) * 4;
                 As[buf][kk][mm] = ra[h].x; As[buf][kk + 1][mm] = ra[h].y; As[buf][kk + 2][mm] = ra[h].z; As[buf][kk + 3][mm] = ra[h].w;
             }
-            const int kk = f >> 5, nn = (f & 31) * 4;
-            *reinterpret_cast<float4*>(&Bs[buf][kk][nn]) = rb[h];
         }
+        const int kk = tid >> 5, nn = (tid & 31) * 4;
+        *reinterpret_cast<float4*>(&Bs[buf][kk][nn]) = rb[0];
     };
     float bsum = 0.0f;                               // bias gradient: thread t < 128 sums row m0 + t of A over this split's k range
     const bool want_bias = TA && bias_partial != nullptr && blockIdx.y == 0;
@@ -315,10 +321,10 @@ hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const floa
     const dim3 grid((unsigned)((M + GM - 1) / GM), (unsigned)((N + GN - 1) / GN), (unsigned)splits);
     float* bias_partial = bias_out ? partial + (int64_t)splits * M * N : nullptr;
     if (trans_a)
-        hipLaunchKernelGGL(k_gemm_f32_big<true>, grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0, partial,
+        hipLaunchKernelGGL(k_gemm_f32_big<true>, grid, dim3(GT), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0, partial,
                            relu_x, bias_partial, b_vec);
     else
-        hipLaunchKernelGGL(k_gemm_f32_big<false>, grid, dim3(256), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0, partial,
+        hipLaunchKernelGGL(k_gemm_f32_big<false>, grid, dim3(GT), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0, partial,
                            relu_x, bias_partial, b_vec);
     if (splits > 1) {
         const int64_t n = (int64_t)M * N;
