@@ -782,7 +782,7 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
     auto wgrad = [&](const float* dY, int64_t ldy, int nout, const float* X, int64_t ldx, int rowdiv, int ncols, float* dW, int64_t ldw,
                      float* db) -> hipError_t {
         if (rowdiv == 1 && mip::gemm_f32_big_ok(nout, ncols, M, dY, ldy))
-            return mip::launch_gemm_f32_big(true, nout, ncols, M, dY, ldy, X, ldx, dW, ldw, acc, splits, part, nullptr, db, st);
+            return mip::launch_gemm_f32_big(true, nout, ncols, M, dY, ldy, X, ldx, dW, ldw, acc, splits, part, nullptr, nullptr, 0, nullptr, db, st);
         if (nout <= 4)            // colour / density heads: few output ROWS, wide in the input features
             return mip::launch_thin_wgrad(M, ncols, nout, X, ldx, dY, ldy, 1, dW, 1, ldw, db, acc, part, st);
         if (ncols <= 32 && !db)   // the view features: few input COLUMNS (one row of X per ray), wide in the output features
@@ -791,12 +791,16 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
         if (e == hipSuccess && db) e = mip::launch_gemm_f32(true, nout, 1, M, dY, ldy, nullptr, 0, 1, true, db, 1, acc, splits, part, st);
         return e;
     };
-    // dX[M, nin] = dY[M, nout] Wt[nout, ldw] (first nin columns), then (optionally) the ReLU mask of the layer input x
+    // dX[M, nin] = dY[M, nout] Wt[nout, ldw] (first nin columns) [+ r1_col[m * r1_ld] * r1_row[n]], then (optionally) the ReLU
+    // mask of the layer input x
     auto dgrad = [&](const float* dY, int64_t ldy, int nout, const float* Wt, int64_t ldw, int nin, float* dX, int64_t ldxo,
-                     const float* relu_x) -> hipError_t {
+                     const float* relu_x, const float* r1_col = nullptr, int64_t r1_ld = 0, const float* r1_row = nullptr) -> hipError_t {
         if (mip::gemm_f32_big_ok(Mi, nin, nout, dY, ldy))
-            return mip::launch_gemm_f32_big(false, Mi, nin, nout, dY, ldy, Wt, ldw, dX, ldxo, false, 1, nullptr, relu_x, nullptr, st);
+            return mip::launch_gemm_f32_big(false, Mi, nin, nout, dY, ldy, Wt, ldw, dX, ldxo, false, 1, nullptr, relu_x, r1_col, r1_ld,
+                                            r1_row, nullptr, st);
         hipError_t e = mip::launch_gemm_f32(false, Mi, nin, nout, dY, ldy, Wt, ldw, 1, false, dX, ldxo, false, 1, nullptr, st);
+        if (e == hipSuccess && r1_col)
+            e = mip::launch_gemm_f32(false, Mi, nin, 1, r1_col, r1_ld, r1_row, nin, 1, false, dX, ldxo, true, 1, nullptr, st);
         if (e == hipSuccess && relu_x) e = mip::launch_relu_mask((int64_t)M * nin, relu_x, dX, st);
         return e;
     };
@@ -815,9 +819,8 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
         // bottleneck (extra_layer, :102) and density head (:100)
         HIP_TRY(wgrad(g1, W, W, x8, W, 1, W, G(tExW), W, G(tExB)));
         HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W, G(tDensB)));
-        // g8 = (g_bott We + d_den Wd) * relu'(x8)   in g0
-        HIP_TRY(dgrad(g1, W, W, P(tExW), W, W, g0, W, nullptr));
-        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, 1, d_raw + 3, 4, P(tDensW), W, 1, false, g0, W, true, 1, nullptr, st));
+        // g8 = (g_bott We + d_den Wd) * relu'(x8)   in g0: the density head's dgrad is the rank-1 term of the epilogue
+        HIP_TRY(dgrad(g1, W, W, P(tExW), W, W, g0, W, x8, d_raw + 3, 4, P(tDensW)));
     } else {
         // MLP.forward(x, None) (mip_nerf.py:99-110): colour and density heads both read the trunk output; extra_layer and
         // view_layers are unused parameters (autograd leaves their .grad None; here: zero unless accumulating)
@@ -828,10 +831,8 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
             for (int u = 0; u < 4; ++u)
                 HIP_TRY(hipMemsetAsync(G(unused[u]), 0, (size_t)PL.param_numel[unused[u]] * 4, st));
         }
-        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, W, g0, W, nullptr));
-        HIP_TRY(mip::launch_gemm_f32(false, Mi, W, 1, d_raw + 3, 4, P(tDensW), W, 1, false, g0, W, true, 1, nullptr, st));
+        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, W, g0, W, x8, d_raw + 3, 4, P(tDensW)));
     }
-    HIP_TRY(mip::launch_relu_mask((int64_t)M * W, x8, g0, st));
     float* g = g0;          // delta of layer i (gradient w.r.t. its pre-activation)
     float* gn = g1;
     for (int i = D - 1; i >= 0; --i) {

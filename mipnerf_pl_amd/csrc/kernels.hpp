@@ -161,7 +161,7 @@ hipError_t launch_gemm_f32(bool trans_a, int M, int N, int64_t K, const float* A
 bool gemm_f32_big_ok(int M, int N, int64_t K, const float* A, int64_t lda);
 hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                                float* C, int64_t ldc, bool accumulate, int splits, float* partial, const float* relu_x,
-                               float* bias_out, hipStream_t st);
+                               const float* r1_col, int64_t r1_ld, const float* r1_row, float* bias_out, hipStream_t st);
 hipError_t launch_thin_wgrad(int64_t S, int C, int R, const float* Xc, int64_t ldxc, const float* Yr, int64_t ldyr, int rowdiv,
                              float* out, int64_t ldo_c, int64_t ldo_r, float* out_bias, bool accumulate, float* partial,
                              hipStream_t st);

@@ -80,29 +80,40 @@ k_gemm_f32(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda, co
 }
 
 // ---- the big GEMMs of the backward: 256 x 128 output tile per workgroup (8 waves, each 64 x 64 = four 32x32 MFMA tiles),
-// K in blocks of 16 through a double-buffered LDS stage, global loads as float4 one block ahead (registers), so the 32
-// MFMAs (2048 cycles) of a block hide the next block's loads; 3 workgroups per CU cover each other's barriers.
+// K in blocks of KB through a double-buffered LDS stage, global loads as float4 one block ahead (registers), so the MFMAs of
+// a block (KB = 16: 32 per wave = 2048 cycles) hide the next block's loads.
 // Tile shape: at fp32 MFMA rate a CU retires 292 FLOP/cycle; a 128 x 128 tile moves (128 + 128) x 4 B per 2 x 128 x 128 FLOP
 // = 9.1 B/cycle/CU, which IS the ~10 B/cycle/CU a CU can pull through global_load_dwordx4 (measured: 85 TF/s, 0.54);
-// 256 x 128 needs 6.8 B/cycle.
-//   TA = false (dgrad, dX = dY W):  A(m,k) = A[m*lda + k], rows = samples;   epilogue optionally applies the ReLU mask of the
-//                                   layer input (relu_x[m*ldc + n] <= 0 -> 0), fusing the separate mask pass
-//   TA = true  (wgrad, dW = dY^T X): A(m,k) = A[k*lda + m], contraction over samples, split-K over gridDim.z; the workgroups
-//                                   of column-tile 0 also produce the bias gradient db[m] = sum_k A(m,k) from the staged A tile
+// 256 x 128 needs 6.8 B/cycle (wgrad: 0.52 ms = 132 TF/s = 0.84).
+//   TA = false (dgrad, dX = dY W):  A(m,k) = A[m*lda + k], rows = samples, KB = 32 so that a row contributes a whole 128-byte
+//                                   line per block (with KB = 16 a wave's load touched 16 half lines: 90 TF/s).  Epilogue:
+//                                   optional rank-1 term v += r1_col[m * r1_ld] * r1_row[n] (the density head's dgrad) and the
+//                                   ReLU mask of the layer input (relu_x[m*ldc + n] <= 0 -> 0), fusing two separate passes
+//   TA = true  (wgrad, dW = dY^T X): A(m,k) = A[k*lda + m], KB = 16, contraction over samples, split-K over gridDim.z; the
+//                                   workgroups of column-tile 0 also produce the bias gradient db[m] = sum_k A(m,k)
 //   B(k,n) = B[k*ldb + n].
-constexpr int GM = 256, GN = 128, GK = 16, GT = 512;      // GT threads = 8 waves
-template <bool TA>
+constexpr int GM = 256, GN = 128, GT = 512;      // GT threads = 8 waves
+struct GemmEpi {
+    const float* relu_x;     // [M, ldc] or null
+    const float* r1_col;     // [M] with stride r1_ld, or null
+    const float* r1_row;     // [N]
+    int64_t r1_ld;
+};
+template <bool TA, int KB>
 __global__ void __launch_bounds__(GT)
 k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
-               float* __restrict__ C, int64_t ldc, int accumulate, float* __restrict__ partial, const float* __restrict__ relu_x,
+               float* __restrict__ C, int64_t ldc, int accumulate, float* __restrict__ partial, GemmEpi epi,
                float* __restrict__ bias_partial, int b_vec) {
-    __shared__ float As[2][GK][GM + 4];
-    __shared__ float Bs[2][GK][GN + 4];
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    constexpr int LDA_S = GM + 4, LDB_S = GN + 4;
+    float* const As = gsm;                                   // [2][KB][LDA_S]
+    float* const Bs = gsm + 2 * KB * LDA_S;                  // [2][KB][LDB_S]
+    constexpr int NA = GM * KB / 4 / GT, NB = KB * GN / 4 / GT;     // float4 loads per thread per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;      // wave tile: rows [64 wm, +64), columns [64 wn, +64)
     const int64_t m0 = (int64_t)blockIdx.x * GM;
     const int n0 = blockIdx.y * GN;
-    const int64_t kchunk = ((K + gridDim.z - 1) / gridDim.z + GK - 1) / GK * GK;
+    const int64_t kchunk = ((K + gridDim.z - 1) / gridDim.z + KB - 1) / KB * KB;
     const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
     const int64_t kend = kbeg + kchunk < K ? kbeg + kchunk : K;
     f32x16 acc[2][2];
@@ -112,66 +123,69 @@ k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    // staging assignment: A tile 256 x 16 floats = 1024 float4 (two per thread), B tile 16 x 128 = 512 float4 (one per thread)
-    float4 ra[2], rb[1];
+    float4 ra[NA], rb[NB];
     auto load_tiles = [&](int64_t k0) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NA; ++h) {
             const int f = tid + h * GT;               // float4 index in the A tile
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TA) {                                 // A(m,k) = A[k*lda + m]: contiguous along m
-                const int kk = f >> 6, mm = (f & 63) * 4;
+                const int kk = f / (GM / 4), mm = (f % (GM / 4)) * 4;
                 const int64_t k = k0 + kk, m = m0 + mm;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (k < kend) {
                     const float* src = A + k * lda + m;
                     if (m + 3 < M) v = *reinterpret_cast<const float4*>(src);
                     else { if (m < M) v.x = src[0]; if (m + 1 < M) v.y = src[1]; if (m + 2 < M) v.z = src[2]; }
                 }
-                ra[h] = v;
-            } else {                                  // A(m,k) = A[m*lda + k]: contiguous along k
-                const int mm = f >> 2, kk = (f & 3) * 4;
+            } else {                                  // A(m,k) = A[m*lda + k]: contiguous along k, KB / 4 lanes per row
+                const int mm = f / (KB / 4), kk = (f % (KB / 4)) * 4;
                 const int64_t k = k0 + kk, m = m0 + mm;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (m < M) {
                     const float* src = A + m * lda + k;
                     if (k + 3 < kend) v = *reinterpret_cast<const float4*>(src);
                     else { if (k < kend) v.x = src[0]; if (k + 1 < kend) v.y = src[1]; if (k + 2 < kend) v.z = src[2]; }
                 }
-                ra[h] = v;
             }
+            ra[h] = v;
         }
-        {
-            {
-                const int h = 0, f = tid;
-                const int kk = f >> 5, nn = (f & 31) * 4;
-                const int64_t k = k0 + kk;
-                const int n = n0 + nn;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < kend) {
-                    const float* src = B + k * ldb + n;
-                    if (b_vec && n + 3 < N) v = *reinterpret_cast<const float4*>(src);
-                    else { if (n < N) v.x = src[0]; if (n + 1 < N) v.y = src[1]; if (n + 2 < N) v.z = src[2]; if (n + 3 < N) v.w = src[3]; }
-                }
-                rb[h] = v;
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            const int f = tid + h * GT;
+            const int kk = f / (GN / 4), nn = (f % (GN / 4)) * 4;
+            const int64_t k = k0 + kk;
+            const int n = n0 + nn;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend) {
+                const float* src = B + k * ldb + n;
+                if (b_vec && n + 3 < N) v = *reinterpret_cast<const float4*>(src);
+                else { if (n < N) v.x = src[0]; if (n + 1 < N) v.y = src[1]; if (n + 2 < N) v.z = src[2]; if (n + 3 < N) v.w = src[3]; }
             }
+            rb[h] = v;
         }
     };
     auto store_tiles = [&](int buf) {
+        float* as = As + buf * KB * LDA_S;
+        float* bs = Bs + buf * KB * LDB_S;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NA; ++h) {
             const int f = tid + h * GT;
             if (TA) {
-                const int kk = f >> 6, mm = (f & 63) * 4;
-                *reinterpret_cast<float4*>(&As[buf][kk][mm]) = ra[h];
+                const int kk = f / (GM / 4), mm = (f % (GM / 4)) * 4;
+                *reinterpret_cast<float4*>(as + kk * LDA_S + mm) = ra[h];
             } else {
-                const int mm = f >> 2, kk = (f & 3) * 4;
-                As[buf][kk][mm] = ra[h].x; As[buf][kk + 1][mm] = ra[h].y; As[buf][kk + 2][mm] = ra[h].z; As[buf][kk + 3][mm] = ra[h].w;
+                const int mm = f / (KB / 4), kk = (f % (KB / 4)) * 4;
+                as[kk * LDA_S + mm] = ra[h].x; as[(kk + 1) * LDA_S + mm] = ra[h].y;
+                as[(kk + 2) * LDA_S + mm] = ra[h].z; as[(kk + 3) * LDA_S + mm] = ra[h].w;
             }
         }
-        const int kk = tid >> 5, nn = (tid & 31) * 4;
-        *reinterpret_cast<float4*>(&Bs[buf][kk][nn]) = rb[0];
+#pragma unroll
+        for (int h = 0; h < NB; ++h) {
+            const int f = tid + h * GT;
+            const int kk = f / (GN / 4), nn = (f % (GN / 4)) * 4;
+            *reinterpret_cast<float4*>(bs + kk * LDB_S + nn) = rb[h];
+        }
     };
-    float bsum = 0.0f;                               // bias gradient: thread t < 128 sums row m0 + t of A over this split's k range
+    float bsum = 0.0f;                               // bias gradient: thread t < GM sums row m0 + t of A over this split's k range
     const bool want_bias = TA && bias_partial != nullptr && blockIdx.y == 0;
     int buf = 0;
     if (kbeg < kend) {
@@ -179,18 +193,20 @@ k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda
         store_tiles(0);
     }
     __syncthreads();
-    for (int64_t k0 = kbeg; k0 < kend; k0 += GK) {
-        const bool more = k0 + GK < kend;
-        if (more) load_tiles(k0 + GK);               // next block's global loads fly during this block's MFMAs
+    for (int64_t k0 = kbeg; k0 < kend; k0 += KB) {
+        const bool more = k0 + KB < kend;
+        if (more) load_tiles(k0 + KB);               // next block's global loads fly during this block's MFMAs
+        const float* as = As + buf * KB * LDA_S;
+        const float* bs = Bs + buf * KB * LDB_S;
         if (want_bias && tid < GM) {
 #pragma unroll
-            for (int kk = 0; kk < GK; ++kk) bsum += As[buf][kk][tid];
+            for (int kk = 0; kk < KB; ++kk) bsum += as[kk * LDA_S + tid];
         }
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 2) {
+        for (int kk = 0; kk < KB; kk += 2) {
             const int kr = kk + (lane >> 5);
-            const float a0 = As[buf][kr][wm * 64 + (lane & 31)], a1 = As[buf][kr][wm * 64 + 32 + (lane & 31)];
-            const float b0 = Bs[buf][kr][wn * 64 + (lane & 31)], b1 = Bs[buf][kr][wn * 64 + 32 + (lane & 31)];
+            const float a0 = as[kr * LDA_S + wm * 64 + (lane & 31)], a1 = as[kr * LDA_S + wm * 64 + 32 + (lane & 31)];
+            const float b0 = bs[kr * LDB_S + wn * 64 + (lane & 31)], b1 = bs[kr * LDB_S + wn * 64 + 32 + (lane & 31)];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -208,13 +224,15 @@ k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + (lane & 31);
             if (n >= N) continue;
+            const float r1w = epi.r1_col ? epi.r1_row[n] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (m >= M) continue;
                 float v = acc[i][j][r];
                 if (gridDim.z > 1) { partial[((int64_t)blockIdx.z * M + m) * N + n] = v; continue; }
-                if (relu_x && !(relu_x[m * ldc + n] > 0.0f)) v = 0.0f;
+                if (epi.r1_col) v += epi.r1_col[m * epi.r1_ld] * r1w;
+                if (epi.relu_x && !(epi.relu_x[m * ldc + n] > 0.0f)) v = 0.0f;
                 C[m * ldc + n] = accumulate ? C[m * ldc + n] + v : v;
             }
         }
@@ -238,10 +256,22 @@ k_thin_wgrad(int64_t S, int C, int R, const float* __restrict__ Xc, int64_t ldxc
     float acc[RMAX];
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) acc[r] = 0.0f;
-    if (c < CC) {
+    if (c < CC && rowdiv > 1) {
+        // Yr has one row per GROUP of `rowdiv` consecutive samples (a ray's view features): sum the group's Xc first, then
+        // one multiply-add per row and group -- rowdiv times fewer FMAs and broadcast loads (slices are whole groups)
+        for (int64_t g0 = s0; g0 < s1; g0 += rowdiv) {
+            const int64_t g1 = g0 + rowdiv < s1 ? g0 + rowdiv : s1;
+            float xs = 0.0f;
+            for (int64_t s = g0 + sl; s < g1; s += 4) xs += c < C ? Xc[s * ldxc + c] : 1.0f;
+            const float* y = Yr + (g0 / rowdiv) * ldyr;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r)
+                if (r < R) acc[r] = fmaf(xs, y[r], acc[r]);
+        }
+    } else if (c < CC) {
         for (int64_t s = s0 + sl; s < s1; s += 4) {
             const float x = c < C ? Xc[s * ldxc + c] : 1.0f;
-            const float* y = Yr + (s / rowdiv) * ldyr;
+            const float* y = Yr + s * ldyr;
 #pragma unroll
             for (int r = 0; r < RMAX; ++r)
                 if (r < R) acc[r] = fmaf(x, y[r], acc[r]);
@@ -309,23 +339,34 @@ bool gemm_f32_big_ok(int M, int N, int64_t K, const float* A, int64_t lda) {
     return M >= 64 && N >= 64 && K >= 64 && lda % 4 == 0 && (uintptr_t)A % 16 == 0;
 }
 
-// Big-GEMM entry: same contract as launch_gemm_f32 plus (a) `relu_x` (dgrad only, splits == 1): C's element is zeroed where
-// relu_x[m*ldc + n] <= 0; (b) `bias_out` (wgrad only): db[m] (+)= sum_k A(m,k), reduced over the splits like C.
-// `partial` must hold splits * M * (N + 1) floats.  Falls back to the 64 x 64 kernel for thin shapes.
+// Big-GEMM entry: same contract as launch_gemm_f32 plus (a) dgrad epilogue (splits == 1): optional rank-1 term
+// r1_col[m * r1_ld] * r1_row[n] and ReLU mask relu_x[m*ldc + n] <= 0 -> 0; (b) `bias_out` (wgrad only): db[m] (+)= sum_k A(m,k),
+// reduced over the splits like C.  `partial` must hold splits * M * (N + 1) floats.
 hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                                float* C, int64_t ldc, bool accumulate, int splits, float* partial, const float* relu_x,
-                               float* bias_out, hipStream_t st) {
+                               const float* r1_col, int64_t r1_ld, const float* r1_row, float* bias_out, hipStream_t st) {
     if (splits < 1) splits = 1;
-    if (!gemm_f32_big_ok(M, N, K, A, lda) || (relu_x && splits != 1) || (bias_out && !trans_a)) return hipErrorInvalidValue;
+    if (!gemm_f32_big_ok(M, N, K, A, lda) || ((relu_x || r1_col) && (splits != 1 || trans_a)) || (bias_out && !trans_a))
+        return hipErrorInvalidValue;
     const int b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
     const dim3 grid((unsigned)((M + GM - 1) / GM), (unsigned)((N + GN - 1) / GN), (unsigned)splits);
     float* bias_partial = bias_out ? partial + (int64_t)splits * M * N : nullptr;
+    const GemmEpi epi = {relu_x, r1_col, r1_row, r1_ld};
+    static bool attr_done = false;
+    constexpr int kLdsTA = 2 * 16 * (GM + 4 + GN + 4) * 4, kLdsNA = 2 * 32 * (GM + 4 + GN + 4) * 4;
+    if (!attr_done) {
+        hipError_t er = hipFuncSetAttribute((const void*)k_gemm_f32_big<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTA);
+        if (er != hipSuccess) return er;
+        er = hipFuncSetAttribute((const void*)k_gemm_f32_big<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsNA);
+        if (er != hipSuccess) return er;
+        attr_done = true;
+    }
     if (trans_a)
-        hipLaunchKernelGGL(k_gemm_f32_big<true>, grid, dim3(GT), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0, partial,
-                           relu_x, bias_partial, b_vec);
+        hipLaunchKernelGGL((k_gemm_f32_big<true, 16>), grid, dim3(GT), kLdsTA, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0,
+                           partial, epi, bias_partial, b_vec);
     else
-        hipLaunchKernelGGL(k_gemm_f32_big<false>, grid, dim3(GT), 0, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0, partial,
-                           relu_x, bias_partial, b_vec);
+        hipLaunchKernelGGL((k_gemm_f32_big<false, 32>), grid, dim3(GT), kLdsNA, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0,
+                           partial, epi, bias_partial, b_vec);
     if (splits > 1) {
         const int64_t n = (int64_t)M * N;
         hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, M, N, splits, partial, C, ldc,
@@ -342,7 +383,7 @@ hipError_t launch_thin_wgrad(int64_t S, int C, int R, const float* Xc, int64_t l
                              float* out, int64_t ldo_c, int64_t ldo_r, float* out_bias, bool accumulate, float* partial,
                              hipStream_t st) {
     if (R < 1 || R > 32 || C < 1 || S < 1) return hipErrorInvalidValue;
-    const int64_t slice = 2048;
+    const int64_t slice = rowdiv > 1 ? (int64_t)rowdiv * ((2048 + rowdiv - 1) / rowdiv) : 2048;     // whole groups per slice
     const int nslices = (int)((S + slice - 1) / slice);
     const int bias = out_bias ? 1 : 0;
     const dim3 grid((unsigned)((C + bias + 63) / 64), (unsigned)nslices);
