@@ -85,21 +85,22 @@ k_gemm_f32(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda, co
 // Tile shape: at fp32 MFMA rate a CU retires 292 FLOP/cycle; a 128 x 128 tile moves (128 + 128) x 4 B per 2 x 128 x 128 FLOP
 // = 9.1 B/cycle/CU, which IS the ~10 B/cycle/CU a CU can pull through global_load_dwordx4 (measured: 85 TF/s, 0.54);
 // 256 x 128 needs 6.8 B/cycle (wgrad: 0.52 ms = 132 TF/s = 0.84).
-//   TA = false (dgrad, dX = dY W):  A(m,k) = A[m*lda + k], rows = samples, KB = 32 so that a row contributes a whole 128-byte
-//                                   line per block (with KB = 16 a wave's load touched 16 half lines: 90 TF/s).  Epilogue:
+//   TA = false (dgrad, dX = dY W):  A(m,k) = A[m*lda + k], rows = samples, tile 128 x 256: one column tile covers the whole
+//                                   layer width, so every dY row is fetched once (tried: KB = 32 for whole 128-byte lines per
+//                                   row -- 100 KB of LDS, one workgroup per CU: 1.32 ms instead of 0.76).  Epilogue:
 //                                   optional rank-1 term v += r1_col[m * r1_ld] * r1_row[n] (the density head's dgrad) and the
 //                                   ReLU mask of the layer input (relu_x[m*ldc + n] <= 0 -> 0), fusing two separate passes
-//   TA = true  (wgrad, dW = dY^T X): A(m,k) = A[k*lda + m], KB = 16, contraction over samples, split-K over gridDim.z; the
+//   TA = true  (wgrad, dW = dY^T X): A(m,k) = A[k*lda + m], tile 256 x 128, contraction over samples, split-K over gridDim.z; the
 //                                   workgroups of column-tile 0 also produce the bias gradient db[m] = sum_k A(m,k)
 //   B(k,n) = B[k*ldb + n].
-constexpr int GM = 256, GN = 128, GT = 512;      // GT threads = 8 waves
+constexpr int GT = 512;      // GT threads = 8 waves; tile = TM x TN with TM * TN = 256 * 128
 struct GemmEpi {
     const float* relu_x;     // [M, ldc] or null
     const float* r1_col;     // [M] with stride r1_ld, or null
     const float* r1_row;     // [N]
     int64_t r1_ld;
 };
-template <bool TA, int KB>
+template <bool TA, int KB, int GM, int GN>
 __global__ void __launch_bounds__(GT)
 k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda, const float* __restrict__ B, int64_t ldb,
                float* __restrict__ C, int64_t ldc, int accumulate, float* __restrict__ partial, GemmEpi epi,
@@ -110,7 +111,8 @@ k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda
     float* const Bs = gsm + 2 * KB * LDA_S;                  // [2][KB][LDB_S]
     constexpr int NA = GM * KB / 4 / GT, NB = KB * GN / 4 / GT;     // float4 loads per thread per block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;      // wave tile: rows [64 wm, +64), columns [64 wn, +64)
+    constexpr int WN = GN / 64;
+    const int wm = wave / WN, wn = wave % WN;     // wave tile: rows [64 wm, +64), columns [64 wn, +64)
     const int64_t m0 = (int64_t)blockIdx.x * GM;
     const int n0 = blockIdx.y * GN;
     const int64_t kchunk = ((K + gridDim.z - 1) / gridDim.z + KB - 1) / KB * KB;
@@ -349,24 +351,26 @@ hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const floa
     if (!gemm_f32_big_ok(M, N, K, A, lda) || ((relu_x || r1_col) && (splits != 1 || trans_a)) || (bias_out && !trans_a))
         return hipErrorInvalidValue;
     const int b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
-    const dim3 grid((unsigned)((M + GM - 1) / GM), (unsigned)((N + GN - 1) / GN), (unsigned)splits);
     float* bias_partial = bias_out ? partial + (int64_t)splits * M * N : nullptr;
     const GemmEpi epi = {relu_x, r1_col, r1_row, r1_ld};
+    constexpr int kLds = 2 * 16 * (256 + 4 + 128 + 4) * 4;
     static bool attr_done = false;
-    constexpr int kLdsTA = 2 * 16 * (GM + 4 + GN + 4) * 4, kLdsNA = 2 * 32 * (GM + 4 + GN + 4) * 4;
     if (!attr_done) {
-        hipError_t er = hipFuncSetAttribute((const void*)k_gemm_f32_big<true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTA);
+        hipError_t er = hipFuncSetAttribute((const void*)k_gemm_f32_big<true, 16, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (er != hipSuccess) return er;
-        er = hipFuncSetAttribute((const void*)k_gemm_f32_big<false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsNA);
+        er = hipFuncSetAttribute((const void*)k_gemm_f32_big<false, 16, 128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (er != hipSuccess) return er;
         attr_done = true;
     }
-    if (trans_a)
-        hipLaunchKernelGGL((k_gemm_f32_big<true, 16>), grid, dim3(GT), kLdsTA, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0,
-                           partial, epi, bias_partial, b_vec);
-    else
-        hipLaunchKernelGGL((k_gemm_f32_big<false, 32>), grid, dim3(GT), kLdsNA, st, M, N, K, A, lda, B, ldb, C, ldc, accumulate ? 1 : 0,
-                           partial, epi, bias_partial, b_vec);
+    if (trans_a) {
+        const dim3 grid((unsigned)((M + 255) / 256), (unsigned)((N + 127) / 128), (unsigned)splits);
+        hipLaunchKernelGGL((k_gemm_f32_big<true, 16, 256, 128>), grid, dim3(GT), kLds, st, M, N, K, A, lda, B, ldb, C, ldc,
+                           accumulate ? 1 : 0, partial, epi, bias_partial, b_vec);
+    } else {
+        const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 255) / 256), (unsigned)splits);
+        hipLaunchKernelGGL((k_gemm_f32_big<false, 16, 128, 256>), grid, dim3(GT), kLds, st, M, N, K, A, lda, B, ldb, C, ldc,
+                           accumulate ? 1 : 0, partial, epi, bias_partial, b_vec);
+    }
     if (splits > 1) {
         const int64_t n = (int64_t)M * N;
         hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, M, N, splits, partial, C, ldc,
