@@ -85,9 +85,11 @@ k_gemm_f32(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda, co
 // Tile shape: at fp32 MFMA rate a CU retires 292 FLOP/cycle; a 128 x 128 tile moves (128 + 128) x 4 B per 2 x 128 x 128 FLOP
 // = 9.1 B/cycle/CU, which IS the ~10 B/cycle/CU a CU can pull through global_load_dwordx4 (measured: 85 TF/s, 0.54);
 // 256 x 128 needs 6.8 B/cycle (wgrad: 0.52 ms = 132 TF/s = 0.84).
-//   TA = false (dgrad, dX = dY W):  A(m,k) = A[m*lda + k], rows = samples, tile 128 x 256: one column tile covers the whole
-//                                   layer width, so every dY row is fetched once (tried: KB = 32 for whole 128-byte lines per
-//                                   row -- 100 KB of LDS, one workgroup per CU: 1.32 ms instead of 0.76).  Epilogue:
+//   TA = false (dgrad, dX = dY W):  A(m,k) = A[m*lda + k], rows = samples.  K is only the layer width (256), so a tile's
+//                                   output (C write + ReLU-mask read, 256 KB) weighs as much as its input (A 256 KB + B 128 KB):
+//                                   640 KB per 65k MFMA cycles = 9.8 B/cycle/CU, again the CU's memory pipeline: 0.76 ms =
+//                                   90 TF/s.  Tried and worse: KB = 32 for whole 128-byte lines per row (100 KB of LDS, one
+//                                   workgroup per CU: 1.32 ms); a 128 x 256 tile that fetches every dY row once (0.93 ms).  Epilogue:
 //                                   optional rank-1 term v += r1_col[m * r1_ld] * r1_row[n] (the density head's dgrad) and the
 //                                   ReLU mask of the layer input (relu_x[m*ldc + n] <= 0 -> 0), fusing two separate passes
 //   TA = true  (wgrad, dW = dY^T X): A(m,k) = A[k*lda + m], tile 256 x 128, contraction over samples, split-K over gridDim.z; the
@@ -358,7 +360,7 @@ hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const floa
     if (!attr_done) {
         hipError_t er = hipFuncSetAttribute((const void*)k_gemm_f32_big<true, 16, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (er != hipSuccess) return er;
-        er = hipFuncSetAttribute((const void*)k_gemm_f32_big<false, 16, 128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+        er = hipFuncSetAttribute((const void*)k_gemm_f32_big<false, 16, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (er != hipSuccess) return er;
         attr_done = true;
     }
@@ -367,8 +369,8 @@ hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const floa
         hipLaunchKernelGGL((k_gemm_f32_big<true, 16, 256, 128>), grid, dim3(GT), kLds, st, M, N, K, A, lda, B, ldb, C, ldc,
                            accumulate ? 1 : 0, partial, epi, bias_partial, b_vec);
     } else {
-        const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 255) / 256), (unsigned)splits);
-        hipLaunchKernelGGL((k_gemm_f32_big<false, 16, 128, 256>), grid, dim3(GT), kLds, st, M, N, K, A, lda, B, ldb, C, ldc,
+        const dim3 grid((unsigned)((M + 255) / 256), (unsigned)((N + 127) / 128), (unsigned)splits);
+        hipLaunchKernelGGL((k_gemm_f32_big<false, 16, 256, 128>), grid, dim3(GT), kLds, st, M, N, K, A, lda, B, ldb, C, ldc,
                            accumulate ? 1 : 0, partial, epi, bias_partial, b_vec);
     }
     if (splits > 1) {
