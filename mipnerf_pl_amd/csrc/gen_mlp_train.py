@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 from mipnerf_pl_amd.mlp_plan import Plan  # noqa: E402
 from mipnerf_pl_amd.mlp_train_plan import GROUP, SLOTS, TrainPlan  # noqa: E402
-from gen_mlp_bf16 import KERNEL_PREAMBLE  # noqa: E402
+from gen_mlp_bf16 import KERNEL_PREAMBLE, SETPRIO  # noqa: E402
 
 WAVES = 8
 CHUNK_BYTES = 1024
@@ -402,6 +402,8 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     e("    for (int i = tid; i < kBiasBytes / 16; i += blockDim.x)")
     e("        reinterpret_cast<float4*>(smem + kRingBytes)[i] = reinterpret_cast<const float4*>(bias_tab)[i];")
     e("    __syncthreads();")
+    if SETPRIO:
+        e("    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // as the inference kernel (gen_mlp_bf16.SETPRIO)")
     e("    if ((int)blockIdx.x < ntiles) issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
     e("    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {")
     e("        const bool has_next = tile + (int)gridDim.x < ntiles;")
@@ -572,6 +574,8 @@ def gen_dgrad(tp: TrainPlan) -> str:
     e("    const char* priv_lane = privw + lane16;")
     for ln in SELECTORS:
         e("    " + ln)
+    if SETPRIO:
+        e("    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // as the inference kernel (gen_mlp_bf16.SETPRIO)")
     e("    if ((int)blockIdx.x < ntiles) issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
     e("    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {")
     e("        const bool has_next = tile + (int)gridDim.x < ntiles;")

@@ -24,8 +24,10 @@ stats() {  # name, args...
   f=$(find $OUT/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
   rm -rf $OUT/prof_$name
 }
-stats bench --no-cpu-baseline --sustain-seconds 0 --steps 20
+stats bench_inference --mode inference --no-cpu-baseline --sustain-seconds 0 --steps 20      # the headline kernel alone: its average = roofline.launch_ms
+stats bench --no-cpu-baseline --sustain-seconds 0 --steps 20                                  # the default line (inference + train + render sub-records)
 stats train --mode train --steps 10 --warmup 2 --no-graph
+stats fp32_inference --precision fp32 --mode inference --no-cpu-baseline --sustain-seconds 0 --steps 5
 stats fp32_train --precision fp32 --mode train --steps 3 --warmup 1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python $ROOT/bench.py --mode inference --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 > $OUT/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
