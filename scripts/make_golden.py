@@ -391,8 +391,7 @@ def fullsize_case(name, batch, num_samples, param_seed, gain, ray_seed, unbounde
         out[f"l{lvl}_distance"] = dist.numpy()
         out[f"l{lvl}_acc"] = acc.numpy()
         out[f"l{lvl}_wsum_t"] = (w * 0.5 * (t[:, :-1] + t[:, 1:])).sum(-1).numpy()    # unclamped expected depth (checksum of weights x t)
-    out["ref_cpu_seconds"] = np.float64(dt)
-    out["ref_cpu_threads"] = torch.get_num_threads()
+    # (the wall time of this forward is printed, not stored: the files must regenerate value-for-value)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"wrote {name}.npz  reference forward {dt:.2f} s on {torch.get_num_threads()} threads "
           f"= {batch * num_samples * 2 / dt:.3e} ray-samples/s; acc range [{float(out['l1_acc'].min()):.3f}, {float(out['l1_acc'].max()):.3f}]")
