@@ -4,7 +4,16 @@ mounted read-only at /root/reference) on CPU with seeded inputs.
 
 Run (only possible in the build container; the GPU box has no /root/reference):
 
-    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 -B /root/repo/scripts/make_golden.py
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 -B /root/repo/scripts/make_golden.py [FLAG]
+
+    (no flag)                the 11 round-1 files: forward cases, stages, training gradients, ray generation, metrics (~1 min)
+    --only-fullsize          round 2: BASELINE configs[1] 4096x128 and configs[3] 8192x256, every ray (~1 min on 8 threads)
+    --only-trajectory        round 2: 300-step training trajectories (deterministic / randomized) of the reference's own loop,
+                             each run twice (all threads / 1 thread) to record the reference's self-divergence (~20 min)
+    --only-trajectory-long   round 2: converged 1500-step randomized trajectory (~8 min)
+    --only-noise             round 2: density_noise > 0 with the reference's four draws replayed
+    --only-variants          round 2: 128-wide trunk; use_viewdirs=False
+    --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
 
 The reference's own tests hold no golden vectors (it has no tests), so these files
 are the pin for oracle/mipnerf_oracle.py and, through it, for the HIP path.
