@@ -220,6 +220,11 @@ int mipnerf_sample_along_rays_360(int64_t num_rays, int32_t num_samples, const f
 int mipnerf_cast_ipe_360(int64_t num_rays, int32_t num_samples, int32_t min_deg, int32_t max_deg, int32_t contracted,
                          const float* t_samples, const float* origins, const float* directions, const float* radii,
                          void* enc, int out_dtype, float* means, float* covs, void* stream);
+/* The same on GIVEN Gaussians, means [M,3] / covs [M,3,3]: contraction of mean and covariance (contracted != 0; `contract`,
+ * `parameterization`, mip.py:424-447) into means_out / covs_out (covs_out may be NULL) and / or the off-axis encoding
+ * enc [M, 2*21*(max_deg-min_deg)] (`integrated_pos_enc_360`, mip.py:292-319) of the (contracted) Gaussians. */
+int mipnerf_gauss_360(int64_t num_points, int32_t min_deg, int32_t max_deg, int32_t contracted, const float* means,
+                      const float* covs, void* enc, int out_dtype, float* means_out, float* covs_out, void* stream);
 
 /* ---- evaluation metrics: eval_errors (utils/metrics.py:191-197) on one frame: pred, gt [H,W,3] fp32 in [0,1];
  * out[0] = PSNR (metrics.py:182-188), out[1] = mean SSIM, 11x11 Gaussian window sigma 1.5, zero padding

@@ -67,6 +67,7 @@ SIGNATURES = {
     "mipnerf_sorted_piecewise_constant_pdf": (C.c_int, [_I64, _I32, _P, _P, _I32, _P, _P, _P]),
     "mipnerf_sample_along_rays_360": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P]),
     "mipnerf_cast_ipe_360": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    "mipnerf_gauss_360": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, C.c_int, _P, _P, _P]),
     "mipnerf_generate_rays": (C.c_int, [_I64, _P, _P, _P, C.POINTER(RaysPtrs), _P]),
     "mipnerf_eval_workspace_floats": (_I64, [_I32, _I32]),
     "mipnerf_eval_errors": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P]),

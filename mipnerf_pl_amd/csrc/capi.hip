@@ -546,6 +546,15 @@ int mipnerf_cast_ipe_360(int64_t B, int32_t N, int32_t min_deg, int32_t max_deg,
     return MIPNERF_OK;
 }
 
+int mipnerf_gauss_360(int64_t M, int32_t min_deg, int32_t max_deg, int32_t contracted, const float* means, const float* covs,
+                      void* enc, int out_dtype, float* means_out, float* covs_out, void* stream) {
+    if (M < 1 || !means || !covs || (!enc && !means_out)) return fail(MIPNERF_E_INVALID, "gauss_360: bad argument");
+    if (enc && (min_deg < 0 || max_deg <= min_deg || max_deg > 31)) return fail(MIPNERF_E_INVALID, "gauss_360: need 0 <= min_deg < max_deg <= 31");
+    HIP_TRY(mip::launch_gauss_360(M, min_deg, enc ? max_deg : min_deg + 1, contracted, means, covs, enc, out_dtype == MIPNERF_PREC_BF16,
+                                  means_out, covs_out, S(stream)));
+    return MIPNERF_OK;
+}
+
 // ---- device-side ray generation (datasets/datasets.py:116-168, 214-263) ---------------------------------------
 int mipnerf_generate_rays(int64_t n, const float* cameras, const int32_t* cam_idx, const int32_t* pix_idx,
                           const mipnerf_rays_out* out, void* stream) {

@@ -44,6 +44,9 @@ hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int c
                                const float* dirs, const float* radii, void* enc, bool bf16, float* means, float* covs,
                                hipStream_t st);
 
+hipError_t launch_gauss_360(int64_t M, int min_deg, int max_deg, int contracted, const float* means, const float* covs, void* enc,
+                            bool bf16, float* means_out, float* covs_out, hipStream_t st);
+
 // ---- kernels_train.hip ------------------------------------------------------------------------
 // dnoise (nullable): standard-normal draws [M]; the density pre-activation becomes raw + dnoise_scale * dnoise (mip_nerf.py:232-233)
 hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, const float* dnoise,

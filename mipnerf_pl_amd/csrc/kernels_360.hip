@@ -65,6 +65,54 @@ k_cast_ipe_360(int64_t B, int N, int min_deg, int L, int contracted, const float
     }
 }
 
+// The same on GIVEN Gaussians (the reference's free functions take (means, covs) tensors): optional contraction of mean and
+// covariance (`parameterization`, mip.py:431-447 -- generic J Sigma J^T, see raymath360.hpp for its conditioning), optional
+// off-axis encoding (`integrated_pos_enc_360`, mip.py:292-319).  means [M,3], covs [M,3,3] (symmetric; the upper triangle is read).
+template <typename OutT>
+__global__ void __launch_bounds__(256)
+k_gauss_360(int64_t M, int min_deg, int L, int contracted, const float* __restrict__ means, const float* __restrict__ covs,
+            OutT* __restrict__ enc, float* __restrict__ means_out, float* __restrict__ covs_out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = gid / kBasis360N;
+    const int j = (int)(gid - s * kBasis360N);
+    if (s >= M) return;
+    GaussFull g;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) g.mean[a] = means[s * 3 + a];
+    const float* c = covs + s * 9;
+    g.cov[0] = c[0]; g.cov[1] = c[1]; g.cov[2] = c[2]; g.cov[3] = c[4]; g.cov[4] = c[5]; g.cov[5] = c[8];
+    if (contracted) contract_gaussian(g);
+    if (j == 0 && means_out) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) means_out[s * 3 + a] = g.mean[a];
+        if (covs_out) {
+            const float full[9] = {g.cov[0], g.cov[1], g.cov[2], g.cov[1], g.cov[3], g.cov[4], g.cov[2], g.cov[4], g.cov[5]};
+#pragma unroll
+            for (int a = 0; a < 9; ++a) covs_out[s * 9 + a] = full[a];
+        }
+    }
+    if (!enc) return;
+    float y, var;
+    project_360(g, j, y, var);
+    OutT* row = enc + s * (int64_t)(2 * kBasis360N * L);
+    for (int l = 0; l < L; ++l) {
+        row[l * kBasis360N + j] = (OutT)ipe360_feature(y, var, 0, l, min_deg);
+        row[(L + l) * kBasis360N + j] = (OutT)ipe360_feature(y, var, 1, l, min_deg);
+    }
+}
+
+hipError_t launch_gauss_360(int64_t M, int min_deg, int max_deg, int contracted, const float* means, const float* covs, void* enc,
+                            bool bf16, float* means_out, float* covs_out, hipStream_t st) {
+    const int64_t n = M * kBasis360N;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const int L = max_deg - min_deg;
+    if (bf16)
+        hipLaunchKernelGGL((k_gauss_360<__bf16>), grid, block, 0, st, M, min_deg, L, contracted, means, covs, (__bf16*)enc, means_out, covs_out);
+    else
+        hipLaunchKernelGGL((k_gauss_360<float>), grid, block, 0, st, M, min_deg, L, contracted, means, covs, (float*)enc, means_out, covs_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample_along_rays_360(int64_t B, int N, const float* nearp, const float* farp, const float* t_rand,
                                         float* t_inv, float* t, hipStream_t st) {
     const int64_t n = B * (int64_t)(N + 1);

@@ -293,3 +293,38 @@ def cast_ipe_360(t_samples, origins, directions, radii, min_deg, max_deg, contra
     L.check(L.lib().mipnerf_cast_ipe_360(B, N1 - 1, min_deg, max_deg, int(bool(contracted)), _ptr(t_samples), _ptr(o), _ptr(d),
                                          _ptr(r), _ptr(enc), precision, None, None, _stream()), "cast_ipe_360")
     return enc
+
+
+def parameterization(means, covs):
+    """models/mip.py:431-447 done right: the scene contraction pushed through Gaussians, (contract(mean), J cov J^T)."""
+    means, covs = _f32c(means, "means"), _f32c(covs, "covs")
+    M = means.numel() // 3
+    if covs.numel() != 9 * M:
+        raise ValueError("parameterization: covs must be [..., 3, 3] full covariances")
+    mo, co = torch.empty_like(means), torch.empty_like(covs)
+    L.check(L.lib().mipnerf_gauss_360(M, 0, 1, 1, _ptr(means), _ptr(covs), None, L.PREC_FP32, _ptr(mo), _ptr(co), _stream()),
+            "parameterization")
+    return mo, co
+
+
+def contract(x):
+    """models/mip.py:424-426: x inside the unit ball, (2 - 1/|x|) x/|x| outside (mip-NeRF 360 eq. 10); x [..., 3]."""
+    x = _f32c(x, "x")
+    M = x.numel() // 3
+    out = torch.empty_like(x)
+    zero = torch.zeros(M, 9, device=x.device, dtype=torch.float32)
+    L.check(L.lib().mipnerf_gauss_360(M, 0, 1, 1, _ptr(x), _ptr(zero), None, L.PREC_FP32, _ptr(out), None, _stream()), "contract")
+    return out
+
+
+def integrated_pos_enc_360(means_covs, min_deg=0, max_deg=1, contracted=True, precision=L.PREC_FP32):
+    """models/mip.py:292-319 done right: off-axis integrated positional encoding of (means [...,3], covs [...,3,3]) on the 21
+    icosahedron directions at the frequencies 2^min_deg .. 2^(max_deg-1) (the dead upstream code has a single frequency =
+    the defaults here), contracting the Gaussians first like its `parameterization` call: [..., 2*21*(max_deg-min_deg)]."""
+    means, covs = means_covs
+    means, covs = _f32c(means, "means"), _f32c(covs, "covs")
+    M = means.numel() // 3
+    enc = torch.empty(*means.shape[:-1], 42 * (max_deg - min_deg), device=means.device, dtype=_torch_dtype(precision))
+    L.check(L.lib().mipnerf_gauss_360(M, min_deg, max_deg, int(bool(contracted)), _ptr(means), _ptr(covs), _ptr(enc), precision,
+                                      None, None, _stream()), "integrated_pos_enc_360")
+    return enc

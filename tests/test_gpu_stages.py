@@ -330,3 +330,37 @@ def test_mipnerf360_path(G, contracted, randomized):
     cg = gc.cpu().numpy().astype(np.float64)
     assert np.abs(cg - np.swapaxes(cg, -1, -2)).max() == 0.0
     assert np.linalg.eigvalsh(cg).min() >= -1e-6 * np.abs(cg).max()
+
+
+def test_mipnerf360_free_functions(G):
+    """The reference's free functions for unbounded scenes, by name (mip.py:424-447 contract / parameterization, :292-319
+    integrated_pos_enc_360), on GIVEN Gaussians: against the oracle (parity unpinned, paper equations).  The generic
+    J Sigma J^T of `parameterization` is conditioned like |x| (raymath360.hpp): covariances within 1e-3 of the largest entry."""
+    from mipnerf_pl_amd import ops, _lib as L
+    from oracle import mipnerf360_oracle as o360
+    DEV = G.DEV
+    rng = np.random.default_rng(41)
+    M = 4096
+    x = (rng.standard_normal((M, 3)) * rng.choice([0.3, 2.0, 30.0, 400.0], size=(M, 1))).astype(np.float32)
+    A = rng.standard_normal((M, 3, 3)).astype(np.float32) * rng.choice([1e-2, 1.0], size=(M, 1, 1)).astype(np.float32)
+    cov = (A @ np.swapaxes(A, -1, -2)).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(DEV)     # noqa: E731
+    got = ops.contract(T(x)).cpu().numpy()
+    want = o360.contract(x)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=2e-6)
+    inside = np.linalg.norm(x, axis=-1) <= 1
+    assert inside.any() and np.array_equal(got[inside], x[inside]) and np.linalg.norm(got, axis=-1).max() < 2.0
+    gm, gc = ops.parameterization(T(x), T(cov))
+    wm, wc = o360.contract_gaussian(x, cov)
+    np.testing.assert_allclose(gm.cpu().numpy(), wm, rtol=2e-6, atol=2e-6)
+    scale = np.abs(wc).max(axis=(-1, -2), keepdims=True)
+    cerr = float((np.abs(gc.cpu().numpy() - wc) / scale).max())
+    Lf = 5
+    enc = ops.integrated_pos_enc_360((T(x), T(cov)), 0, Lf, contracted=True).cpu().numpy()
+    want_e = o360.integrated_pos_enc_360((wm, wc), 0, Lf)
+    eerr = float(np.abs(enc - want_e).max())
+    G.record("mipnerf360 free functions", cov_rel=cerr, enc_abs=eerr)
+    assert cerr <= 1e-3 and enc.shape == (M, 42 * Lf)
+    assert eerr <= 2e-3          # var errors of 1e-3 relative enter exp(-0.5 * 4^l var)
+    single = ops.integrated_pos_enc_360((T(x), T(cov))).cpu().numpy()       # upstream signature: one frequency
+    assert single.shape == (M, 42) and np.abs(single - enc[:, [*range(21), *range(21 * Lf, 21 * Lf + 21)]]).max() == 0.0
