@@ -13,6 +13,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-trajectory-long   round 2: converged 1500-step randomized trajectory (~8 min)
     --only-noise             round 2: density_noise > 0 with the reference's four draws replayed
     --only-variants          round 2: 128-wide trunk; use_viewdirs=False
+    --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
     --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
 
 The reference's own tests hold no golden vectors (it has no tests), so these files
@@ -191,6 +192,26 @@ def variant_case(name, batch, num_samples, param_seed, gain, ray_seed, **ctor):
     check_oracle(name, ret, oret, 2e-4)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"wrote {name}.npz loss={loss.item():.6f}")
+
+
+def ctor_case(name, batch, num_samples, param_seed, gain, ray_seed, tol=2e-4, **ctor):
+    """Scalar constructor arguments away from their defaults (mip_nerf.py:117-141): num_levels, disable_integration,
+    min/max_deg_point, resample_padding, density_bias, rgb_padding -- deterministic forward, both backgrounds."""
+    rays = orc.synthetic_rays(batch, seed=ray_seed, multiscale=True)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples, **ctor)
+    load_params(model, params)
+    out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain, ray_seed=ray_seed,
+               **{"ctor_" + k: np.asarray(v) for k, v in ctor.items()})
+    with torch.no_grad():
+        for wb in (True, False):
+            ret = model(to_ref_rays(rays), False, wb)
+            out.update(ret_dict(ret, prefix=f"wb{int(wb)}_"))
+            oret = orc.mipnerf_forward(params, rays, False, wb, num_samples=num_samples, **ctor)
+            check_oracle(f"{name}/wb{int(wb)}/level0", ret[:1], oret[:1], 2e-4)     # level 0 (deterministic t) is always tight
+            check_oracle(f"{name}/wb{int(wb)}", ret, oret, tol)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz")
 
 
 def stage_case(name, batch, num_samples, param_seed, gain, ray_seed):
@@ -487,6 +508,15 @@ if __name__ == "__main__":
     if "--only-variants" in sys.argv:       # round 2: other reference-legal MLP shapes
         variant_case("var_w128_48x64", 48, 64, param_seed=12, gain=20.0, ray_seed=12, mlp_net_width=128, mlp_net_width_condition=128)
         variant_case("var_noview_48x64", 48, 64, param_seed=13, gain=20.0, ray_seed=13, mlp_net_width_condition=256, use_viewdirs=False)
+        sys.exit(0)
+    if "--only-ctor" in sys.argv:           # round 2: non-default scalar constructor arguments
+        ctor_case("ctor_levels1_40x64", 40, 64, param_seed=14, gain=20.0, ray_seed=14, num_levels=1)
+        ctor_case("ctor_scalars_40x64", 40, 64, param_seed=15, gain=20.0, ray_seed=15, min_deg_point=1, max_deg_point=17,
+                  resample_padding=0.05, density_bias=-0.5, rgb_padding=0.01)
+        # disable_integration leaves the 2^15-rad features undamped (|arg| up to 2e5 rad, fp32 ulp 0.016 rad): the forward is
+        # ill-conditioned in fp32 itself at level 1 (1-ulp differences of the resampled t x 2^15): two correct fp32 evaluations differ
+        # by up to 4e-3 on acc; level 0 agrees to 2e-4
+        ctor_case("ctor_noint_40x64", 40, 64, param_seed=16, gain=20.0, ray_seed=16, tol=1e-2, disable_integration=True)
         sys.exit(0)
     if "--only-noise" in sys.argv:          # round 2: density_noise > 0
         noise_case("fwd_noise_48x64_trained", 48, 64, param_seed=9, gain=4.0, ray_seed=9, torch_seed=77, density_noise=1.0)

@@ -244,3 +244,42 @@ def test_constructor_variants_train_fp32(G, name):
     bsys = bsys.to(G.DEV)
     with pytest.raises(NotImplementedError, match="bf16 training kernels"):
         bsys.training_step((rays, gt), 0)
+
+
+CTOR_KW = {"ctor_levels1_40x64": dict(num_levels=1),
+           "ctor_scalars_40x64": dict(min_deg_point=1, max_deg_point=17, resample_padding=0.05, density_bias=-0.5, rgb_padding=0.01),
+           "ctor_noint_40x64": dict(disable_integration=True)}
+
+
+@pytest.mark.parametrize("name", sorted(CTOR_KW))
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_constructor_scalars_forward(G, name, precision):
+    """Scalar constructor arguments off their defaults (mip_nerf.py:117-141): num_levels=1; disable_integration with the
+    degree range 1..17, other resample padding / density bias / rgb padding -- goldens from the reference, both backgrounds."""
+    g = G.load_golden(name)
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    model = G.make_model(params, int(g["num_samples"]), precision, **CTOR_KW[name])
+    tol = dict(G.TOL_FP32 if precision == "fp32" else G.TOL_BF16)
+    tol1 = tol
+    if name == "ctor_noint_40x64":
+        # disable_integration leaves the features at 2^15 x undamped (|arg| up to 2e5 rad, fp32 ulp 0.016 rad).  Level 0 (t is
+        # deterministic) is as tight as ever; at level 1 a 1-ulp difference of a resampled t moves the top features by 1e-2 rad
+        # and two correct fp32 evaluations differ by 4e-3 on acc (numpy oracle vs reference, scripts/make_golden.py): loose
+        # bound there.  bf16 (features rounded to 8 bits, fast sin): level 0 within the usual bf16 bounds x 2, level 1 only finite
+        tol1 = dict(rgb=2e-2, acc=2e-2, distance=8e-2, weights=4e-2, t_samples=1e-3) if precision == "fp32" else None
+        if precision == "bf16":
+            tol = {k: 2 * v for k, v in tol.items()}
+    for wb in (True, False):
+        with torch.no_grad():
+            ret = model(G.to_dev(G.rays_of(g)), False, wb)
+        assert len(ret) == model.num_levels
+        errs = {}
+        for lvl in range(model.num_levels):
+            for nm, val in zip(G.NAMES, ret[lvl]):
+                errs[f"l{lvl}_{nm}"] = G.maxdiff(val, g[f"wb{int(wb)}_l{lvl}_{nm}"])
+        G.record(f"ctor {name} {precision} white={wb}", **errs)
+        for k, e in errs.items():
+            bound = tol if k.startswith("l0_") else tol1
+            assert np.isfinite(e)
+            if bound is not None:
+                assert e <= bound[k.split("_", 1)[1]], f"{name} {precision} {k}: {e}"
