@@ -204,3 +204,24 @@ def test_oracle_on_fullsize_golden_sample(golden_dir):
         assert np.max(np.abs(ret[lvl][0] - g[f"l{lvl}_rgb"][idx])) <= 2e-4
         assert np.max(np.abs(ret[lvl][1] - g[f"l{lvl}_distance"][idx])) <= 5e-4
         assert np.max(np.abs(ret[lvl][2] - g[f"l{lvl}_acc"][idx])) <= 2e-4
+
+
+@pytest.mark.parametrize("name,kw,tol1", [
+    ("ctor_levels1_40x64", dict(num_levels=1), 2e-4),
+    ("ctor_scalars_40x64", dict(min_deg_point=1, max_deg_point=17, resample_padding=0.05, density_bias=-0.5, rgb_padding=0.01), 2e-4),
+    ("ctor_noint_40x64", dict(disable_integration=True), 1e-2),      # level 1 is ill-conditioned without the integration
+    ("var_w128_48x64", dict(), 2e-4), ("var_noview_48x64", dict(use_viewdirs=False), 2e-4)])
+def test_oracle_constructor_variants(golden_dir, name, kw, tol1):
+    """Oracle vs the reference's outputs for constructor arguments off their defaults (round-2 goldens)."""
+    import os
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    arch = {}
+    if "net_width" in g:
+        arch = dict(net_width=int(g["net_width"]), net_width_condition=int(g["net_width_condition"]))
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]), **arch)
+    rays = orc.Rays(*[g["rays_" + k] for k in orc.Rays._fields])
+    ret = orc.mipnerf_forward(params, rays, False, True, num_samples=int(g["num_samples"]), **kw)
+    for lvl in range(len(ret)):
+        for nm, val in zip(("rgb", "distance", "acc", "weights", "t_samples"), ret[lvl]):
+            d = float(np.max(np.abs(val - g[f"wb1_l{lvl}_{nm}"])))
+            assert d <= (2e-4 if lvl == 0 else tol1), (name, lvl, nm, d)
