@@ -637,11 +637,19 @@ int mipnerf_mlp_dgrad(mipnerf_ctx* c, int64_t M, const float* d_raw, const void*
     return MIPNERF_OK;
 }
 
+// weight gradients of `n_wt` consecutive wave tiles (32 samples each; the tiles of several levels may be concatenated)
+static int wgrad_tiles(mipnerf_ctx* c, int64_t n_wt, const void* act, const void* delta, float* partials, float* grad_flat,
+                       int32_t accumulate, void* stream);
+
 int mipnerf_mlp_wgrad(mipnerf_ctx* c, int64_t M, const void* act, const void* delta, float* partials, float* grad_flat,
                       int32_t accumulate, void* stream) {
     if (!c || M < 1 || !act || !delta || !partials) return fail(MIPNERF_E_INVALID, "mlp_wgrad: bad argument");
     NEED_BF16_TRAIN("mlp_wgrad");
-    const int64_t n_wt = ((M + 255) / 256) * 8;
+    return wgrad_tiles(c, ((M + 255) / 256) * 8, act, delta, partials, grad_flat, accumulate, stream);
+}
+
+static int wgrad_tiles(mipnerf_ctx* c, int64_t n_wt, const void* act, const void* delta, float* partials, float* grad_flat,
+                       int32_t accumulate, void* stream) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->time_mlp == 2) {          // option 2 = 2: time the weight-gradient launches (bench.py --mode train roofline)
         if (c->ev_used + 2 > c->ev.size())
@@ -868,8 +876,9 @@ size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
     if (mipnerf_mlp_train_sizes(c, (int64_t)M, &act, &masks, &delta, &partials)) return 0;
     size_t per_level = align256(B * (N + 1) * 4) + align256(B * N * 4) + align256(B * 3 * 4) + 2 * align256(B * 4) +   // t, w, rgb, dist, acc
                        align256(M * c->P->xyz_dim * 2) + 2 * align256(M * 16) +                                    // enc, rgb_sigma, raw
-                       align256(act) + align256(masks) + align256(B * 4) + align256(B * N * 4) + align256(B * 3 * 4);   // act, masks, ray_loss, d_w, g_rgb
-    return 256 + L * per_level + align256(B * 32 * 2) + align256(delta) + align256(partials) + align256(M * 16) + 256;
+                       align256(masks) + align256(B * 4) + align256(B * N * 4) + align256(B * 3 * 4);   // masks, ray_loss, d_w, g_rgb
+    // act and delta: one contiguous run of wave tiles over ALL levels (one weight-gradient launch over both levels)
+    return 256 + L * per_level + align256(B * 32 * 2) + align256(L * act) + align256(L * delta) + align256(partials) + align256(M * 16) + 256;
 }
 
 int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* gt_rgb, const float* t_rand,
@@ -899,11 +908,15 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
         lv[l].dist = ws.take<float>(B * 4); lv[l].acc = ws.take<float>(B * 4);
         lv[l].enc = ws.take<char>(M * c->P->xyz_dim * 2);
         lv[l].rgb_sigma = ws.take<float>(M * 16); lv[l].raw = ws.take<float>(M * 16);
-        lv[l].act = ws.take<char>(act_b); lv[l].masks = ws.take<char>(mask_b);
+        lv[l].masks = ws.take<char>(mask_b);
         lv[l].ray_loss = ws.take<float>(B * 4); lv[l].d_w = ws.take<float>(B * N * 4); lv[l].g_rgb = ws.take<float>(B * 3 * 4);
     }
     void* viewenc = ws.take<char>(B * 32 * 2);
-    void* delta = ws.take<char>(delta_b);
+    // T-blocks of the activations and of the deltas: level l owns wave tiles [l * n_wt, (l + 1) * n_wt) of one contiguous run,
+    // so that ONE weight-gradient launch (+ one reduction) covers every level (padding tiles carry delta = 0)
+    char* act_all = ws.take<char>((size_t)L * act_b);
+    char* delta_all = ws.take<char>((size_t)L * delta_b);
+    for (int l = 0; l < L; ++l) lv[l].act = act_all + (size_t)l * act_b;
     float* partials = ws.take<float>(part_b);
     float* d_raw = ws.take<float>(M * 16);
     const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
@@ -949,9 +962,11 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     for (int l = L - 1; l >= 0; --l) {
         if ((rc = mipnerf_volumetric_rendering_bwd(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].g_rgb, nullptr,
                                                    nullptr, lv[l].d_w, cfg.rgb_padding, d_raw, stream))) return rc;
-        const int acc = (l == L - 1) ? (accumulate ? 1 : 0) : 1;
-        if ((rc = mipnerf_mlp_backward(c, (int64_t)M, d_raw, lv[l].act, lv[l].masks, delta, partials, grad_flat, acc, stream))) return rc;
+        if ((rc = mipnerf_mlp_dgrad(c, (int64_t)M, d_raw, lv[l].masks, delta_all + (size_t)l * delta_b, stream))) return rc;
     }
+    // one weight-gradient pass over the wave tiles of all levels (the sum over levels is part of the sample contraction)
+    if ((rc = wgrad_tiles(c, (int64_t)L * (int64_t)(((M + 255) / 256) * 8), act_all, delta_all, partials, grad_flat, accumulate ? 1 : 0,
+                          stream))) return rc;
     if (out)      // optional copies of what MipNerf.forward returns (async device-to-device)
         for (int l = 0; l < L; ++l) {
             const mipnerf_level_out& o = out[l];
