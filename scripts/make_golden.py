@@ -10,7 +10,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-fullsize          round 2: BASELINE configs[1] 4096x128 and configs[3] 8192x256, every ray (~1 min on 8 threads)
     --only-trajectory        round 2: 300-step training trajectories (deterministic / randomized) of the reference's own loop,
                              each run twice (all threads / 1 thread) to record the reference's self-divergence (~20 min)
-    --only-trajectory-long   round 2: converged 1500-step randomized trajectory (~8 min)
+    --only-trajectory-long   round 2: converged 1500-step randomized trajectory, re-run at 4 and 2 threads (~60 min)
     --only-noise             round 2: density_noise > 0 with the reference's four draws replayed
     --only-variants          round 2: 128-wide trunk; use_viewdirs=False
     --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
@@ -431,7 +431,7 @@ TRAJ = dict(batch=256, num_samples=32, steps=300, nbatches=300, lr_init=2e-3, lr
             lr_delay_steps=30, lr_delay_mult=0.01, heldout=1024, param_seed=11, ray_seed=1000, rng_seed=4321)
 
 
-def trajectory_case(name, randomized, threads=None, save=True, overrides=None, self_check=True):
+def trajectory_case(name, randomized, threads=None, save=True, overrides=None, self_check=True, self_threads=()):
     """K-step TRAINING trajectory of the unmodified reference: MipNerf + the loss of nerf_system.py:99-111 +
     torch.optim.Adam (nerf_system.py:71-72) + the reference's MipLRDecay (utils/lr_schedule.py:5-59), on fixed seeded
     batches.  Stored: loss / lr per step, held-out render PSNR, parameter norms at the end.  The randomized variant seeds
@@ -482,6 +482,14 @@ def trajectory_case(name, randomized, threads=None, save=True, overrides=None, s
         out["pnorm_" + k] = np.float64(p.detach().double().norm().item())
     if not save:
         return out
+    if self_threads:
+        # the same run with fewer CPU threads (only the GEMM summation order changes): the reference's own end-point spread
+        alts = [trajectory_case(name, randomized, threads=th, save=False, overrides=overrides) for th in self_threads]
+        torch.set_num_threads(os.cpu_count())
+        out["self_threads"] = np.array(self_threads)
+        out["self_heldout_psnr"] = np.array([float(a["heldout_psnr"]) for a in alts])
+        out["self_loss_tail"] = np.array([float(a["loss"][-100:].mean()) for a in alts])
+        print(f"  reference vs itself at {self_threads} threads: held-out PSNR {out['self_heldout_psnr']} (all threads: {hpsnr:.3f})")
     if not self_check:
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
         print(f"wrote {name}.npz  loss {losses[0]:.5f} -> {losses[-1]:.5f}, held-out PSNR {hpsnr:.3f} dB (train PSNR last 5: "
@@ -530,7 +538,7 @@ if __name__ == "__main__":
         trajectory_case("traj_256x32_rand", randomized=True)
         sys.exit(0)
     if "--only-trajectory-long" in sys.argv:   # converged run: the LR decays 100x, the PSNR curve flattens (bf16 acceptance: 0.1 dB)
-        trajectory_case("traj_256x32_long", randomized=True, self_check=False,
+        trajectory_case("traj_256x32_long", randomized=True, self_check=False, self_threads=(4, 2),
                         overrides=dict(steps=1500, nbatches=1500, max_steps=1500, lr_init=2e-3, lr_final=2e-5, lr_delay_steps=50))
         sys.exit(0)
     if "--only-metrics" in sys.argv:
