@@ -27,6 +27,7 @@ from gen_mlp_bf16 import KERNEL_PREAMBLE, SETPRIO  # noqa: E402
 WAVES = 8
 CHUNK_BYTES = 1024
 PREFETCH = int(os.environ.get("MLP_TRAIN_PREFETCH", "4"))
+ABLATE_TMFMA = os.environ.get("MLP_TRAIN_ABLATE_TMFMA", "0") == "1"    # timing experiment: no transposing MFMAs (wrong T-blocks)
 NE = 3
 
 TRAIN_PREAMBLE = r"""
@@ -280,8 +281,9 @@ def build_fwd_prog(tp: TrainPlan):
                     post.append(f"epilogue_half<{relu}, 0>({acc}, {op.out}[{2 * t}]);  /*op{oi}*/")
                     post.append(f"epilogue_half<{relu}, 8>({acc}, {op.out}[{2 * t + 1}]);  /*op{oi}*/")
                     if hb is not None:
-                        post_t.append(f"TMFMA0({acc}, {op.out}[{2 * t}], P1);  /*op{oi}*/")
-                        post_t.append(f"MFMA({acc}, {op.out}[{2 * t + 1}], P2);  /*op{oi}*/")
+                        if not ABLATE_TMFMA:
+                            post_t.append(f"TMFMA0({acc}, {op.out}[{2 * t}], P1);  /*op{oi}*/")
+                            post_t.append(f"MFMA({acc}, {op.out}[{2 * t + 1}], P2);  /*op{oi}*/")
                         post_late.append(f"store_tfrag<0>({acc}, ht_wave + {(hb + t) * 2048}, lane16);")
                         post_late.append(f"store_tfrag<8>({acc}, ht_wave + {(hb + t) * 2048}, lane16);")
                     if ml is not None:
@@ -528,8 +530,9 @@ def build_dgrad_prog(tp: TrainPlan):
                     post.append(f"depilogue_half<false, 0, 0>({acc}, 0u, {op.out}[{2 * t}]);  /*op{oi}*/")
                     post.append(f"depilogue_half<false, 8, 0>({acc}, 0u, {op.out}[{2 * t + 1}]);  /*op{oi}*/")
                 if op.gblock is not None:      # (the bottleneck delta is consumed in registers only)
-                    post_t.append(f"TMFMA0({acc}, {op.out}[{2 * t}], P1);  /*op{oi}*/")
-                    post_t.append(f"MFMA({acc}, {op.out}[{2 * t + 1}], P2);  /*op{oi}*/")
+                    if not ABLATE_TMFMA:
+                        post_t.append(f"TMFMA0({acc}, {op.out}[{2 * t}], P1);  /*op{oi}*/")
+                        post_t.append(f"MFMA({acc}, {op.out}[{2 * t + 1}], P2);  /*op{oi}*/")
                     post_late.append(f"store_tfrag<0>({acc}, gt_wave + {(op.gblock + t) * 2048}, lane16);")
                     post_late.append(f"store_tfrag<8>({acc}, gt_wave + {(op.gblock + t) * 2048}, lane16);")
             pre = []
