@@ -268,8 +268,14 @@ def run_train(args, e):
     ms = dt / args.steps * 1e3
     peak = PEAK_TFLOPS[args.precision]
     tflops = FLOP_PER_SAMPLE_TRAIN * samples_per_step / (ms * 1e-3) / 1e12
+    traffic, tsrc = None, None
+    pmc = os.path.join(REPO, "profiles", "r02_pmc_train.json")   # HBM bytes/step of the three MFMA kernels, separate --pmc passes
+    if args.precision == "bf16" and native and os.path.exists(pmc) and (B, N) == (4096, 128):
+        with open(pmc) as f:
+            traffic, tsrc = json.load(f).get("hbm_bytes_per_step"), "profiles/r02_pmc_train.json (rocprofv3 --pmc passes, not this run)"
     roofline = {"bound": "mfma", "kernel": "whole step (forward-with-save + dgrad + wgrad MFMA kernels and everything around them)",
-                "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": None,
+                "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": traffic,
+                "traffic_source": tsrc,
                 "flop_per_sample": FLOP_PER_SAMPLE_TRAIN, "samples_per_step": samples_per_step}
     rec = {"value": round(value, 1), "ms_per_step": round(ms, 4), "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
            "roofline": roofline,
