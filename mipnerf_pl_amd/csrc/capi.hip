@@ -493,7 +493,7 @@ int mipnerf_mlp_forward(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, c
         HIP_TRY(launch_bf16_variant(c, enc, viewenc, rgb_sigma, raw, M, N, c->mlp_dma != 0, nullptr, S(stream)));
     } else if (precision == MIPNERF_PREC_FP32) {
         HIP_TRY(mip::launch_mlp_f32(f32net_with_heads(c), c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
-                                    rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, c->dnoise,
+                                    rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, nullptr, c->dnoise,
                                     c->cfg.density_noise, S(stream)));
     } else {
         return fail(MIPNERF_E_INVALID, "unknown precision %d", precision);
@@ -743,11 +743,14 @@ int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host) {
 
 
 // ---- parity-mode (fp32) MLP training: fused forward that saves every layer output + GEMM-based backward ------------
-// `save` = 10 slots of [M, 256] fp32 (layers 0..7 outputs, bottleneck, view-layer output [M,128] in slot 9).
+// `save` = one [M, width] fp32 slot per op of the plan (shipped: layers 0..7 outputs, bottleneck, view-layer output
+// [M,128] in slot 9), followed by the ReLU sign bits of the same slots (1 bit per element, f32_bits_slot_words) that the
+// dgrad epilogue reads instead of the fp32 values.
 size_t mipnerf_mlp_train_f32_bytes(const mipnerf_ctx* c, int64_t M, size_t* save_bytes, size_t* workspace_bytes) {
     if (!c || M < 1) return 0;
     const PlanDesc& P = *c->P;
-    const size_t save = (size_t)P.num_ops * M * P.net_width * 4;          // one [M, width] slot per layer (op) of the plan
+    const size_t save = (size_t)P.num_ops * M * P.net_width * 4           // one [M, width] slot per layer (op) of the plan
+                        + (size_t)P.num_ops * mip::f32_bits_slot_words(M, P.net_width) * 8;   // + their sign bits
     const int splits = kF32WgradSplits;
     const size_t wmax = P.net_width > P.net_width_cond ? P.net_width : P.net_width_cond;
     size_t part = (size_t)splits * wmax * (wmax + P.xyz_dim + 32);                 // split-K partials of the big wgrad GEMMs
@@ -765,7 +768,9 @@ int mipnerf_mlp_forward_train_f32(mipnerf_ctx* c, int64_t M, int32_t N, const fl
         return fail(MIPNERF_E_INVALID, "mlp_forward_train_f32: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train_f32: mipnerf_set_params has not been called");
     HIP_TRY(mip::launch_mlp_f32(f32net_with_heads(c), c->d_stream_f32, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias,
-                                c->cfg.rgb_padding, save, nullptr, 0.0f, S(stream)));
+                                c->cfg.rgb_padding, save,
+                                reinterpret_cast<unsigned long long*>(save + (size_t)c->P->num_ops * M * c->P->net_width), nullptr, 0.0f,
+                                S(stream)));
     return MIPNERF_OK;
 }
 
@@ -788,6 +793,8 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
     const bool acc = accumulate != 0;
     // `save` slot of op L (k_mlp_f32): [M, 32 * hidden tiles] fp32 at offset L * M * W
     auto slot = [&](int L) { return save + (size_t)L * M * W; };
+    const unsigned long long* bits0 = reinterpret_cast<const unsigned long long*>(save + (size_t)PL.num_ops * M * W);
+    auto slot_bits = [&](int L) { return bits0 + (size_t)L * mip::f32_bits_slot_words(M, W); };
     auto P = [&](int t) { return c->pp.p[t]; };                       // fp32 master parameter t (state_dict order)
     auto G = [&](int t) { return grad_flat + c->tab.tensor_off[t]; }; // its gradient
     const int tDensW = 2 * D, tDensB = 2 * D + 1, tExW = 2 * D + 2, tExB = 2 * D + 3, tVW = 2 * D + 4, tVB = 2 * D + 5,
@@ -811,10 +818,11 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
     // dX[M, nin] = dY[M, nout] Wt[nout, ldw] (first nin columns) [+ r1_col[m * r1_ld] * r1_row[n]], then (optionally) the ReLU
     // mask of the layer input x
     auto dgrad = [&](const float* dY, int64_t ldy, int nout, const float* Wt, int64_t ldw, int nin, float* dX, int64_t ldxo,
-                     const float* relu_x, const float* r1_col = nullptr, int64_t r1_ld = 0, const float* r1_row = nullptr) -> hipError_t {
+                     int relu_slot, const float* r1_col = nullptr, int64_t r1_ld = 0, const float* r1_row = nullptr) -> hipError_t {
+        const float* relu_x = relu_slot >= 0 ? slot(relu_slot) : nullptr;
         if (mip::gemm_f32_big_ok(Mi, nin, nout, dY, ldy))
             return mip::launch_gemm_f32_big(false, Mi, nin, nout, dY, ldy, Wt, ldw, dX, ldxo, false, 1, nullptr, relu_x, r1_col, r1_ld,
-                                            r1_row, nullptr, st);
+                                            r1_row, nullptr, st, relu_slot >= 0 ? slot_bits(relu_slot) : nullptr);
         hipError_t e = mip::launch_gemm_f32(false, Mi, nin, nout, dY, ldy, Wt, ldw, 1, false, dX, ldxo, false, 1, nullptr, st);
         if (e == hipSuccess && r1_col)
             e = mip::launch_gemm_f32(false, Mi, nin, 1, r1_col, r1_ld, r1_row, nin, 1, false, dX, ldxo, true, 1, nullptr, st);
@@ -827,17 +835,17 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
         // colour layer (mip_nerf.py:110): d_rgb = d_raw[:, 0:3]
         HIP_TRY(wgrad(d_raw, 4, RGB, hv, Wc, 1, Wc, G(tCW), Wc, G(tCB)));
         // g_hv = (d_rgb Wc) * relu'   [M, Wc] in g0
-        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, Wc, g0, Wc, hv));
+        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, Wc, g0, Wc, D + 1));
         // view layer (mip_nerf.py:106-109): input [bottleneck | view encoding of the sample's ray]
         HIP_TRY(wgrad(g0, Wc, Wc, bott, W, 1, W, G(tVW), W + V, G(tVB)));
         HIP_TRY(wgrad(g0, Wc, Wc, viewenc, 32, N, V, G(tVW) + W, W + V, nullptr));
         // g_bott = g_hv Wv[:, :W]   [M, W] in g1
-        HIP_TRY(dgrad(g0, Wc, Wc, P(tVW), W + V, W, g1, W, nullptr));
+        HIP_TRY(dgrad(g0, Wc, Wc, P(tVW), W + V, W, g1, W, -1));
         // bottleneck (extra_layer, :102) and density head (:100)
         HIP_TRY(wgrad(g1, W, W, x8, W, 1, W, G(tExW), W, G(tExB)));
         HIP_TRY(wgrad(d_raw + 3, 4, 1, x8, W, 1, W, G(tDensW), W, G(tDensB)));
         // g8 = (g_bott We + d_den Wd) * relu'(x8)   in g0: the density head's dgrad is the rank-1 term of the epilogue
-        HIP_TRY(dgrad(g1, W, W, P(tExW), W, W, g0, W, x8, d_raw + 3, 4, P(tDensW)));
+        HIP_TRY(dgrad(g1, W, W, P(tExW), W, W, g0, W, D - 1, d_raw + 3, 4, P(tDensW)));
     } else {
         // MLP.forward(x, None) (mip_nerf.py:99-110): colour and density heads both read the trunk output; extra_layer and
         // view_layers are unused parameters (autograd leaves their .grad None; here: zero unless accumulating)
@@ -848,7 +856,7 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
             for (int u = 0; u < 4; ++u)
                 HIP_TRY(hipMemsetAsync(G(unused[u]), 0, (size_t)PL.param_numel[unused[u]] * 4, st));
         }
-        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, W, g0, W, x8, d_raw + 3, 4, P(tDensW)));
+        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, W, g0, W, D - 1, d_raw + 3, 4, P(tDensW)));
     }
     float* g = g0;          // delta of layer i (gradient w.r.t. its pre-activation)
     float* gn = g1;
@@ -859,7 +867,7 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
         HIP_TRY(wgrad(g, W, W, xin, nin, 1, nin, G(2 * i), ld, G(2 * i + 1)));
         if (ld > nin) HIP_TRY(wgrad(g, W, W, enc, E, 1, E, G(2 * i) + W, ld, nullptr));      // skip concat (:96-97)
         if (i > 0) {
-            HIP_TRY(dgrad(g, W, W, P(2 * i), ld, W, gn, W, slot(i - 1)));
+            HIP_TRY(dgrad(g, W, W, P(2 * i), ld, W, gn, W, i - 1));
             float* t = g; g = gn; gn = t;
         }
     }

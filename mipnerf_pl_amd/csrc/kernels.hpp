@@ -154,8 +154,10 @@ struct F32Net {
 };
 hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float* bias_tab, const float* enc,
                           const float* viewenc, float* rgb_sigma, float* raw_out, int64_t M, int num_samples,
-                          float density_bias, float rgb_padding, float* save, const float* dnoise, float dnoise_scale,
-                          hipStream_t st);
+                          float density_bias, float rgb_padding, float* save, unsigned long long* save_bits, const float* dnoise,
+                          float dnoise_scale, hipStream_t st);
+// words (uint64) of one slot of the ReLU sign-bit side table of `save` (k_mlp_f32 writes it, the dgrad epilogue reads it)
+__host__ __device__ inline int64_t f32_bits_slot_words(int64_t M, int W) { return ((M * (W / 4) + 63) / 64) * 4; }
 
 // ---- kernels_gemm_f32.hip (parity-mode backward) -------------------------------------------------
 hipError_t launch_gemm_f32(bool trans_a, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
@@ -164,7 +166,8 @@ hipError_t launch_gemm_f32(bool trans_a, int M, int N, int64_t K, const float* A
 bool gemm_f32_big_ok(int M, int N, int64_t K, const float* A, int64_t lda);
 hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                                float* C, int64_t ldc, bool accumulate, int splits, float* partial, const float* relu_x,
-                               const float* r1_col, int64_t r1_ld, const float* r1_row, float* bias_out, hipStream_t st);
+                               const float* r1_col, int64_t r1_ld, const float* r1_row, float* bias_out, hipStream_t st,
+                               const unsigned long long* relu_bits = nullptr);
 hipError_t launch_thin_wgrad(int64_t S, int C, int R, const float* Xc, int64_t ldxc, const float* Yr, int64_t ldyr, int rowdiv,
                              float* out, int64_t ldo_c, int64_t ldo_r, float* out_bias, bool accumulate, float* partial,
                              hipStream_t st);

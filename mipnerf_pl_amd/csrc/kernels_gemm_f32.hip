@@ -101,6 +101,7 @@ struct GemmEpi {
     const float* r1_col;     // [M] with stride r1_ld, or null
     const float* r1_row;     // [N]
     int64_t r1_ld;
+    const unsigned long long* relu_bits;   // sign bits of relu_x written by k_mlp_f32 (f32_bits_slot_words layout, vpr = ldc / 4) or null
 };
 template <bool TA, int KB, int GM, int GN>
 __global__ void __launch_bounds__(GT)
@@ -236,7 +237,10 @@ k_gemm_f32_big(int M, int N, int64_t K, const float* __restrict__ A, int64_t lda
                 float v = acc[i][j][r];
                 if (gridDim.z > 1) { partial[((int64_t)blockIdx.z * M + m) * N + n] = v; continue; }
                 if (epi.r1_col) v += epi.r1_col[m * epi.r1_ld] * r1w;
-                if (epi.relu_x && !(epi.relu_x[m * ldc + n] > 0.0f)) v = 0.0f;
+                if (epi.relu_bits) {          // 1 bit instead of 4 bytes per element: float4 number F of the [M, ldc] slot, component n & 3
+                    const int64_t F = m * (ldc >> 2) + (n >> 2);
+                    if (!((epi.relu_bits[(F >> 6) * 4 + (n & 3)] >> (F & 63)) & 1ull)) v = 0.0f;
+                } else if (epi.relu_x && !(epi.relu_x[m * ldc + n] > 0.0f)) v = 0.0f;
                 C[m * ldc + n] = accumulate ? C[m * ldc + n] + v : v;
             }
         }
@@ -266,6 +270,7 @@ k_thin_wgrad(int64_t S, int C, int R, const float* __restrict__ Xc, int64_t ldxc
         for (int64_t g0 = s0; g0 < s1; g0 += rowdiv) {
             const int64_t g1 = g0 + rowdiv < s1 ? g0 + rowdiv : s1;
             float xs = 0.0f;
+#pragma unroll 8
             for (int64_t s = g0 + sl; s < g1; s += 4) xs += c < C ? Xc[s * ldxc + c] : 1.0f;
             const float* y = Yr + (g0 / rowdiv) * ldyr;
 #pragma unroll
@@ -289,25 +294,100 @@ k_thin_wgrad(int64_t S, int C, int R, const float* __restrict__ Xc, int64_t ldxc
             partial[((int64_t)blockIdx.y * R + r) * CC + c] = ((red[0][col_l][r] + red[1][col_l][r]) + red[2][col_l][r]) + red[3][col_l][r];
 }
 
+// Same contract for the heads proper (R <= 4 output rows, rowdiv == 1, C % 4 == 0, 16-byte aligned rows): a thread owns FOUR
+// consecutive columns, so a wavefront reads whole 1-KiB row segments (float4 per lane) with several rows in flight, instead of
+// 256-byte pieces one row at a time (0.31 -> 0.1x ms per head at 524,288 x 256).  The bias column is summed by lane 0 of column
+// block 0 from the same (wave-uniform) Yr values.
+__global__ void __launch_bounds__(256)
+k_thin_wgrad_v4(int64_t S, int C, int R, const float* __restrict__ Xc, int64_t ldxc, const float* __restrict__ Yr, int64_t ldyr,
+                int bias, int64_t slice, float* __restrict__ partial) {
+    __shared__ float red[4][64][20];
+    const int lane = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 256 + lane * 4;
+    const int CC = C + (bias ? 1 : 0);
+    const int64_t s0 = (int64_t)blockIdx.y * slice;
+    const int64_t s1 = s0 + slice < S ? s0 + slice : S;
+    float acc[4][4], ysum[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ysum[r] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[r][k] = 0.0f;
+    }
+    const bool colok = c0 < C;
+#pragma unroll 8
+    for (int64_t s = s0 + sl; s < s1; s += 4) {
+        const float4 x = colok ? *reinterpret_cast<const float4*>(Xc + s * ldxc + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* y = Yr + s * ldyr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < R) {
+                const float yv = y[r];
+                acc[r][0] = fmaf(x.x, yv, acc[r][0]); acc[r][1] = fmaf(x.y, yv, acc[r][1]);
+                acc[r][2] = fmaf(x.z, yv, acc[r][2]); acc[r][3] = fmaf(x.w, yv, acc[r][3]);
+                ysum[r] += yv;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[sl][lane][r * 4 + k] = acc[r][k];
+        red[sl][lane][16 + r] = ysum[r];
+    }
+    __syncthreads();
+    if (sl != 0) return;
+    for (int r = 0; r < R; ++r) {
+        float* dst = partial + ((int64_t)blockIdx.y * R + r) * CC;
+        if (colok)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                dst[c0 + k] = ((red[0][lane][r * 4 + k] + red[1][lane][r * 4 + k]) + red[2][lane][r * 4 + k]) + red[3][lane][r * 4 + k];
+        if (bias && blockIdx.x == 0 && lane == 0)
+            dst[C] = ((red[0][0][16 + r] + red[1][0][16 + r]) + red[2][0][16 + r]) + red[3][0][16 + r];
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_thin_reduce(int nslices, int C, int R, int bias, const float* __restrict__ partial, float* __restrict__ out, int64_t ldo_c,
               int64_t ldo_r, float* __restrict__ out_bias, int accumulate) {
+    // 64 outputs x 4 slice groups per workgroup (fixed combination order), as k_gemm_reduce
+    __shared__ float red[4][64];
     const int CC = C + (bias ? 1 : 0);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R * CC) return;
-    const int r = i / CC, c = i - r * CC;
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
+    const bool live = i < R * CC;
+    const int r = live ? i / CC : 0, c = live ? i - r * CC : 0;
     float s = 0.0f;
-    for (int z = 0; z < nslices; ++z) s += partial[((int64_t)z * R + r) * CC + c];
+    if (live) {
+#pragma unroll 8
+        for (int z = g; z < nslices; z += 4) s += partial[((int64_t)z * R + r) * CC + c];
+    }
+    red[g][o] = s;
+    __syncthreads();
+    if (g != 0 || !live) return;
+    s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
     float* dst = c < C ? out + c * ldo_c + r * ldo_r : out_bias + r;
     *dst = accumulate ? *dst + s : s;
 }
 
 __global__ void __launch_bounds__(256)
 k_gemm_reduce(int M, int N, int splits, const float* __restrict__ partial, float* __restrict__ C, int64_t ldc, int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)M * N) return;
+    // 64 outputs x 4 split groups per workgroup: group g sums splits g, g+4, ... (eight loads in flight), the four group sums
+    // are combined in a fixed order -> deterministic, and 4x the memory-level parallelism of one thread per output
+    __shared__ float red[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t mn = (int64_t)M * N;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
     float s = 0.0f;
-    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * M * N + i];
+    if (i < mn) {
+        const float* p = partial + i;
+#pragma unroll 8
+        for (int z = g; z < splits; z += 4) s += p[(int64_t)z * mn];
+    }
+    red[g][o] = s;
+    __syncthreads();
+    if (g != 0 || i >= mn) return;
+    s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
     const int64_t m = i / N, n = i - m * N;
     C[m * ldc + n] = accumulate ? C[m * ldc + n] + s : s;
 }
@@ -333,7 +413,7 @@ hipError_t launch_gemm_f32(bool trans_a, int M, int N, int64_t K, const float* A
                            accumulate ? 1 : 0, partial);
     if (splits > 1) {
         const int64_t n = (int64_t)M * N;
-        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, M, N, splits, partial, C, ldc,
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, M, N, splits, partial, C, ldc,
                            accumulate ? 1 : 0);
     }
     return hipGetLastError();
@@ -348,13 +428,14 @@ bool gemm_f32_big_ok(int M, int N, int64_t K, const float* A, int64_t lda) {
 // reduced over the splits like C.  `partial` must hold splits * M * (N + 1) floats.
 hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                                float* C, int64_t ldc, bool accumulate, int splits, float* partial, const float* relu_x,
-                               const float* r1_col, int64_t r1_ld, const float* r1_row, float* bias_out, hipStream_t st) {
+                               const float* r1_col, int64_t r1_ld, const float* r1_row, float* bias_out, hipStream_t st,
+                               const unsigned long long* relu_bits) {
     if (splits < 1) splits = 1;
     if (!gemm_f32_big_ok(M, N, K, A, lda) || ((relu_x || r1_col) && (splits != 1 || trans_a)) || (bias_out && !trans_a))
         return hipErrorInvalidValue;
     const int b_vec = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
     float* bias_partial = bias_out ? partial + (int64_t)splits * M * N : nullptr;
-    const GemmEpi epi = {relu_x, r1_col, r1_row, r1_ld};
+    const GemmEpi epi = {relu_x, r1_col, r1_row, r1_ld, relu_x && ldc % 4 == 0 ? relu_bits : nullptr};
     constexpr int kLds = 2 * 16 * (256 + 4 + 128 + 4) * 4;
     static bool attr_done = false;
     if (!attr_done) {
@@ -375,16 +456,17 @@ hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const floa
     }
     if (splits > 1) {
         const int64_t n = (int64_t)M * N;
-        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, M, N, splits, partial, C, ldc,
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, M, N, splits, partial, C, ldc,
                            accumulate ? 1 : 0);
     }
     if (bias_out)
-        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, M, 1, splits, bias_partial, bias_out,
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, st, M, 1, splits, bias_partial, bias_out,
                            (int64_t)1, accumulate ? 1 : 0);
     return hipGetLastError();
 }
 
-// thin weight gradient (see k_thin_wgrad).  `partial` needs ceil(S / 2048) * R * (C + 1) floats.
+// thin weight gradient (see k_thin_wgrad).  `partial` needs ceil(S / 2048) * max(R, 16) * (C + 1) floats (the float4 path for
+// R <= 4 cuts 512-sample slices).
 hipError_t launch_thin_wgrad(int64_t S, int C, int R, const float* Xc, int64_t ldxc, const float* Yr, int64_t ldyr, int rowdiv,
                              float* out, int64_t ldo_c, int64_t ldo_r, float* out_bias, bool accumulate, float* partial,
                              hipStream_t st) {
@@ -393,12 +475,24 @@ hipError_t launch_thin_wgrad(int64_t S, int C, int R, const float* Xc, int64_t l
     const int nslices = (int)((S + slice - 1) / slice);
     const int bias = out_bias ? 1 : 0;
     const dim3 grid((unsigned)((C + bias + 63) / 64), (unsigned)nslices);
+    if (R <= 4 && rowdiv == 1 && C % 4 == 0 && ldxc % 4 == 0 && (uintptr_t)Xc % 16 == 0) {
+        // 512-sample slices: ~4 workgroups per CU and 8 rows in flight per wave cover the HBM latency (2048-sample slices with
+        // 4 in flight streamed at 1.7 TB/s); 4 x the slices of the generic path at <= 1/8 of its rows: same partial buffer
+        const int64_t slice4 = 512;
+        const int nsl4 = (int)((S + slice4 - 1) / slice4);
+        hipLaunchKernelGGL(k_thin_wgrad_v4, dim3((unsigned)((C + 255) / 256), (unsigned)nsl4), dim3(256), 0, st, S, C, R, Xc, ldxc, Yr,
+                           ldyr, bias, slice4, partial);
+        const int n4 = R * (C + bias);
+        hipLaunchKernelGGL(k_thin_reduce, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, nsl4, C, R, bias, partial, out, ldo_c, ldo_r,
+                           out_bias, accumulate ? 1 : 0);
+        return hipGetLastError();
+    }
     if (R <= 4)
         hipLaunchKernelGGL(k_thin_wgrad<4>, grid, dim3(256), 0, st, S, C, R, Xc, ldxc, Yr, ldyr, rowdiv, bias, slice, partial);
     else
         hipLaunchKernelGGL(k_thin_wgrad<32>, grid, dim3(256), 0, st, S, C, R, Xc, ldxc, Yr, ldyr, rowdiv, bias, slice, partial);
     const int n = R * (C + bias);
-    hipLaunchKernelGGL(k_thin_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, nslices, C, R, bias, partial, out, ldo_c, ldo_r,
+    hipLaunchKernelGGL(k_thin_reduce, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, nslices, C, R, bias, partial, out, ldo_c, ldo_r,
                        out_bias, accumulate ? 1 : 0);
     return hipGetLastError();
 }

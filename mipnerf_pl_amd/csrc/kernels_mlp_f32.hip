@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(kF32Waves * 64)
 k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __restrict__ bias_tab,
           const float* __restrict__ enc, const float* __restrict__ viewenc, float4* __restrict__ rgb_sigma,
           float4* __restrict__ raw_out, int64_t M, int num_samples, int ntiles_total, float density_bias,
-          float rgb_padding, float* __restrict__ save, const float* __restrict__ dnoise, float dnoise_scale) {
+          float rgb_padding, float* __restrict__ save, unsigned long long* __restrict__ save_bits,
+          const float* __restrict__ dnoise, float dnoise_scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* X = reinterpret_cast<float*>(smem_raw);
     const int tid = threadIdx.x;
@@ -48,6 +49,27 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
     const int ldx = net.ldx;
     const int W = net.width;
     const int ecol = net.enc_col;
+
+    // deferred copy of a layer's output into `save` (slot pend_slot = [M, pend_width] fp32) + its ReLU sign bits for the dgrad
+    // epilogue (k_gemm_f32_big): float4 number F = s * vpr + c4 of the slot <-> bit F & 63 of the four words [(F >> 6) * 4 + k],
+    // k = component; one wavefront covers one 64-float4 group (item strides are multiples of 64)
+    int pend_slot = 0, pend_xout = 0, pend_width = 0, pend_done = 0, pend_items = 0;
+    auto save_item = [&](int64_t s0, int it) {
+        const int vpr = pend_width / 4;
+        const int i = tid + it * (int)blockDim.x;
+        const int r = i / vpr, c4 = i - r * vpr;
+        const int64_t s = s0 + r;
+        const float4 v = *reinterpret_cast<const float4*>(X + r * ldx + pend_xout + c4 * 4);
+        const bool live = s < M;
+        if (live) *reinterpret_cast<float4*>(save + (int64_t)pend_slot * M * W + s * pend_width + c4 * 4) = v;
+        if (save_bits) {
+            const unsigned long long b0 = __ballot(live && v.x > 0.0f), b1 = __ballot(live && v.y > 0.0f),
+                                     b2 = __ballot(live && v.z > 0.0f), b3 = __ballot(live && v.w > 0.0f);
+            const int64_t g = (s0 * vpr + i) >> 6;
+            if (lane < 4 && (g << 6) < M * vpr)
+                save_bits[(int64_t)pend_slot * f32_bits_slot_words(M, W) + g * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+        }
+    };
 
     for (int tile = blockIdx.x; tile < ntiles_total; tile += gridDim.x) {
         const int64_t s0 = (int64_t)tile * kF32TileSamples;
@@ -107,6 +129,7 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                         }
                         a0 = n0;
                         a1 = n1;
+                        if (pend_done < pend_items) save_item(s0, pend_done++);     // previous layer's output -> save (see below)
                     }
                     // ---- this tile's results: the OTHER activation buffer (nobody reads it during this layer)
 #pragma unroll
@@ -163,6 +186,7 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                         *reinterpret_cast<const float4*>(viewenc + ray * 32 + c4 * 4);
                 }
             }
+            while (pend_done < pend_items) save_item(s0, pend_done++);     // what the k loop did not cover (idle waves, thin heads)
             __syncthreads();     // this layer's outputs are visible; its input buffer is free
             if (ly.kind == 2 && wave == 0) {
                 // finalise: sum the 8 k-slice partials in wave order, add the biases, activations (mip_nerf.py:232-238)
@@ -184,28 +208,24 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                 }
             }
             if (save && ly.kind != 2) {
-                // training (parity mode): keep this layer's output -- slot L of `save` is [M, width] fp32, width =
-                // 32 x (hidden tiles); the density tile of the head is not part of the bottleneck.  The next layer
-                // writes the OTHER buffer, so no barrier is needed after this copy.
-                const int width = 32 * (ly.ntiles - (ly.kind == 1 ? 1 : 0));
-                float* dst = save + (int64_t)L * M * W;
-                const int vpr = width / 4;
-                for (int i = tid; i < kF32TileSamples * vpr; i += blockDim.x) {
-                    const int r = i / vpr, c4 = i - r * vpr;
-                    const int64_t s = s0 + r;
-                    if (s < M)
-                        *reinterpret_cast<float4*>(dst + s * width + c4 * 4) =
-                            *reinterpret_cast<const float4*>(X + r * ldx + ly.x_out + c4 * 4);
-                }
+                // training (parity mode): keep this layer's output.  The copy is deferred into the NEXT layer's k loop (one
+                // float4 per thread and k block, in the shadow of that layer's MFMAs): the next layer reads this buffer and
+                // writes the other one, so the values stay put until the next layer's closing barrier
+                pend_slot = L;
+                pend_xout = ly.x_out;
+                pend_width = 32 * (ly.ntiles - (ly.kind == 1 ? 1 : 0));     // the density tile of the head is not part of the bottleneck
+                pend_done = 0;
+                pend_items = kF32TileSamples * (pend_width / 4) / (int)blockDim.x;
             }
         }
+        while (pend_done < pend_items) save_item(s0, pend_done++);     // the last layer's output (no next layer to hide behind)
     }
 }
 
 hipError_t launch_mlp_f32(const F32Net& net_in, const float* stream_w, const float* bias_tab, const float* enc,
                           const float* viewenc, float* rgb_sigma, float* raw_out, int64_t M, int num_samples,
-                          float density_bias, float rgb_padding, float* save, const float* dnoise, float dnoise_scale,
-                          hipStream_t st) {
+                          float density_bias, float rgb_padding, float* save, unsigned long long* save_bits, const float* dnoise,
+                          float dnoise_scale, hipStream_t st) {
     const F32Net& net = net_in;
     if (!net.dens_w || !net.dens_b || !net.col_w || !net.col_b || net.num_rgb > 3 || net.width > 32 * kF32Waves * kF32Rounds ||
         net.ldx - net.enc_col - 4 < 64)      // VALU-head partials live in encoding columns [32, 64)
@@ -221,7 +241,7 @@ hipError_t launch_mlp_f32(const F32Net& net_in, const float* stream_w, const flo
     int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(k_mlp_f32, dim3(grid), dim3(kF32Waves * 64), lds, st, net, stream_w, bias_tab, enc, viewenc,
-                       (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save, dnoise, dnoise_scale);
+                       (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save, save_bits, dnoise, dnoise_scale);
     return hipGetLastError();
 }
 
