@@ -3,8 +3,9 @@
 `render_image` follow the reference line by line; Lightning itself stays third-party: if
 `pytorch_lightning` is importable the class derives from `LightningModule`, otherwise from a minimal
 shim (nn.Module + hparams/log) so the hooks can be driven by a plain loop (bench.py --mode train).
-Datasets / dataloaders are out of scope: `setup` uses the reference's `datasets` package
-when it is on sys.path."""
+`setup` / `train_dataloader` / `val_dataloader` read the reference's dataset directories through
+`mipnerf_pl_amd.datasets` (images + camera table resident on the device, rays generated per batch by the HIP kernel; SURVEY
+8f-1) and hand Lightning a device-side `RayLoader` instead of a host `DataLoader`."""
 from __future__ import annotations
 
 import torch
@@ -113,19 +114,17 @@ class MipNeRFSystem(_Base):
     def forward(self, batch_rays, randomized: bool, white_bkgd: bool):
         return self.mip_nerf(batch_rays, randomized, white_bkgd)     # nerf_system.py:50-54
 
-    def setup(self, stage):   # nerf_system.py:56-68 (datasets are the reference's, out of scope here)
-        try:
-            from datasets import dataset_dict
-        except Exception as e:  # noqa: BLE001
-            raise RuntimeError("MipNeRFSystem.setup needs the reference's `datasets` package on sys.path "
-                               "(data loading is outside the native hot path)") from e
+    def setup(self, stage=None):   # nerf_system.py:56-68
+        from .datasets import dataset_dict
         dataset = dataset_dict[self.hparams['dataset_name']]
+        dev = next(self.mip_nerf.parameters()).device          # the datasets live where the model lives
+        dev = dev if dev.type == "cuda" else None              # (None: the current HIP device, if any)
         self.train_dataset = dataset(data_dir=self.hparams['data_path'], split='train',
                                      white_bkgd=self.hparams['train.white_bkgd'],
-                                     batch_type=self.hparams['train.batch_type'])
+                                     batch_type=self.hparams['train.batch_type'], device=dev)
         self.val_dataset = dataset(data_dir=self.hparams['data_path'], split='val',
                                    white_bkgd=self.hparams['val.white_bkgd'],
-                                   batch_type=self.hparams['val.batch_type'])
+                                   batch_type=self.hparams['val.batch_type'], device=dev)
 
     def configure_optimizers(self):   # nerf_system.py:70-76
         hp = self.hparams
@@ -152,15 +151,13 @@ class MipNeRFSystem(_Base):
         self._optimizer_for_log = optimizer
         return [optimizer], [{'scheduler': scheduler, 'interval': 'step'}]
 
-    def train_dataloader(self):   # nerf_system.py:78-83
-        from torch.utils.data import DataLoader
-        return DataLoader(self.train_dataset, shuffle=True, num_workers=self.hparams['train.num_work'],
-                          batch_size=self.hparams['train.batch_size'], pin_memory=True)
+    def train_dataloader(self):   # nerf_system.py:78-83: shuffled batches of `train.batch_size` rays, drawn on the device
+        from .datasets import RayLoader
+        return RayLoader(self.train_dataset, batch_size=self.hparams['train.batch_size'], shuffle=True)
 
-    def val_dataloader(self):     # nerf_system.py:85-93
-        from torch.utils.data import DataLoader
-        return DataLoader(self.val_dataset, shuffle=False, num_workers=1, batch_size=1, pin_memory=True,
-                          persistent_workers=True)
+    def val_dataloader(self):     # nerf_system.py:85-93: one whole image per item
+        from .datasets import RayLoader
+        return RayLoader(self.val_dataset, batch_size=1, shuffle=False)
 
     def compute_loss(self, ret, rays, rgbs):
         """nerf_system.py:99-111."""

@@ -13,6 +13,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-trajectory-long   round 2: converged 1500-step randomized trajectory, re-run at 4 and 2 threads (~60 min)
     --only-noise             round 2: density_noise > 0 with the reference's four draws replayed
     --only-variants          round 2: 128-wide trunk; use_viewdirs=False
+    --only-datasets          round 2: Blender / Multicam / RealData360 / RenderGen on the synthetic datasets of tests/dataset_fixture.py
     --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
     --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
 
@@ -511,8 +512,76 @@ def trajectory_case(name, randomized, threads=None, save=True, overrides=None, s
     print(f"wrote {name}.npz  loss {losses[0]:.5f} -> {losses[-1]:.5f}, held-out PSNR {hpsnr:.3f} dB, lr {lrs[0]:.2e} .. {max(lrs):.2e} .. {lrs[-1]:.2e}")
 
 
+
+def datasets_case(name):
+    """Dataset goldens (round 2): the reference's OWN `Blender`, `Multicam`, `RealData360` classes (datasets.py:84-474) and
+    `RenderGen` (render_video.py:19-118, class body exec'd from the mounted file because the module imports Lightning) run on
+    the tiny synthetic datasets of tests/dataset_fixture.py.  Stored: every image and every ray of every split."""
+    import ast
+    import collections
+    import tempfile
+    from datasets.datasets import Blender, Multicam, RealData360
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dataset_fixture as fx
+    out = {}
+
+    def dump(tag, ds, per_image):
+        # train split: flattened over all images; val / test: lists per image
+        if not per_image:
+            out[tag + "_images"] = np.asarray(ds.images, dtype=np.float64)
+            for k in RefRays._fields:
+                out[f"{tag}_{k}"] = np.asarray(getattr(ds.rays, k), dtype=np.float64)
+        else:
+            out[tag + "_n"] = np.int64(len(ds.images))
+            for i in range(len(ds.images)):
+                out[f"{tag}_image{i}"] = np.asarray(ds.images[i], dtype=np.float64)
+                for k in RefRays._fields:
+                    out[f"{tag}{i}_{k}"] = np.asarray(getattr(ds.rays, k)[i], dtype=np.float64)
+
+    with tempfile.TemporaryDirectory() as tmp:
+        b = fx.write_blender(os.path.join(tmp, "blender"))
+        dump("blender_train", Blender(b, "train", True, "all_images"), False)
+        dump("blender_val", Blender(b, "val", True, "single_image"), True)
+        dump("blender_train_black", Blender(b, "train", False, "all_images"), False)
+        m = fx.write_multicam(os.path.join(tmp, "multicam"))
+        dump("multicam_train", Multicam(m, "train", True, "all_images"), False)
+        dump("multicam_test", Multicam(m, "test", True, "single_image"), True)
+        l = fx.write_llff(os.path.join(tmp, "llff"))
+        tr = RealData360(l, "train", True, "all_images", factor=4)
+        dump("llff_train", tr, False)
+        te = RealData360(l, "test", True, "single_image", factor=4)
+        dump("llff_test", te, True)
+        out["llff_train_c2w"] = np.asarray(tr.camtoworlds, dtype=np.float64)
+        out["llff_test_c2w"] = np.asarray(te.camtoworlds, dtype=np.float64)
+        out["llff_K_inv"] = np.asarray(tr.K_inv, dtype=np.float64)
+    # RenderGen + create_spheric_poses: exec the two definitions from the mounted files
+    for mod in ("torchvision", "torchvision.transforms", "matplotlib", "matplotlib.pyplot"):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules["cv2"].COLORMAP_JET = 2        # default argument evaluated at import (utils/vis.py:75)
+    from utils.vis import create_spheric_poses
+    src = open(os.path.join(REF, "render_video.py")).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "RenderGen"][0]
+    ns = dict(np=np, Dataset=torch.utils.data.Dataset, create_spheric_poses=create_spheric_poses, Rays=RefRays,
+              Rays_keys=RefRays._fields, collections=collections)
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "render_video.py", "exec"), ns)
+    focal = .5 * 24 / np.tan(.5 * 0.6911112070083618)
+    rg = ns["RenderGen"](focal, [24, 20], 2)
+    out["render_focal"] = np.float64(focal)
+    out["render_n"] = np.int64(len(rg))
+    out["render_poses"] = np.asarray(create_spheric_poses(4), dtype=np.float64)
+    for i in (0, 7, 119, 120, 239):
+        r = rg[i]
+        for k in RefRays._fields:
+            out[f"render{i}_{k}"] = np.asarray(getattr(r, k), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"[golden] {name}: {len(out)} arrays")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
+    if "--only-datasets" in sys.argv:       # round 2: the on-disk formats through the reference's dataset classes
+        datasets_case("datasets_tiny")
+        sys.exit(0)
     if "--only-variants" in sys.argv:       # round 2: other reference-legal MLP shapes
         variant_case("var_w128_48x64", 48, 64, param_seed=12, gain=20.0, ray_seed=12, mlp_net_width=128, mlp_net_width_condition=128)
         variant_case("var_noview_48x64", 48, 64, param_seed=13, gain=20.0, ray_seed=13, mlp_net_width_condition=256, use_viewdirs=False)
