@@ -247,6 +247,7 @@ k_loss_fused(int64_t B, int nlevels, const float* __restrict__ rgb0, const float
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double acc[6] = {0, 0, 0, 0, 0, 0};     // sum mask, sum mask se0, sum mask se1, sum dl0, sum dl1, sum se_fine (unmasked)
     const float* rgbf = nlevels > 1 ? rgb1 : rgb0;
+#pragma unroll 4
     for (int64_t b = tid; b < B; b += blockDim.x) {
         const float m = lossmult ? lossmult[b] : 1.0f;
         float se0 = 0.f, se1 = 0.f, sef = 0.f;

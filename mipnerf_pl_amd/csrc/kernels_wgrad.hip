@@ -128,15 +128,25 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ partials, const int32_t* __restrict__ otab, const int2* __restrict__ job_slots,
                float* __restrict__ grad_flat, float* __restrict__ scratch, int nparams, int accumulate) {
+    // 64 positions x 4 split groups per workgroup: group g sums splits g, g+4, ... with several loads in flight, the four group
+    // sums meet in LDS in a fixed order (deterministic; one thread per position walked the ~26 splits one load at a time)
+    __shared__ float red[4][64];
     const int job = blockIdx.y;
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= kWgradJobFloats) return;
-    const int32_t idx = otab[(int64_t)job * kWgradJobFloats + pos];
-    if (idx < 0) return;
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int pos = blockIdx.x * 64 + o;
+    const bool live = pos < kWgradJobFloats;
+    const int32_t idx = live ? otab[(int64_t)job * kWgradJobFloats + pos] : -1;
     const int2 js = job_slots[job];                          // first partial slot, number of splits
-    const float* p = partials + (int64_t)js.x * kWgradJobFloats + pos;
     float s = 0.0f;
-    for (int k = 0; k < js.y; ++k) s += p[(int64_t)k * kWgradJobFloats];
+    if (idx >= 0) {
+        const float* p = partials + (int64_t)js.x * kWgradJobFloats + pos;
+#pragma unroll 8
+        for (int k = g; k < js.y; k += 4) s += p[(int64_t)k * kWgradJobFloats];
+    }
+    red[g][o] = s;
+    __syncthreads();
+    if (g != 0 || idx < 0) return;
+    s = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
     if (idx >= nparams) scratch[idx - nparams] = s;
     else grad_flat[idx] = accumulate ? grad_flat[idx] + s : s;     // every parameter has exactly one source position
 }
@@ -224,7 +234,7 @@ hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs
 hipError_t launch_wgrad_reduce(const float* partials, const int32_t* otab, const void* job_slots, int njobs,
                                float* grad_flat, float* scratch, int nparams, const WgradPost& post, bool accumulate,
                                hipStream_t st) {
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((kWgradJobFloats + 255) / 256, njobs), dim3(256), 0, st, partials, otab,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((kWgradJobFloats + 63) / 64, njobs), dim3(256), 0, st, partials, otab,
                        (const int2*)job_slots, grad_flat, scratch, nparams, accumulate ? 1 : 0);
     const int n = post.W * post.W + post.Wc * post.W + post.W + post.Wc;
     hipLaunchKernelGGL(k_wgrad_post, dim3((n + 255) / 256), dim3(256), 0, st, post, scratch, grad_flat, accumulate ? 1 : 0);
