@@ -397,6 +397,46 @@ def cpu_baseline(args, rays_np, params):
                       f"BLAS threads = all cores)"}
 
 
+def cpu_baseline_train(args, rays_np, params, threads):
+    """The reference's own training step on this host for the train sub-record ("also time fwd+bwd with the
+    nerf_system loss"): staged reference MipNerf.forward(randomized=True) + the loss of nerf_system.py:99-111 (restated: the
+    module needs Lightning) + backward + torch.optim.Adam, on a BOUNDED sample of 1024 rays of the same batch."""
+    import numpy as np
+    import torch
+    from oracle import ref as oref
+    r = oref.load()
+    if r is None:
+        return None
+    N, nb = args.samples, 1024
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = r.MipNerf(num_samples=N)
+    model.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    RR = r.Rays(*[torch.from_numpy(np.asarray(a)[:nb].copy()) for a in rays_np])
+    gt = torch.rand(nb, 3)
+
+    def step():
+        ret = model(RR, True, True)
+        mask = RR.lossmult
+        terms = [(mask * (rgb - gt) ** 2).sum() / mask.sum() + 0.01 * r.mip.distloss(w, t) for rgb, _, _, w, t in ret]
+        loss = 0.1 * terms[0] + terms[1]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    step()
+    ts = []
+    for _ in range(2):
+        c0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - c0)
+    sec = min(ts)
+    return {"value": round(nb * N * 2 / sec, 1), "unit": "ray-samples/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "reference",
+            "seconds_per_step": round(sec, 3),
+            "sample": f"best of 2 x the reference's training step (oracle/_ref MipNerf.forward randomized + nerf_system.py:99-111 loss + "
+                      f"backward + torch Adam, fp32, {threads} threads) on {nb} of the {args.rays} rays x {N} samples x 2 levels"}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -426,6 +466,11 @@ def main():
     cpu = None
     if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline and inputs is not None:
         cpu = cpu_baseline(args, *inputs)
+        if "train" in recs and recs["train"].get("value") and cpu.get("kind") == "reference":
+            try:
+                recs["train"]["cpu_baseline"] = cpu_baseline_train(args, *inputs, cpu["cores"])
+            except Exception as ex:  # noqa: BLE001  (a baseline must not take the line down)
+                recs["train"]["cpu_baseline"] = {"error": f"{type(ex).__name__}: {ex}"}
     if e.rank == 0:
         line = {"metric": "ray-samples/sec", "value": head["value"], "unit": "ray-samples/s", "n_gpus": e.world,
                 "steps": head["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"], "higher_is_better": True,

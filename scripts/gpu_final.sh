@@ -39,4 +39,5 @@ print(f"{sys.argv[2]} k_mlp_bf16 mean per dispatch {sum(v)/max(1,len(v)):.6g} KB
 PY
   rm -rf $OUT/pmc_$c
 done
+OUT=$OUT bash $ROOT/scripts/pmc_train.sh > $OUT/pmc_train.log 2>&1; tail -6 $OUT/pmc_train.log
 date

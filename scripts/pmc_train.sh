@@ -1,5 +1,7 @@
+# HBM traffic of the three bf16 training kernels: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over the eager
+# training bench (summary -> profiles/r02_pmc_train.json).   usage: [OUT=dir] pmc_train.sh
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r02p; mkdir -p $OUT
+OUT=${OUT:-$GRAFT_REPO_ROOT/gpurun_out/pmc_train}; mkdir -p $OUT
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --mode train --steps 3 --warmup 1 --no-graph --no-cpu-baseline > $OUT/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
