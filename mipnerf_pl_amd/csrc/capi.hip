@@ -13,7 +13,8 @@
 #include "mlp_plan_gen.hpp"
 
 // binary tables of the training kernels (mlp_train_plan.TrainPlan.blob()), linked in through train_tables.c (.incbin)
-extern "C" const unsigned char mip_train_tables[];
+extern "C" const unsigned char mip_train_tables[];       // variant 0
+extern "C" const unsigned char mip_train_tables_v1[];    // variant 1 (build.py TRAIN_TABLE_VARIANTS)
 
 namespace {
 
@@ -186,8 +187,9 @@ struct TrainTables {
     const int32_t* otab;     // [njobs * job_floats] flat parameter index or -1
 };
 
-bool train_tables(TrainTables& T) {
-    const int32_t* h = reinterpret_cast<const int32_t*>(mip_train_tables);
+bool train_tables(TrainTables& T, int variant = 0) {
+    if (variant != 0 && variant != 1) return false;
+    const int32_t* h = reinterpret_cast<const int32_t*>(variant == 0 ? mip_train_tables : mip_train_tables_v1);
     if (h[0] != 0x54524E31) return false;
     T.n_bchunks = h[1]; T.njobs = h[2]; T.NH = h[3]; T.NG = h[4]; T.NMASK = h[5]; T.job_floats = h[6]; T.nparams = h[7];
     T.n_scratch = h[11]; T.off_extra_w = h[12]; T.off_extra_b = h[13]; T.off_view_w = h[14]; T.off_view_b = h[15];
@@ -243,6 +245,18 @@ hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* view
                                 c->grid_limit, dma, rays, c->dnoise, c->cfg.density_noise, st);
 }
 
+// ... and its training kernels (variants with has_bf16_train)
+hipError_t launch_trainfwd_variant(mipnerf_ctx* c, const void* enc, const void* viewenc, float* rgb_sigma, float* raw, void* act,
+                                   void* masks, int64_t M, int N, const mip::RayInputs* rays, hipStream_t st) {
+    auto fn = c->P->variant == 1 ? mip::launch_mlp_bf16_trainfwd_v1 : mip::launch_mlp_bf16_trainfwd;
+    return fn(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, act, masks, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
+              c->grid_limit, rays, c->dnoise, c->cfg.density_noise, st);
+}
+hipError_t launch_dgrad_variant(mipnerf_ctx* c, const float* d_raw, const void* masks, void* delta, int64_t M, hipStream_t st) {
+    auto fn = c->P->variant == 1 ? mip::launch_mlp_bf16_dgrad_v1 : mip::launch_mlp_bf16_dgrad;
+    return fn(c->d_stream_dgrad, d_raw, masks, delta, M, c->grid_limit, st);
+}
+
 // split-K factor of the sample-contracted fp32 GEMMs: 1 x 2(3) output tiles (256 x 128) x 256 splits = 512+ eight-wave workgroups (with
 // 64 splits every CU ran ONE 4-wave workgroup and nothing covered its barriers: 1.24 ms per 256 x 256 x 524288 wgrad)
 constexpr int kF32WgradSplits = 256;
@@ -260,8 +274,8 @@ mip::F32Net f32net_with_heads(const mipnerf_ctx* c) {
 
 #define NEED_BF16_TRAIN(what)                                                                                               \
     if (!c->P->has_bf16_train)                                                                                               \
-        return fail(MIPNERF_E_UNSUPPORTED, what ": the bf16 training kernels are generated for the shipped architecture only " \
-                                                "(variant 0); train this shape in fp32 precision")
+        return fail(MIPNERF_E_UNSUPPORTED, what ": the bf16 training kernels are generated for architectures with a view layer " \
+                                                "(gen_mlp_train.train_variants); train this shape in fp32 precision")
 
 struct TrainWs {                   // carve-up of the caller's workspace (all 256-byte aligned)
     char* base;
@@ -367,8 +381,8 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
         c->grid_limit = cus;
-    // ---- training tables (bf16 training kernels exist for variant 0 only) ----
-    if (P->has_bf16_train && (!train_tables(c->tt) || c->tt.nparams != off_total(c->tab))) {
+    // ---- training tables (one blob per variant with generated bf16 training kernels) ----
+    if (P->has_bf16_train && (!train_tables(c->tt, P->variant) || c->tt.nparams != off_total(c->tab))) {
         mipnerf_destroy(c);
         return fail(MIPNERF_E_INVALID, "mipnerf_create: embedded training tables are inconsistent with the compiled plan");
     }
@@ -382,7 +396,7 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         chk(hipMalloc(&c->d_otab, (size_t)tt.njobs * tt.job_floats * 4));
         chk(hipMalloc(&c->d_jobslots, (size_t)tt.njobs * sizeof(int2)));
         chk(hipMalloc(&c->d_scratch, (size_t)(tt.n_scratch > 0 ? tt.n_scratch : 1) * 4));
-        chk(hipMalloc(&c->d_extra_wT, (size_t)kNetWidth * kNetWidth * 4));
+        chk(hipMalloc(&c->d_extra_wT, (size_t)P->net_width * P->net_width * 4));
         if (er == hipSuccess) {
             chk(hipMemcpy(c->d_pack_dgrad, e_dg.data(), e_dg.size() * 4, hipMemcpyHostToDevice));
             chk(hipMemcpy(c->d_jobs, tt.jobs, (size_t)tt.njobs * sizeof(mip::WgradJob), hipMemcpyHostToDevice));
@@ -623,9 +637,7 @@ int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* 
         return fail(MIPNERF_E_INVALID, "mlp_forward_train: bad argument");
     NEED_BF16_TRAIN("mlp_forward_train");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train: mipnerf_set_params has not been called");
-    HIP_TRY(mip::launch_mlp_bf16_trainfwd(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, act, masks, M, N,
-                                          c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, nullptr, c->dnoise,
-                                          c->cfg.density_noise, S(stream)));
+    HIP_TRY(launch_trainfwd_variant(c, enc, viewenc, rgb_sigma, raw, act, masks, M, N, nullptr, S(stream)));
     return MIPNERF_OK;
 }
 
@@ -633,7 +645,7 @@ int mipnerf_mlp_dgrad(mipnerf_ctx* c, int64_t M, const float* d_raw, const void*
     if (!c || M < 1 || !d_raw || !masks || !delta) return fail(MIPNERF_E_INVALID, "mlp_dgrad: bad argument");
     NEED_BF16_TRAIN("mlp_dgrad");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_dgrad: mipnerf_set_params has not been called");
-    HIP_TRY(mip::launch_mlp_bf16_dgrad(c->d_stream_dgrad, d_raw, masks, delta, M, c->grid_limit, S(stream)));
+    HIP_TRY(launch_dgrad_variant(c, d_raw, masks, delta, M, S(stream)));
     return MIPNERF_OK;
 }
 
@@ -662,15 +674,15 @@ static int wgrad_tiles(mipnerf_ctx* c, int64_t n_wt, const void* act, const void
     if (e1) HIP_TRY(hipEventRecord(e1, S(stream)));
     if (grad_flat) {
         if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_wgrad: mipnerf_set_params has not been called");
-        using namespace mip::plan;
+        const PlanDesc& P = *c->P;
         mip::WgradPost post;
-        post.W = kNetWidth; post.Wc = kNetWidthCond; post.ldv = kNetWidth + kViewDim;
+        post.W = P.net_width; post.Wc = P.net_width_cond; post.ldv = P.net_width + P.view_dim;
         post.off_extra_w = c->tt.off_extra_w; post.off_extra_b = c->tt.off_extra_b;
         post.off_view_w = c->tt.off_view_w; post.off_view_b = c->tt.off_view_b;
         // state_dict order: ... density (2*D, 2*D+1), extra (2*D+2, +3), view (2*D+4, +5), colour
         post.extra_wT = c->d_extra_wT;
-        post.extra_w = c->pp.p[2 * kNetDepth + 2]; post.extra_b = c->pp.p[2 * kNetDepth + 3];
-        post.view_w = c->pp.p[2 * kNetDepth + 4];
+        post.extra_w = c->pp.p[2 * P.net_depth + 2]; post.extra_b = c->pp.p[2 * P.net_depth + 3];
+        post.view_w = c->pp.p[2 * P.net_depth + 4];
         HIP_TRY(mip::launch_wgrad_reduce(partials, c->d_otab, c->d_jobslots, c->tt.njobs, grad_flat, c->d_scratch,
                                          c->tt.nparams, post, accumulate != 0, S(stream)));
     }
@@ -945,9 +957,8 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
         if (c->fused_ipe && max_deg_span_is_16(cfg)) {      // encoding computed inside the forward-with-save kernel
             const mip::RayInputs ri = {lv[l].t, rays->origins, rays->directions, rays->radii, cfg.min_deg_point,
                                        cfg.disable_integration};
-            HIP_TRY(mip::launch_mlp_bf16_trainfwd(c->d_stream_bf16, c->d_bias, nullptr, viewenc, lv[l].rgb_sigma, lv[l].raw,
-                                                  lv[l].act, lv[l].masks, (int64_t)M, N, cfg.density_bias, cfg.rgb_padding,
-                                                  c->grid_limit, &ri, c->dnoise, cfg.density_noise, S(stream)));
+            HIP_TRY(launch_trainfwd_variant(c, nullptr, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act, lv[l].masks, (int64_t)M, N, &ri,
+                                            S(stream)));
         } else {
             if ((rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, lv[l].t, rays->origins,
                                        rays->directions, rays->radii, lv[l].enc, MIPNERF_PREC_BF16, stream))) return rc;
@@ -1109,7 +1120,15 @@ int mipnerf_selftest(void* stream) {
 // Host-only debug export of the plan tables (flat parameter indices), used by the CPU tests to prove the
 // C++ expansion equals mlp_plan.py.  which: 0 bf16 pack, 1 bias, 2 fp32 pack.  Returns element count.
 int64_t mipnerf_debug_table_variant(int variant, int which, int32_t* out_host, int64_t cap) {
-    if (variant < 0 || variant >= mip::plan::kNumVariants || which < 0 || which > 2) return -1;
+    if (variant < 0 || variant >= mip::plan::kNumVariants || which < 0 || which > 5) return -1;
+    if (which >= 3) {               // training tables of the variant (3 dgrad pack, 4 wgrad partial -> parameter, 5 jobs)
+        TrainTables tt;
+        if (!mip::plan::kPlans[variant].has_bf16_train || !train_tables(tt, variant)) return -1;
+        const int32_t* src = which == 3 ? tt.bpack : (which == 4 ? tt.otab : tt.jobs);
+        const int64_t n = which == 3 ? (int64_t)tt.n_bchunks * 512 : (which == 4 ? (int64_t)tt.njobs * tt.job_floats : tt.njobs * 20);
+        if (out_host && cap >= n) memcpy(out_host, src, (size_t)n * 4);
+        return n;
+    }
     Tables T;
     build_tables(T, mip::plan::kPlans[variant]);
     const std::vector<int32_t>& v = which == 0 ? T.pack_bf16 : (which == 1 ? T.bias : T.pack_f32);

@@ -356,10 +356,12 @@ SELECTORS = [
 ]
 
 
-def gen_trainfwd(tp: TrainPlan) -> str:
+def gen_trainfwd(tp: TrainPlan, variant: int = 0) -> str:
+    sfx = f"_v{variant}" if variant else ""
     plan = tp.fwd
     a = plan.arch
     nchunks = len(plan.chunks)
+    nreal = plan.n_real_chunks        # the stream is padded with zero chunks to whole ring groups (mlp_plan.RING_MULTIPLE)
     assert nchunks % GROUP == 0 and (nchunks // GROUP) % SLOTS == 0
     nenc = a.xyz_dim // 16
     enc_wave_bytes = 8192
@@ -370,15 +372,15 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     lds_bytes = enc_off + WAVES * enc_wave_bytes
     assert lds_bytes <= 160 * 1024
     prog = build_fwd_prog(tp)
-    assert len(prog.slots) == nchunks
-    side_e, prologue_e = assign_lds_b(prog, nchunks)
-    side = place_sides(prog, nchunks, "fwd")
-    for c in range(nchunks):
+    assert len(prog.slots) == nreal and nchunks - nreal < GROUP
+    side_e, prologue_e = assign_lds_b(prog, nreal)
+    side = place_sides(prog, nreal, "fwd")
+    for c in range(nreal):
         side[c] = side_e[c] + side[c]
     check_hazards(prog, side)
     lines = []
     e = lines.append
-    file_header(e, "trainfwd", dict(kRingBytes=ring_bytes, kBiasBytes=nbias_bytes, kEncOff=enc_off,
+    file_header(e, "trainfwd" + sfx, dict(kRingBytes=ring_bytes, kBiasBytes=nbias_bytes, kEncOff=enc_off,
                                     kEncWaveBytes=enc_wave_bytes, kLdsBytes=lds_bytes,
                                     kGroupBytes=GROUP * CHUNK_BYTES, kNumGroups=nchunks // GROUP,
                                     kTileSamples=WAVES * 32, kNH=tp.NH, kNMask=tp.NMASK))
@@ -460,14 +462,14 @@ def gen_trainfwd(tp: TrainPlan) -> str:
     emit_tile_body(e, prog, side, nchunks, pro, final, lda)
     e("    }")
     e("}")
-    e("}  // namespace trainfwd")
+    e("}  // namespace trainfwd" + sfx)
     e("")
-    e("int mlp_trainfwd_lds_bytes() { return trainfwd::kLdsBytes; }")
-    e("hipError_t launch_mlp_bf16_trainfwd(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,")
+    e(f"int mlp_trainfwd_lds_bytes{sfx}() {{ return trainfwd{sfx}::kLdsBytes; }}")
+    e(f"hipError_t launch_mlp_bf16_trainfwd{sfx}(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,")
     e("                                    float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,")
     e("                                    float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,")
     e("                                    const float* dnoise, float dnoise_scale, hipStream_t st) {")
-    e("    using namespace trainfwd;")
+    e(f"    using namespace trainfwd{sfx};")
     e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
     e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
     e("    if (grid < 1) grid = 1;")
@@ -545,7 +547,8 @@ def build_dgrad_prog(tp: TrainPlan):
     return prog
 
 
-def gen_dgrad(tp: TrainPlan) -> str:
+def gen_dgrad(tp: TrainPlan, variant: int = 0) -> str:
+    sfx = f"_v{variant}" if variant else ""
     nchunks = len(tp.bchunks)
     nreal = tp.n_bchunks_real
     assert nchunks % GROUP == 0 and (nchunks // GROUP) % SLOTS == 0
@@ -560,7 +563,7 @@ def gen_dgrad(tp: TrainPlan) -> str:
     check_hazards(prog, side)
     lines = []
     e = lines.append
-    file_header(e, "dgrad", dict(kRingBytes=ring_bytes, kPrivOff=priv_off, kPrivWaveBytes=priv_wave_bytes,
+    file_header(e, "dgrad" + sfx, dict(kRingBytes=ring_bytes, kPrivOff=priv_off, kPrivWaveBytes=priv_wave_bytes,
                                  kLdsBytes=lds_bytes, kGroupBytes=GROUP * CHUNK_BYTES, kNumGroups=nchunks // GROUP,
                                  kTileSamples=WAVES * 32, kNG=tp.NG, kNMask=tp.NMASK))
     e(f"__global__ void __launch_bounds__({WAVES * 64})")
@@ -616,12 +619,12 @@ def gen_dgrad(tp: TrainPlan) -> str:
     emit_tile_body(e, prog, side, nchunks, pro, final, lda)
     e("    }")
     e("}")
-    e("}  // namespace dgrad")
+    e("}  // namespace dgrad" + sfx)
     e("")
-    e("int mlp_dgrad_lds_bytes() { return dgrad::kLdsBytes; }")
-    e("hipError_t launch_mlp_bf16_dgrad(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,")
+    e(f"int mlp_dgrad_lds_bytes{sfx}() {{ return dgrad{sfx}::kLdsBytes; }}")
+    e(f"hipError_t launch_mlp_bf16_dgrad{sfx}(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,")
     e("                                 int grid_limit, hipStream_t st) {")
-    e("    using namespace dgrad;")
+    e(f"    using namespace dgrad{sfx};")
     e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
     e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
     e("    if (grid < 1) grid = 1;")
@@ -639,17 +642,31 @@ def gen_dgrad(tp: TrainPlan) -> str:
     return "\n".join(lines) + "\n"
 
 
+def train_variants():
+    """(variant index, TrainPlan) of every architecture of gen_mlp_bf16.VARIANTS the training plan covers (variant 0 = shipped;
+    `use_viewdirs=False` has no view layer / bottleneck algebra in mlp_train_plan.py: it trains in fp32 mode)."""
+    from gen_mlp_bf16 import VARIANTS
+    out = []
+    for vi, arch in enumerate(VARIANTS):
+        try:
+            out.append((vi, TrainPlan.build(arch)))
+        except NotImplementedError:
+            pass
+    return out
+
+
 def main():
     outdir = sys.argv[1] if len(sys.argv) > 1 else HERE
-    tp = TrainPlan.build()
-    with open(os.path.join(outdir, "mlp_bf16_trainfwd_gen.hip"), "w") as f:
-        f.write(gen_trainfwd(tp))
-    with open(os.path.join(outdir, "mlp_bf16_dgrad_gen.hip"), "w") as f:
-        f.write(gen_dgrad(tp))
-    with open(os.path.join(outdir, "_gen_train_tables.bin"), "wb") as f:
-        f.write(tp.blob())
-    print(f"generated training kernels: fwd {len(tp.fwd.chunks)} chunks, dgrad {tp.n_bchunks_real} (+{len(tp.bchunks) - tp.n_bchunks_real} pad) "
-          f"chunks, {len(tp.jobs)} wgrad jobs -> {outdir}")
+    for vi, tp in train_variants():
+        sfx = f"_v{vi}" if vi else ""
+        with open(os.path.join(outdir, f"mlp_bf16_trainfwd_gen{sfx}.hip"), "w") as f:
+            f.write(gen_trainfwd(tp, vi))
+        with open(os.path.join(outdir, f"mlp_bf16_dgrad_gen{sfx}.hip"), "w") as f:
+            f.write(gen_dgrad(tp, vi))
+        with open(os.path.join(outdir, f"_gen_train_tables{sfx}.bin"), "wb") as f:
+            f.write(tp.blob())
+        print(f"generated training kernels (variant {vi}): fwd {tp.fwd.n_real_chunks} chunks, dgrad {tp.n_bchunks_real} "
+              f"(+{len(tp.bchunks) - tp.n_bchunks_real} pad) chunks, {len(tp.jobs)} wgrad jobs -> {outdir}")
 
 
 if __name__ == "__main__":

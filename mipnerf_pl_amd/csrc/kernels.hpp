@@ -99,6 +99,13 @@ hipError_t launch_mlp_bf16_trainfwd(const void* stream_w, const float* bias_tab,
 int mlp_dgrad_lds_bytes();
 hipError_t launch_mlp_bf16_dgrad(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,
                                  int grid_limit, hipStream_t st);
+// the same two kernels generated for architecture variant 1 (gen_mlp_train.train_variants): *_gen_v1.hip
+hipError_t launch_mlp_bf16_trainfwd_v1(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,
+                                       float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,
+                                       float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,
+                                       const float* dnoise, float dnoise_scale, hipStream_t st);
+hipError_t launch_mlp_bf16_dgrad_v1(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,
+                                    int grid_limit, hipStream_t st);
 
 // ---- kernels_wgrad.hip -----------------------------------------------------------------------
 constexpr int kWgradJobFloats = 8 * 9 * 64 * 16;     // fp32 partials per (job, split): [wave][slot][lane][reg]

@@ -119,6 +119,8 @@ class TrainPlan:
         a = fwd.arch
         if a.net_depth_condition != 1:
             raise NotImplementedError("training kernels are generated for net_depth_condition == 1")
+        if not a.use_viewdirs:
+            raise NotImplementedError("training kernels are generated for use_viewdirs=True (bottleneck + view layer)")
         if a.xyz_dim % TILE:
             raise NotImplementedError("training kernels need xyz_dim to be a multiple of 32")
         tp = TrainPlan(fwd)

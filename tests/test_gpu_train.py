@@ -171,9 +171,9 @@ def test_render_image_chunked_equals_unchunked(G):
 
 
 # ---- native bf16 MLP training kernels (forward-with-save, dgrad, wgrad) ---------------------------------------
-def _mlp_case(B, N, seed):
+def _mlp_case(B, N, seed, **arch):
     rng = np.random.default_rng(seed)
-    params = orc.make_params(seed=seed, density_gain=40.0)
+    params = orc.make_params(seed=seed, density_gain=40.0, **arch)
     enc = (rng.uniform(-1, 1, (B, N, 96)) * rng.uniform(0, 1, (1, 1, 96)) ** 2).astype(np.float32)
     vdir = rng.normal(0, 1, (B, 3)).astype(np.float32)
     vdir /= np.linalg.norm(vdir, axis=-1, keepdims=True)
@@ -182,10 +182,10 @@ def _mlp_case(B, N, seed):
     return params, enc, venc, d_raw
 
 
-def _run_native_mlp(G, params, enc, venc, d_raw):
+def _run_native_mlp(G, params, enc, venc, d_raw, **model_kw):
     from mipnerf_pl_amd.autograd import mlp_native
     B, N = enc.shape[:2]
-    model = G.make_model(params, N, "bf16")
+    model = G.make_model(params, N, "bf16", **model_kw)
     v32 = np.zeros((B, 32), np.float32)
     v32[:, :27] = venc
     e = torch.from_numpy(enc).to(DEV).to(torch.bfloat16)
@@ -224,6 +224,36 @@ def test_native_mlp_backward_equals_bf16_emulation(G, B, N):
     # bf16 operands (8-bit mantissa) for activations AND deltas through up to 10 chained layers: measured 0.11-0.13
     # relative L2 on layers.0.weight (the deepest gradient), < 0.05 on the heads
     assert worst_or <= 0.2, worst_or       # measured 0.11-0.16 (white-noise upstream gradients: pure cancellation, the adversarial case)
+    assert e_raw <= 2e-2 * max(1.0, float(np.abs(raw_em).max()))
+
+
+
+@pytest.mark.parametrize("B,N", [(8, 32), (3, 100)])
+def test_native_mlp_backward_variant_w128(G, B, N):
+    """The training kernels generated for the 128-wide variant (gen_mlp_train.train_variants) against the numpy emulation
+    of the same dataflow with bf16 operand rounding and against the fp32 oracle gradients of that architecture."""
+    from mipnerf_pl_amd.mlp_plan import Arch
+    from mipnerf_pl_amd.mlp_train_plan import TrainPlan, emulate_train
+    arch = dict(net_width=128, net_width_condition=128)
+    params, enc, venc, d_raw = _mlp_case(B, N, seed=B * 100 + N + 7, **arch)
+    raw, grads, enc_bf, v_bf = _run_native_mlp(G, params, enc, venc, d_raw, mlp_net_width=128, mlp_net_width_condition=128)
+    tp = TrainPlan.build(Arch(**arch))
+    flatp = np.concatenate([v.ravel() for v in params.values()])
+    S = B * N
+    flat, seen, raw_em = emulate_train(tp, flatp, enc_bf.reshape(S, 96), np.repeat(v_bf, N, axis=0), d_raw.reshape(S, 4),
+                                       round_bf16=True)
+    e_raw = G.maxdiff(raw.reshape(S, 4), raw_em)
+    og = orc.mlp_backward(params, enc, venc, d_raw[..., :3], d_raw[..., 3:])
+    off, worst_em, worst_or = 0, 0.0, 0.0
+    for k, v in og.items():
+        g = grads[k].ravel().astype(np.float64)
+        em = flat[off:off + v.size].astype(np.float64)
+        off += v.size
+        worst_em = max(worst_em, np.linalg.norm(g - em) / max(np.linalg.norm(em), 1e-30))
+        worst_or = max(worst_or, np.linalg.norm(g - v.ravel()) / max(np.linalg.norm(v.ravel()), 1e-30))
+    G.record(f"native_mlp_bwd_w128 B={B} N={N}", raw_vs_emul=e_raw, grad_rel_l2_vs_emul=worst_em, grad_rel_l2_vs_fp32=worst_or)
+    assert worst_em <= 1e-2, worst_em
+    assert worst_or <= 0.2, worst_or
     assert e_raw <= 2e-2 * max(1.0, float(np.abs(raw_em).max()))
 
 
