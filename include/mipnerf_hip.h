@@ -124,8 +124,8 @@ int mipnerf_destroy(mipnerf_ctx* ctx);
 /* Writes the MLP shape the library was compiled for into *cfg (other fields defaulted). */
 int mipnerf_compiled_arch(mipnerf_config* cfg);
 /* The library carries tables (+ a bf16 inference kernel) for a fixed list of MLP shapes ("variants", csrc/gen_mlp_bf16.py
- * VARIANTS); variant 0 is the shipped shape; bf16 TRAINING kernels are generated for every variant with a view layer
- * (*has_bf16_training), the others train in fp32.
+ * VARIANTS); variant 0 is the shipped shape; bf16 TRAINING kernels + tables are generated per variant as well
+ * (*has_bf16_training; a variant without them would train in fp32).
  * mipnerf_create picks the variant that matches cfg or fails with MIPNERF_E_UNSUPPORTED listing them. */
 int mipnerf_num_variants(void);
 int mipnerf_variant_arch(int variant, mipnerf_config* cfg, int* has_bf16_training);

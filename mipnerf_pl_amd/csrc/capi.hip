@@ -14,7 +14,8 @@
 
 // binary tables of the training kernels (mlp_train_plan.TrainPlan.blob()), linked in through train_tables.c (.incbin)
 extern "C" const unsigned char mip_train_tables[];       // variant 0
-extern "C" const unsigned char mip_train_tables_v1[];    // variant 1 (build.py TRAIN_TABLE_VARIANTS)
+extern "C" const unsigned char mip_train_tables_v1[];    // variants 1, 2 (build.py TRAIN_TABLE_VARIANTS)
+extern "C" const unsigned char mip_train_tables_v2[];
 
 namespace {
 
@@ -188,8 +189,9 @@ struct TrainTables {
 };
 
 bool train_tables(TrainTables& T, int variant = 0) {
-    if (variant != 0 && variant != 1) return false;
-    const int32_t* h = reinterpret_cast<const int32_t*>(variant == 0 ? mip_train_tables : mip_train_tables_v1);
+    if (variant < 0 || variant > 2) return false;
+    const unsigned char* blobs[3] = {mip_train_tables, mip_train_tables_v1, mip_train_tables_v2};
+    const int32_t* h = reinterpret_cast<const int32_t*>(blobs[variant]);
     if (h[0] != 0x54524E31) return false;
     T.n_bchunks = h[1]; T.njobs = h[2]; T.NH = h[3]; T.NG = h[4]; T.NMASK = h[5]; T.job_floats = h[6]; T.nparams = h[7];
     T.n_scratch = h[11]; T.off_extra_w = h[12]; T.off_extra_b = h[13]; T.off_view_w = h[14]; T.off_view_b = h[15];
@@ -248,12 +250,13 @@ hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* view
 // ... and its training kernels (variants with has_bf16_train)
 hipError_t launch_trainfwd_variant(mipnerf_ctx* c, const void* enc, const void* viewenc, float* rgb_sigma, float* raw, void* act,
                                    void* masks, int64_t M, int N, const mip::RayInputs* rays, hipStream_t st) {
-    auto fn = c->P->variant == 1 ? mip::launch_mlp_bf16_trainfwd_v1 : mip::launch_mlp_bf16_trainfwd;
+    auto fn = c->P->variant == 1 ? mip::launch_mlp_bf16_trainfwd_v1
+                                 : (c->P->variant == 2 ? mip::launch_mlp_bf16_trainfwd_v2 : mip::launch_mlp_bf16_trainfwd);
     return fn(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, act, masks, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
               c->grid_limit, rays, c->dnoise, c->cfg.density_noise, st);
 }
 hipError_t launch_dgrad_variant(mipnerf_ctx* c, const float* d_raw, const void* masks, void* delta, int64_t M, hipStream_t st) {
-    auto fn = c->P->variant == 1 ? mip::launch_mlp_bf16_dgrad_v1 : mip::launch_mlp_bf16_dgrad;
+    auto fn = c->P->variant == 1 ? mip::launch_mlp_bf16_dgrad_v1 : (c->P->variant == 2 ? mip::launch_mlp_bf16_dgrad_v2 : mip::launch_mlp_bf16_dgrad);
     return fn(c->d_stream_dgrad, d_raw, masks, delta, M, c->grid_limit, st);
 }
 
@@ -274,7 +277,7 @@ mip::F32Net f32net_with_heads(const mipnerf_ctx* c) {
 
 #define NEED_BF16_TRAIN(what)                                                                                               \
     if (!c->P->has_bf16_train)                                                                                               \
-        return fail(MIPNERF_E_UNSUPPORTED, what ": the bf16 training kernels are generated for architectures with a view layer " \
+        return fail(MIPNERF_E_UNSUPPORTED, what ": no bf16 training kernels were generated for this architecture variant " \
                                                 "(gen_mlp_train.train_variants); train this shape in fp32 precision")
 
 struct TrainWs {                   // carve-up of the caller's workspace (all 256-byte aligned)
@@ -675,14 +678,22 @@ static int wgrad_tiles(mipnerf_ctx* c, int64_t n_wt, const void* act, const void
     if (grad_flat) {
         if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_wgrad: mipnerf_set_params has not been called");
         const PlanDesc& P = *c->P;
-        mip::WgradPost post;
-        post.W = P.net_width; post.Wc = P.net_width_cond; post.ldv = P.net_width + P.view_dim;
-        post.off_extra_w = c->tt.off_extra_w; post.off_extra_b = c->tt.off_extra_b;
-        post.off_view_w = c->tt.off_view_w; post.off_view_b = c->tt.off_view_b;
-        // state_dict order: ... density (2*D, 2*D+1), extra (2*D+2, +3), view (2*D+4, +5), colour
-        post.extra_wT = c->d_extra_wT;
-        post.extra_w = c->pp.p[2 * P.net_depth + 2]; post.extra_b = c->pp.p[2 * P.net_depth + 3];
-        post.view_w = c->pp.p[2 * P.net_depth + 4];
+        mip::WgradPost post = {};
+        if (P.use_viewdirs) {
+            post.W = P.net_width; post.Wc = P.net_width_cond; post.ldv = P.net_width + P.view_dim;
+            post.off_extra_w = c->tt.off_extra_w; post.off_extra_b = c->tt.off_extra_b;
+            post.off_view_w = c->tt.off_view_w; post.off_view_b = c->tt.off_view_b;
+            // state_dict order: ... density (2*D, 2*D+1), extra (2*D+2, +3), view (2*D+4, +5), colour
+            post.extra_wT = c->d_extra_wT;
+            post.extra_w = c->pp.p[2 * P.net_depth + 2]; post.extra_b = c->pp.p[2 * P.net_depth + 3];
+            post.view_w = c->pp.p[2 * P.net_depth + 4];
+        } else if (!accumulate) {
+            // MLP.forward(x, None): extra_layer / view_layers are unused parameters (autograd leaves their .grad None) and no
+            // partial feeds them: zero unless accumulating
+            const int D = P.net_depth;
+            for (int t = 2 * D + 2; t < 2 * D + 6; ++t)
+                HIP_TRY(hipMemsetAsync(grad_flat + c->tab.tensor_off[t], 0, (size_t)P.param_numel[t] * 4, S(stream)));
+        }
         HIP_TRY(mip::launch_wgrad_reduce(partials, c->d_otab, c->d_jobslots, c->tt.njobs, grad_flat, c->d_scratch,
                                          c->tt.nparams, post, accumulate != 0, S(stream)));
     }

@@ -99,13 +99,17 @@ hipError_t launch_mlp_bf16_trainfwd(const void* stream_w, const float* bias_tab,
 int mlp_dgrad_lds_bytes();
 hipError_t launch_mlp_bf16_dgrad(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,
                                  int grid_limit, hipStream_t st);
-// the same two kernels generated for architecture variant 1 (gen_mlp_train.train_variants): *_gen_v1.hip
-hipError_t launch_mlp_bf16_trainfwd_v1(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,
-                                       float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,
-                                       float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,
-                                       const float* dnoise, float dnoise_scale, hipStream_t st);
-hipError_t launch_mlp_bf16_dgrad_v1(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,
-                                    int grid_limit, hipStream_t st);
+// the same two kernels generated for the other architecture variants (gen_mlp_train.train_variants): *_gen_v<i>.hip
+#define MIP_DECL_TRAIN_VARIANT(sfx)                                                                                             \
+    hipError_t launch_mlp_bf16_trainfwd##sfx(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,    \
+                                             float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples, \
+                                             float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,        \
+                                             const float* dnoise, float dnoise_scale, hipStream_t st);                            \
+    hipError_t launch_mlp_bf16_dgrad##sfx(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,       \
+                                          int grid_limit, hipStream_t st)
+MIP_DECL_TRAIN_VARIANT(_v1);
+MIP_DECL_TRAIN_VARIANT(_v2);
+#undef MIP_DECL_TRAIN_VARIANT
 
 // ---- kernels_wgrad.hip -----------------------------------------------------------------------
 constexpr int kWgradJobFloats = 8 * 9 * 64 * 16;     // fp32 partials per (job, split): [wave][slot][lane][reg]
@@ -118,7 +122,7 @@ int mlp_wgrad_lds_bytes();
 hipError_t launch_transpose_sq(int n, const float* in, float* out, hipStream_t st);
 hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs, const void* wg_tab, int num_wgs,
                             int64_t n_wt, int NH, int NG, float* partials, hipStream_t st);
-struct WgradPost {                                    // chain-rule step that replaces the bottleneck T-blocks
+struct WgradPost {                                    // chain-rule step that replaces the bottleneck T-blocks (W == 0: none)
     int W, Wc, ldv;                                   // net_width, net_width_condition, in_features of the view layer
     int off_extra_w, off_extra_b, off_view_w, off_view_b;   // flat gradient offsets
     const float* extra_wT;                            // W_extra^T, fp32 copy made by mipnerf_set_params

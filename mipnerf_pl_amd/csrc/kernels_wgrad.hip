@@ -236,6 +236,7 @@ hipError_t launch_wgrad_reduce(const float* partials, const int32_t* otab, const
                                hipStream_t st) {
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((kWgradJobFloats + 63) / 64, njobs), dim3(256), 0, st, partials, otab,
                        (const int2*)job_slots, grad_flat, scratch, nparams, accumulate ? 1 : 0);
+    if (post.W == 0) return hipGetLastError();        // architecture without a bottleneck (use_viewdirs=False): nothing to post-process
     const int n = post.W * post.W + post.Wc * post.W + post.W + post.Wc;
     hipLaunchKernelGGL(k_wgrad_post, dim3((n + 255) / 256), dim3(256), 0, st, post, scratch, grad_flat, accumulate ? 1 : 0);
     return hipGetLastError();

@@ -119,8 +119,6 @@ class TrainPlan:
         a = fwd.arch
         if a.net_depth_condition != 1:
             raise NotImplementedError("training kernels are generated for net_depth_condition == 1")
-        if not a.use_viewdirs:
-            raise NotImplementedError("training kernels are generated for use_viewdirs=True (bottleneck + view layer)")
         if a.xyz_dim % TILE:
             raise NotImplementedError("training kernels need xyz_dim to be a multiple of 32")
         tp = TrainPlan(fwd)
@@ -138,8 +136,10 @@ class TrainPlan:
         hadd("enc", nE, NATURAL)
         for i in range(1, D + 1):
             hadd(f"x{i}", nW, DLAYOUT)
-        hadd("view", 1, NATURAL)
-        hadd("hv", nC, DLAYOUT)
+        views = bool(a.use_viewdirs)       # False: MLP.forward(x, None) -- colour head on the trunk output, no bottleneck / view layer
+        if views:
+            hadd("view", 1, NATURAL)
+            hadd("hv", nC, DLAYOUT)
         tp.NH = hid
         gid = 0
 
@@ -148,11 +148,12 @@ class TrainPlan:
             tp.g_blocks[name] = (gid, n, kind)
             gid += n
         gadd("raw", 1, NATURAL)
-        gadd("gv", nC, DLAYOUT)
+        if views:
+            gadd("gv", nC, DLAYOUT)
         for i in range(D, 0, -1):
             gadd(f"g{i}", nW, DLAYOUT)
         tp.NG = gid
-        tp.NMASK = D + 1
+        tp.NMASK = D + (1 if views else 0)
         # ---- what the forward-with-save kernel stores per op ---------------------------------------------
         for op in fwd.ops:
             if op.name.startswith("layer"):
@@ -167,13 +168,20 @@ class TrainPlan:
         # ---- dgrad ops -------------------------------------------------------------------------------------
         G = {k: v[0] for k, v in tp.g_blocks.items()}
         nrgb = a.num_rgb
-        tp.bops.append(BOp("dcolor", [BSeg("raw", NATURAL, 1, pid["color_layer.weight"], Wc, 0, 0, nrgb)],
-                           nC, 0, D, "Y", G["gv"]))
-        tp.bops.append(BOp("dview", [BSeg("Y", DLAYOUT, Wc // KSTEP, pid["view_layers.0.0.weight"],
-                                          W + a.view_dim, 0, 0, Wc)], nW, 0, None, "X", None))
-        tp.bops.append(BOp("dhead", [BSeg("X", DLAYOUT, W // KSTEP, pid["extra_layer.weight"], W, 0, 0, W),
-                                     BSeg("raw", NATURAL, 1, pid["density_layer.weight"], W, -nrgb, nrgb, nrgb + 1)],
-                           nW, 0, D - 1, "Y", G[f"g{D}"]))
+        if views:
+            tp.bops.append(BOp("dcolor", [BSeg("raw", NATURAL, 1, pid["color_layer.weight"], Wc, 0, 0, nrgb)],
+                               nC, 0, D, "Y", G["gv"]))
+            tp.bops.append(BOp("dview", [BSeg("Y", DLAYOUT, Wc // KSTEP, pid["view_layers.0.0.weight"],
+                                              W + a.view_dim, 0, 0, Wc)], nW, 0, None, "X", None))
+            tp.bops.append(BOp("dhead", [BSeg("X", DLAYOUT, W // KSTEP, pid["extra_layer.weight"], W, 0, 0, W),
+                                         BSeg("raw", NATURAL, 1, pid["density_layer.weight"], W, -nrgb, nrgb, nrgb + 1)],
+                               nW, 0, D - 1, "Y", G[f"g{D}"]))
+        else:
+            # both heads read the trunk output: delta_D = (d_rgb W_color + d_density W_density) * relu'(x_D); two k-steps on the
+            # same d_raw register, one per weight tensor
+            tp.bops.append(BOp("dhead", [BSeg("raw", NATURAL, 1, pid["color_layer.weight"], Wc, 0, 0, nrgb),
+                                         BSeg("raw", NATURAL, 1, pid["density_layer.weight"], W, -nrgb, nrgb, nrgb + 1)],
+                               nW, 0, D - 1, "Y", G[f"g{D}"]))
         cur, other = "Y", "X"
         shapes = dict(a.param_shapes())
         for i in range(D - 1, 0, -1):
@@ -226,26 +234,37 @@ class TrainPlan:
             if ld > ncols:      # skip layer: the appended encoding columns
                 tp.jobs.append(WJob(f"L{i}e", blocks(tp.g_blocks, f"g{i + 1}"), blocks(H, "enc"),
                                     rows_d(pid[wname], ld, nW), cols("enc", W, E), None, cost=(nW + nE) / 16))
-        # scratch region behind the parameters: M = sum_s delta_view x8^T [Wc, W], then db_view of THIS call [Wc]
         _, nparams = fwd.param_offsets()
-        tp.scratch_M, tp.scratch_dbv = nparams, nparams + Wc * W
-        tp.n_scratch = Wc * W + Wc
-        tp.post = dict(W=W, Wc=Wc, ldv=W + a.view_dim, extra_w=pid["extra_layer.weight"], extra_b=pid["extra_layer.bias"],
-                       view_w=pid["view_layers.0.0.weight"], view_b=pid["view_layers.0.0.bias"])
-        SCR = -1      # pseudo tensor id: row * ld + col is an offset into the scratch region
-        m_rows = [[(SCR, TILE * ai + colfeat(DLAYOUT, m), W) for m in range(32)] for ai in range(nC)]
-        m_bias = [[(SCR, Wc * W + TILE * ai + colfeat(DLAYOUT, m)) for m in range(32)] for ai in range(nC)]
-        raw_rows_density = [[(pid["density_layer.weight"], 0, W) if m == nrgb else None for m in range(32)]]
         raw_bias = [[(pid["color_layer.bias"], m) if m < nrgb else
                      ((pid["density_layer.bias"], 0) if m == nrgb else None) for m in range(32)]]
-        tp.jobs.append(WJob("M", blocks(tp.g_blocks, "gv") + blocks(tp.g_blocks, "raw"), blocks(H, f"x{D}"),
-                            m_rows + raw_rows_density, cols(f"x{D}", 0, W), m_bias + raw_bias, cost=(nC + 1 + nW) / 16))
-        vw = pid["view_layers.0.0.weight"]
-        tp.jobs.append(WJob("viewd", blocks(tp.g_blocks, "gv"), blocks(H, "view"), rows_d(vw, W + a.view_dim, nC),
-                            cols("view", W, a.view_dim), None, cost=(nC + 1) / 16))
-        raw_rows_color = [[(pid["color_layer.weight"], m, Wc) if m < nrgb else None for m in range(32)]]
-        tp.jobs.append(WJob("color", blocks(tp.g_blocks, "raw"), blocks(H, "hv"), raw_rows_color,
-                            cols("hv", 0, Wc), None, cost=(1 + nC) / 16))
+        if views:
+            # scratch region behind the parameters: M = sum_s delta_view x8^T [Wc, W], then db_view of THIS call [Wc]
+            tp.scratch_M, tp.scratch_dbv = nparams, nparams + Wc * W
+            tp.n_scratch = Wc * W + Wc
+            tp.post = dict(W=W, Wc=Wc, ldv=W + a.view_dim, extra_w=pid["extra_layer.weight"], extra_b=pid["extra_layer.bias"],
+                           view_w=pid["view_layers.0.0.weight"], view_b=pid["view_layers.0.0.bias"])
+            SCR = -1      # pseudo tensor id: row * ld + col is an offset into the scratch region
+            m_rows = [[(SCR, TILE * ai + colfeat(DLAYOUT, m), W) for m in range(32)] for ai in range(nC)]
+            m_bias = [[(SCR, Wc * W + TILE * ai + colfeat(DLAYOUT, m)) for m in range(32)] for ai in range(nC)]
+            raw_rows_density = [[(pid["density_layer.weight"], 0, W) if m == nrgb else None for m in range(32)]]
+            tp.jobs.append(WJob("M", blocks(tp.g_blocks, "gv") + blocks(tp.g_blocks, "raw"), blocks(H, f"x{D}"),
+                                m_rows + raw_rows_density, cols(f"x{D}", 0, W), m_bias + raw_bias, cost=(nC + 1 + nW) / 16))
+            vw = pid["view_layers.0.0.weight"]
+            tp.jobs.append(WJob("viewd", blocks(tp.g_blocks, "gv"), blocks(H, "view"), rows_d(vw, W + a.view_dim, nC),
+                                cols("view", W, a.view_dim), None, cost=(nC + 1) / 16))
+            raw_rows_color = [[(pid["color_layer.weight"], m, Wc) if m < nrgb else None for m in range(32)]]
+            tp.jobs.append(WJob("color", blocks(tp.g_blocks, "raw"), blocks(H, "hv"), raw_rows_color,
+                                cols("hv", 0, Wc), None, cost=(1 + nC) / 16))
+        else:
+            # no bottleneck: nothing to post-process, no scratch; extra_layer / view_layers get no gradient (autograd leaves
+            # them None; the C entry points zero them unless accumulating)
+            tp.scratch_M = tp.scratch_dbv = nparams
+            tp.n_scratch = 0
+            tp.post = None
+            head_rows = [[(pid["color_layer.weight"], m, Wc) if m < nrgb else
+                          ((pid["density_layer.weight"], 0, W) if m == nrgb else None) for m in range(32)]]
+            tp.jobs.append(WJob("heads", blocks(tp.g_blocks, "raw"), blocks(H, f"x{D}"), head_rows, cols(f"x{D}", 0, W),
+                                raw_bias, cost=(1 + nW) / 16))
         for j in tp.jobs:
             assert len(j.a_blocks) <= MAX_JOB_BLOCKS and len(j.b_blocks) <= MAX_JOB_BLOCKS
         return tp
@@ -339,7 +358,8 @@ class TrainPlan:
         hdr[11] = self.n_scratch
         offs, _ = self.fwd.param_offsets()
         po = self.post
-        hdr[12:16] = (offs[po["extra_w"]], offs[po["extra_b"]], offs[po["view_w"]], offs[po["view_b"]])
+        if po is not None:
+            hdr[12:16] = (offs[po["extra_w"]], offs[po["extra_b"]], offs[po["view_w"]], offs[po["view_b"]])
         return hdr.tobytes() + bp.astype(np.int32).tobytes() + jt.astype(np.int32).tobytes() + ot.astype(np.int32).tobytes()
 
 
@@ -424,7 +444,8 @@ def emulate_train_tile(tp: TrainPlan, flat_params, enc, view, d_raw, valid, roun
     e0 = tp.h_blocks["enc"][0]
     for b in range(plan.arch.xyz_dim // 32):
         HT[e0 + b] = tblock(regs["enc"][2 * b], regs["enc"][2 * b + 1])
-    HT[tp.h_blocks["view"][0]] = tblock(regs["view"][0], regs["view"][1])
+    if "view" in tp.h_blocks:
+        HT[tp.h_blocks["view"][0]] = tblock(regs["view"][0], regs["view"][1])
     ci = 0
     raw = np.zeros((32, 4), np.float32)
     for oi, op in enumerate(plan.ops):
@@ -527,6 +548,8 @@ def post_process(tp: TrainPlan, flat_params, flat):
     scratch region of `flat` (M, db_view of this call), returns the parameter gradients [nparams]."""
     offs, nparams = tp.fwd.param_offsets()
     po = tp.post
+    if po is None:            # no bottleneck (use_viewdirs=False): the partials are the gradients
+        return flat[:nparams].copy()
     W, Wc, ldv = po["W"], po["Wc"], po["ldv"]
     fp = flat_params.astype(np.float32)
     We = fp[offs[po["extra_w"]]:offs[po["extra_w"]] + W * W].reshape(W, W)

@@ -286,32 +286,42 @@ def mlp_backward(params, x, view_direction, d_raw_rgb, d_raw_density, skip_index
         if i % skip_index == 0 and i > 0:
             h = np.concatenate([h, inputs], axis=-1)
     trunk = h
-    bottleneck = trunk @ params["extra_layer.weight"].T + params["extra_layer.bias"]
-    vd = np.repeat(view_direction.astype(F32), N, axis=0)
-    hv = np.concatenate([bottleneck, vd], axis=-1)
-    vacts = []
-    for i in range(net_depth_condition):
-        vacts.append(hv)
-        hv = np.maximum(hv @ params[f"view_layers.{i}.0.weight"].T + params[f"view_layers.{i}.0.bias"], F32(0))
-    # backward
     g = collections.OrderedDict((k, None) for k in params)
     d_rgb = d_raw_rgb.reshape(B * N, -1).astype(F32)
     d_den = d_raw_density.reshape(B * N, -1).astype(F32)
-    g["color_layer.weight"] = d_rgb.T @ hv
-    g["color_layer.bias"] = d_rgb.sum(0)
-    d = d_rgb @ params["color_layer.weight"]
-    for i in reversed(range(net_depth_condition)):
-        d = d * (hv > 0)                                   # ReLU of view layer i (hv is its output)
-        g[f"view_layers.{i}.0.weight"] = d.T @ vacts[i]
-        g[f"view_layers.{i}.0.bias"] = d.sum(0)
-        d = d @ params[f"view_layers.{i}.0.weight"]
-        hv = vacts[i]
-    d_bott = d[:, :bottleneck.shape[1]]                    # the view features get no gradient
-    g["extra_layer.weight"] = d_bott.T @ trunk
-    g["extra_layer.bias"] = d_bott.sum(0)
     g["density_layer.weight"] = d_den.T @ trunk
     g["density_layer.bias"] = d_den.sum(0)
-    d = d_bott @ params["extra_layer.weight"] + d_den @ params["density_layer.weight"]
+    if view_direction is None:
+        # MLP.forward(x, None) (mip_nerf.py:99-110): the colour head reads the trunk output; extra_layer / view_layers are
+        # unused (autograd leaves their .grad None: zeros here)
+        g["color_layer.weight"] = d_rgb.T @ trunk
+        g["color_layer.bias"] = d_rgb.sum(0)
+        for k in params:
+            if k.startswith(("extra_layer", "view_layers")):
+                g[k] = np.zeros_like(params[k])
+        d_bott_term = d_rgb @ params["color_layer.weight"]
+    else:
+        bottleneck = trunk @ params["extra_layer.weight"].T + params["extra_layer.bias"]
+        vd = np.repeat(view_direction.astype(F32), N, axis=0)
+        hv = np.concatenate([bottleneck, vd], axis=-1)
+        vacts = []
+        for i in range(net_depth_condition):
+            vacts.append(hv)
+            hv = np.maximum(hv @ params[f"view_layers.{i}.0.weight"].T + params[f"view_layers.{i}.0.bias"], F32(0))
+        g["color_layer.weight"] = d_rgb.T @ hv
+        g["color_layer.bias"] = d_rgb.sum(0)
+        d = d_rgb @ params["color_layer.weight"]
+        for i in reversed(range(net_depth_condition)):
+            d = d * (hv > 0)                                   # ReLU of view layer i (hv is its output)
+            g[f"view_layers.{i}.0.weight"] = d.T @ vacts[i]
+            g[f"view_layers.{i}.0.bias"] = d.sum(0)
+            d = d @ params[f"view_layers.{i}.0.weight"]
+            hv = vacts[i]
+        d_bott = d[:, :bottleneck.shape[1]]                    # the view features get no gradient
+        g["extra_layer.weight"] = d_bott.T @ trunk
+        g["extra_layer.bias"] = d_bott.sum(0)
+        d_bott_term = d_bott @ params["extra_layer.weight"]
+    d = d_bott_term + d_den @ params["density_layer.weight"]
     out = trunk
     width = params["layers.0.0.weight"].shape[0]
     for i in reversed(range(net_depth)):

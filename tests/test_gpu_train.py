@@ -192,7 +192,7 @@ def _run_native_mlp(G, params, enc, venc, d_raw, **model_kw):
     v = torch.from_numpy(v32).to(DEV).to(torch.bfloat16)
     raw = mlp_native(model.mlp, e, v)
     (raw * torch.from_numpy(d_raw).to(DEV)).sum().backward()
-    grads = {k: p.grad.detach().cpu().numpy() for k, p in model.mlp.named_parameters()}
+    grads = {k: (p.grad.detach().cpu().numpy() if p.grad is not None else None) for k, p in model.mlp.named_parameters()}
     return raw.detach().cpu().numpy(), grads, e.float().cpu().numpy(), v.float().cpu().numpy()
 
 
@@ -603,3 +603,33 @@ def test_graphed_train_step_equals_eager(G):
         assert abs(a - b) <= 1e-6 * max(1.0, abs(b))
     G.record("graphed_train_step", hooks_vs_graph_params=G.maxdiff(res["graph"][1], res["hooks"][1]))
     assert G.maxdiff(res["graph"][1], res["hooks"][1]) <= 1e-6
+
+
+def test_native_mlp_backward_variant_noview(G):
+    """The training kernels generated for use_viewdirs=False (MLP.forward(x, None), mip_nerf.py:99-110): native gradients vs the
+    numpy emulation of the same dataflow (bf16 operands) and vs the fp32 oracle; extra_layer / view_layers get exact zeros."""
+    from mipnerf_pl_amd.mlp_plan import Arch
+    from mipnerf_pl_amd.mlp_train_plan import TrainPlan, emulate_train
+    B, N = 5, 40
+    params, enc, venc, d_raw = _mlp_case(B, N, seed=91, net_width_condition=256)
+    raw, grads, enc_bf, v_bf = _run_native_mlp(G, params, enc, venc, d_raw, mlp_net_width_condition=256, use_viewdirs=False)
+    tp = TrainPlan.build(Arch(net_width_condition=256, use_viewdirs=False))
+    flatp = np.concatenate([v.ravel() for v in params.values()])
+    S = B * N
+    flat, seen, raw_em = emulate_train(tp, flatp, enc_bf.reshape(S, 96), np.zeros((S, 32), np.float32), d_raw.reshape(S, 4),
+                                       round_bf16=True)
+    e_raw = G.maxdiff(raw.reshape(S, 4), raw_em)
+    og = orc.mlp_backward(params, enc, None, d_raw[..., :3], d_raw[..., 3:])
+    off, worst_em, worst_or = 0, 0.0, 0.0
+    for k, v in og.items():
+        g = (grads[k] if grads[k] is not None else np.zeros_like(v)).ravel().astype(np.float64)
+        em = flat[off:off + v.size].astype(np.float64)
+        off += v.size
+        if not np.any(v):
+            assert not np.any(g), k
+            continue
+        worst_em = max(worst_em, np.linalg.norm(g - em) / max(np.linalg.norm(em), 1e-30))
+        worst_or = max(worst_or, np.linalg.norm(g - v.ravel()) / max(np.linalg.norm(v.ravel()), 1e-30))
+    G.record("native_mlp_bwd_noview", raw_vs_emul=e_raw, grad_rel_l2_vs_emul=worst_em, grad_rel_l2_vs_fp32=worst_or)
+    assert worst_em <= 1e-2 and worst_or <= 0.2, (worst_em, worst_or)
+    assert e_raw <= 2e-2 * max(1.0, float(np.abs(raw_em).max()))
