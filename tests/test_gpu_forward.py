@@ -306,3 +306,31 @@ def test_constructor_scalars_forward(G, name, precision):
             assert np.isfinite(e)
             if bound is not None:
                 assert e <= bound[k.split("_", 1)[1]], f"{name} {precision} {k}: {e}"
+
+
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 2), (2, 3), (3, 5), (7, 63), (5, 65), (2, 257), (1, 512), (129, 7)])
+@pytest.mark.parametrize("randomized", [False, True])
+def test_extreme_shapes_vs_oracle(G, B, N, randomized):
+    """Sample counts from 1 to 512 (below / across / above a wavefront, odd, not a multiple of 4) and single-ray batches: the
+    whole forward in fp32 mode against the oracle with the randomized draws injected, bf16 against its usual bounds."""
+    params = orc.make_params(seed=21, density_gain=30.0)
+    rays = orc.synthetic_rays(B, seed=100 + B + N, multiscale=True)
+    rng = np.random.default_rng(B * 1000 + N)
+    t_rand = rng.random((B, N + 1), dtype=np.float32) if randomized else None
+    u_rand = rng.random((B, N + 1), dtype=np.float32) if randomized else None
+    want = orc.mipnerf_forward(params, rays, randomized, True, num_samples=N, t_rand=t_rand, u_rand=u_rand)
+    kw = dict(t_rand=torch.from_numpy(t_rand).to(G.DEV), u_rand=torch.from_numpy(u_rand).to(G.DEV)) if randomized else {}
+    worst = {}
+    for precision, tol in (("fp32", G.TOL_FP32), ("bf16", G.TOL_BF16)):
+        model = G.make_model(params, N, precision)
+        with torch.no_grad():
+            ret = model(G.to_dev(rays), randomized, True, **kw)
+        for lvl in range(2):
+            for nm, val in zip(G.NAMES, ret[lvl]):
+                e = G.maxdiff(val, np.asarray(want[lvl][G.NAMES.index(nm)]).reshape(tuple(val.shape)))
+                worst[f"{precision}_{nm}"] = max(worst.get(f"{precision}_{nm}", 0.0), e)
+                # fp32: 257+ samples accumulate rounding over a longer scan; bf16 with a handful of bins: one level-0 weight
+                # error of 1e-2 moves a whole resampled fence post by a large fraction of a (wide) bin
+                slack = 4.0 if precision == "fp32" and N >= 257 else (2.5 if precision == "bf16" and N < 16 else 1.0)
+                assert e <= tol[nm] * slack, (precision, lvl, nm, e)
+    G.record(f"extreme_shape B={B} N={N} rand={int(randomized)}", **worst)
