@@ -486,7 +486,7 @@ def test_fp32_native_mlp_backward_matches_reference_golden(G):
     G.record("fp32_native_mlp_bwd_vs_reference_golden", worst=worst)
 
 
-@pytest.mark.parametrize("B,N,white", [(37, 100, False), (300, 32, True)])
+@pytest.mark.parametrize("B,N,white", [(37, 100, False), (300, 32, True), (1, 1, True), (2, 3, False), (5, 65, True), (1, 512, False)])
 def test_native_train_step_ragged_shapes_randomized(G, B, N, white):
     """mipnerf_train_step vs the autograd path on ragged sizes (rays not a multiple of the 256-sample tile, N not a
     multiple of 32) with the SAME stratified / resampling draws injected into both."""
@@ -509,7 +509,7 @@ def test_native_train_step_ragged_shapes_randomized(G, B, N, white):
             dl = [distloss(r[3], r[4]) for r in ret]
             tot = 0.1 * (mse[0] + 0.01 * dl[0]) + mse[1] + 0.01 * dl[1]
             tot.backward()
-            loss = float(tot)
+            loss = float(tot.detach())
         res[native] = (loss, torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone())
     (l0, g0), (l1, g1) = res[False], res[True]
     eg = G.maxdiff(g0, g1) / float(g0.abs().max())
