@@ -334,3 +334,25 @@ def test_extreme_shapes_vs_oracle(G, B, N, randomized):
                 slack = 4.0 if precision == "fp32" and N >= 257 else (2.5 if precision == "bf16" and N < 16 else 1.0)
                 assert e <= tol[nm] * slack, (precision, lvl, nm, e)
     G.record(f"extreme_shape B={B} N={N} rand={int(randomized)}", **worst)
+
+
+@pytest.mark.parametrize("N", [128, 256])
+def test_whole_frame_in_one_call_equals_chunks(G, N):
+    """640,000 rays (an 800x800 frame, BASELINE configs[4]) in ONE forward call -- 82 M / 164 M samples per level, outputs
+    past 2^31 bytes -- equals the 8192-ray chunks of render_image bit for bit (64-bit indexing everywhere)."""
+    from mipnerf_pl_amd import Rays
+    B = 640000
+    params = orc.make_params(seed=5, density_gain=30.0)
+    m = G.make_model(params, N, "bf16")
+    base = orc.synthetic_rays(8192, seed=3, multiscale=True)
+    reps = (B + 8191) // 8192
+    R = Rays(*[torch.from_numpy(np.tile(a, (reps, 1))[:B]).to(G.DEV) for a in base])
+    R = R._replace(radii=R.radii * (1.0 + 0.01 * (torch.arange(B, device=G.DEV) // 8192).float())[:, None])   # tiles differ
+    with torch.no_grad():
+        full = m(R, False, True)
+        for c0 in (0, 8192 * 37, B - 1024):
+            part = m(Rays(*[x[c0:c0 + 8192] for x in R]), False, True)
+            for lvl in range(2):
+                for a, b in zip(full[lvl], part[lvl]):
+                    assert torch.equal(a[c0:c0 + b.shape[0]], b), (N, c0, lvl)
+    assert bool(torch.isfinite(full[1][0]).all())
