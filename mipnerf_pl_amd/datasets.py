@@ -242,7 +242,7 @@ class BaseDataset(torch.utils.data.Dataset):
     def rays_at(self, ids):
         """(Rays [n,k], pixels [n,3]) of global pixel ids `ids` (int64 device tensor over the concatenation of all images)."""
         d = self._need_device()
-        ids = ids.to(d["offsets"].device, torch.int64).reshape(-1)
+        ids = ids.to(d["offsets"].device, torch.int64).reshape(-1).contiguous()
         cam = torch.searchsorted(d["offsets"], ids, right=True) - 1
         pix = ids - d["offsets"][cam]
         rays = ops.generate_rays(d["cameras"], cam_idx=cam, pix_idx=pix)
@@ -343,16 +343,34 @@ class RenderGen(torch.utils.data.Dataset):
 
 class RayLoader:
     """What `DataLoader(dataset, shuffle, batch_size)` yields in nerf_system.py:78-93, without the host: a fresh device
-    permutation of the pixel ids per epoch (train) or one image per item with the leading batch dimension of 1 (val / test)."""
+    permutation of the pixel ids per epoch (train) or one image per item with the leading batch dimension of 1 (val / test).
+    With world_size > 1 (default: the initialised torch.distributed group) every rank draws the SAME permutation (same seed,
+    same epoch) and keeps every world_size-th id starting at its rank -- what Lightning's DistributedSampler does for the
+    reference under train.py:56-60 -- so the global batch is batch_size x world_size disjoint rays."""
 
-    def __init__(self, dataset, batch_size=1, shuffle=False, drop_last=False, seed=0):
+    def __init__(self, dataset, batch_size=1, shuffle=False, drop_last=False, seed=0, rank=None, world_size=None):
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
-        self.generator = None
-        self.seed = seed
+        self.seed, self.epoch = int(seed), 0
+        if world_size is None:
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized()
+            world_size, rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+        self.rank, self.world_size = int(rank or 0), int(world_size)
+
+    def _local_count(self):
+        n = len(self.dataset)
+        if self.dataset.split != "train":
+            return n
+        return (n - self.rank + self.world_size - 1) // self.world_size
 
     def __len__(self):
-        n = len(self.dataset)
+        n = self._local_count()
+        if self.dataset.split != "train":
+            return n
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
 
     def __iter__(self):
         ds = self.dataset
@@ -361,11 +379,15 @@ class RayLoader:
                 rays, image = ds[i]
                 yield Rays(*[t[None] for t in rays]), image[None]
             return
-        if self.generator is None:
-            self.generator = torch.Generator(device=ds.device)
-            self.generator.manual_seed(self.seed)
         n = len(ds)
-        order = torch.randperm(n, device=ds.device, generator=self.generator) if self.shuffle else torch.arange(n, device=ds.device)
+        if self.shuffle:
+            g = torch.Generator(device=ds.device)
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(n, device=ds.device, generator=g)
+        else:
+            order = torch.arange(n, device=ds.device)
+        self.epoch += 1
+        order = order[self.rank::self.world_size]
         for b in range(len(self)):
             yield ds.rays_at(order[b * self.batch_size:(b + 1) * self.batch_size])
 
