@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MIPNERF_ABI_VERSION 2
+#define MIPNERF_ABI_VERSION 3
 
 enum {
     MIPNERF_OK = 0,
@@ -253,6 +253,25 @@ int mipnerf_distloss(int64_t num_rays, int32_t num_samples, const float* weights
                      const float* t_samples, float* ray_loss, const float* g_ray, float* d_w,
                      void* stream);
 
+/* ---- gradient through the resampler: MipNerf(stop_resample_grad=False) (mip.py:265-279, mip_nerf.py:204-214) ----
+ * With the flag off the fine level's fence posts stay in the autograd graph; these are the extra backward pieces
+ * (fp32 parity mode): compositing and distloss also return dL/dt_samples [B, N+1]; the MLP backward returns the gradient
+ * w.r.t. its input encoding; cast_rays + integrated_pos_enc and the PDF resampler get their backward. */
+int mipnerf_volumetric_rendering_bwd_t(int64_t num_rays, int32_t num_samples, const float* rgb_sigma,
+                                       const float* t_samples, const float* directions, int32_t white_bkgd,
+                                       const float* g_rgb, const float* g_dist, const float* g_acc, const float* g_w,
+                                       float rgb_padding, float* d_raw, float* d_t, void* stream);
+int mipnerf_distloss_bwd(int64_t num_rays, int32_t num_samples, const float* weights, const float* t_samples,
+                         const float* g_ray, float* d_w, float* d_t, void* stream);
+/* d_t [B, N+1] += dL/dt from d_enc [B*N, 6*(max_deg-min_deg)] fp32 (d_t zeroed or holding earlier contributions). */
+int mipnerf_cast_ipe_bwd(int64_t num_rays, int32_t num_samples, int32_t min_deg, int32_t max_deg,
+                         int32_t disable_integration, const float* t_samples, const float* origins,
+                         const float* directions, const float* radii, const float* d_enc, float* d_t, void* stream);
+/* d_weights [B, N] of mipnerf_resample_along_rays for d_t_new [B, N+1]; same u_rand (or NULL) as the forward. */
+int mipnerf_resample_along_rays_bwd(int64_t num_rays, int32_t num_samples, const float* t_samples, const float* weights,
+                                    const float* u_rand, float resample_padding, const float* d_t_new,
+                                    float* d_weights, void* stream);
+
 /* ---- native MLP training step (bf16 MFMA kernels; what torch autograd does to mip_nerf.py:75-111) ----
  * mipnerf_mlp_forward_train = mipnerf_mlp_forward (bf16) that also saves, per 32-sample wave tile, the
  * transposed activations of every layer input (`act`) and the ReLU bit masks (`masks`).
@@ -292,6 +311,10 @@ int mipnerf_mlp_forward_train_f32(mipnerf_ctx* ctx, int64_t num_points, int32_t 
 int mipnerf_mlp_backward_f32(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples, const float* d_raw,
                              const float* enc, const float* viewenc, const float* save, void* workspace,
                              float* grad_flat, int32_t accumulate, void* stream);
+/* The same plus d_enc [num_points, xyz_dim] = dL/d(encoding) (needed only with stop_resample_grad=False). */
+int mipnerf_mlp_backward_f32_enc(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples, const float* d_raw,
+                                 const float* enc, const float* viewenc, const float* save, void* workspace,
+                                 float* grad_flat, int32_t accumulate, float* d_enc, void* stream);
 
 /* ---- optimiser step with the LR schedule on the device (graph-capturable: no per-step host scalars) ------------------
  * torch.optim.Adam(lr) + MipLRDecay of the reference (nerf_system.py:70-76, utils/lr_schedule.py:51-59).

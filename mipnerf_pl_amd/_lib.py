@@ -74,6 +74,10 @@ SIGNATURES = {
     "mipnerf_activate": (C.c_int, [_I64, _P, _F, _F, _P, _F, _P, _P]),
     "mipnerf_volumetric_rendering_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _F, _P, _P]),
     "mipnerf_distloss": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "mipnerf_volumetric_rendering_bwd_t": (C.c_int, [_I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "mipnerf_distloss_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "mipnerf_cast_ipe_bwd": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "mipnerf_resample_along_rays_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _F, _P, _P, _P]),
     "mipnerf_mlp_train_sizes": (C.c_int, [_P, _I64, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ)]),
     "mipnerf_mlp_forward_train": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "mipnerf_mlp_backward": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _P]),
@@ -85,6 +89,7 @@ SIGNATURES = {
     "mipnerf_mlp_train_f32_bytes": (_SZ, [_P, _I64, C.POINTER(_SZ), C.POINTER(_SZ)]),
     "mipnerf_mlp_forward_train_f32": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "mipnerf_mlp_backward_f32": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _P]),
+    "mipnerf_mlp_backward_f32_enc": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I32, _P, _P]),
     "mipnerf_train_workspace_bytes": (_SZ, [_P, _I64]),
     "mipnerf_train_step": (C.c_int, [_P, _I64, C.POINTER(RaysPtrs), _P, _P, _P, _P, C.c_uint32, _F, _F, _I32, _P, _SZ, _P, _I32, _P,
                                      C.POINTER(LevelOut), _P]),

@@ -31,7 +31,6 @@ class _RenderFromRaw(torch.autograd.Function):
         ctx.save_for_backward(rgb_sigma, ops._f32c(t_samples, "t"), ops._f32c(dirs, "dirs"))
         ctx.white = bool(white_bkgd)
         ctx.rgb_padding = float(rgb_padding)
-        ctx.mark_non_differentiable(t_samples)
         return comp_rgb, distance, acc, weights
 
     @staticmethod
@@ -43,6 +42,13 @@ class _RenderFromRaw(torch.autograd.Function):
         def p(g):
             return None if g is None else g.contiguous().float().data_ptr()
         keep = [g.contiguous().float() if g is not None else None for g in (g_rgb, g_dist, g_acc, g_w)]
+        if ctx.needs_input_grad[1]:        # t_samples in the graph (stop_resample_grad=False): also dL/dt_samples
+            d_t = torch.empty_like(t)
+            L.check(L.lib().mipnerf_volumetric_rendering_bwd_t(
+                B, N, rgb_sigma.data_ptr(), t.data_ptr(), dirs.data_ptr(), int(ctx.white),
+                *[None if k is None else k.data_ptr() for k in keep], ctx.rgb_padding, d_raw.data_ptr(), d_t.data_ptr(),
+                ops._stream()), "volumetric_rendering_bwd_t")
+            return d_raw, d_t, None, None, None, None, None, None
         L.check(L.lib().mipnerf_volumetric_rendering_bwd(
             B, N, rgb_sigma.data_ptr(), t.data_ptr(), dirs.data_ptr(), int(ctx.white),
             *[None if k is None else k.data_ptr() for k in keep], ctx.rgb_padding, d_raw.data_ptr(), ops._stream()),
@@ -70,6 +76,11 @@ class _DistLossRays(torch.autograd.Function):
         B, N = weights.shape
         g = g_ray.contiguous().float()
         d_w = torch.empty_like(weights)
+        if ctx.needs_input_grad[1]:        # t_samples in the graph (stop_resample_grad=False)
+            d_t = torch.empty_like(t_samples)
+            L.check(L.lib().mipnerf_distloss_bwd(B, N, weights.data_ptr(), t_samples.data_ptr(), g.data_ptr(), d_w.data_ptr(),
+                                                 d_t.data_ptr(), ops._stream()), "distloss_bwd_t")
+            return d_w, d_t
         L.check(L.lib().mipnerf_distloss(B, N, weights.data_ptr(), t_samples.data_ptr(), None, g.data_ptr(),
                                          d_w.data_ptr(), ops._stream()), "distloss_bwd")
         return d_w, None
@@ -168,15 +179,22 @@ class _MLPNativeF32(torch.autograd.Function):
         ws = nctx.scratch("f32_bwd", ctx.ws_bytes)
         total = sum(int(torch.Size(s).numel()) for s in ctx.shapes)
         grad_flat = torch.empty(total, device=save.device, dtype=torch.float32)
-        L.check(L.lib().mipnerf_mlp_backward_f32(nctx.handle, ctx.M, ctx.N, d_raw.data_ptr(), enc.data_ptr(), venc.data_ptr(),
-                                                 save.data_ptr(), ws.data_ptr(), grad_flat.data_ptr(), 0, ops._stream()),
-                "mlp_backward_f32")
+        d_enc = None
+        if ctx.needs_input_grad[1]:        # the encoding is in the graph (stop_resample_grad=False): input gradient too
+            d_enc = torch.empty_like(enc)
+            L.check(L.lib().mipnerf_mlp_backward_f32_enc(nctx.handle, ctx.M, ctx.N, d_raw.data_ptr(), enc.data_ptr(),
+                                                         venc.data_ptr(), save.data_ptr(), ws.data_ptr(), grad_flat.data_ptr(), 0,
+                                                         d_enc.data_ptr(), ops._stream()), "mlp_backward_f32_enc")
+        else:
+            L.check(L.lib().mipnerf_mlp_backward_f32(nctx.handle, ctx.M, ctx.N, d_raw.data_ptr(), enc.data_ptr(), venc.data_ptr(),
+                                                     save.data_ptr(), ws.data_ptr(), grad_flat.data_ptr(), 0, ops._stream()),
+                    "mlp_backward_f32")
         grads, off = [], 0
         for shp in ctx.shapes:
             n = int(torch.Size(shp).numel())
             grads.append(grad_flat[off:off + n].view(shp))
             off += n
-        return (None, None, None, *grads)
+        return (None, d_enc, None, *grads)
 
 
 def mlp_native_f32(mlp, samples_enc, viewdirs_enc):
@@ -187,6 +205,56 @@ def mlp_native_f32(mlp, samples_enc, viewdirs_enc):
 def mlp_native(mlp, samples_enc, viewdirs_enc):
     """Differentiable bf16 MLP: samples_enc [B,N,96] bf16, viewdirs_enc [B,32] bf16 -> raw [B,N,4] fp32."""
     return _MLPNative.apply(mlp, samples_enc, viewdirs_enc, *mlp.ordered_params())
+
+
+class _CastIPE(torch.autograd.Function):
+    """cast_rays + integrated_pos_enc (mip.py:81-103, 322-350), fp32, differentiable w.r.t. t_samples: the route by which the
+    fine level's loss reaches the resampled fence posts when stop_resample_grad=False."""
+
+    @staticmethod
+    def forward(ctx, t_samples, origins, directions, radii, min_deg, max_deg, disable_integration):
+        t = ops._f32c(t_samples, "t_samples")
+        o, d, r = ops._f32c(origins, "origins"), ops._f32c(directions, "directions"), ops._f32c(radii, "radii")
+        enc = ops.cast_ipe(t, o, d, r, min_deg, max_deg, disable_integration, precision=L.PREC_FP32)
+        ctx.save_for_backward(t, o, d, r)
+        ctx.cfg = (int(min_deg), int(max_deg), int(bool(disable_integration)))
+        return enc
+
+    @staticmethod
+    def backward(ctx, d_enc):
+        t, o, d, r = ctx.saved_tensors
+        B, N = t.shape[0], t.shape[1] - 1
+        g = d_enc.contiguous().float()
+        d_t = torch.zeros_like(t)
+        L.check(L.lib().mipnerf_cast_ipe_bwd(B, N, ctx.cfg[0], ctx.cfg[1], ctx.cfg[2], t.data_ptr(), o.data_ptr(), d.data_ptr(),
+                                             r.data_ptr(), g.data_ptr(), d_t.data_ptr(), ops._stream()), "cast_ipe_bwd")
+        return d_t, None, None, None, None, None, None
+
+
+class _ResampleT(torch.autograd.Function):
+    """The t part of resample_along_rays (mip.py:232-280: blur pool, padding, sorted_piecewise_constant_pdf), differentiable
+    w.r.t. the coarse weights (stop_grad=False branch, mip.py:265-279)."""
+
+    @staticmethod
+    def forward(ctx, t_samples, weights, padding, u_rand):
+        t, w = ops._f32c(t_samples, "t_samples"), ops._f32c(weights, "weights")
+        u = None if u_rand is None else ops._f32c(u_rand, "u_rand")
+        t_new = ops.resample_t(t, w, u is not None, padding, u)
+        ctx.save_for_backward(t, w, *([u] if u is not None else []))
+        ctx.padding = float(padding)
+        return t_new
+
+    @staticmethod
+    def backward(ctx, d_t_new):
+        t, w = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        u = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
+        B, N = w.shape
+        g = d_t_new.contiguous().float()
+        d_w = torch.empty_like(w)
+        L.check(L.lib().mipnerf_resample_along_rays_bwd(B, N, t.data_ptr(), w.data_ptr(), None if u is None else u.data_ptr(),
+                                                        ctx.padding, g.data_ptr(), d_w.data_ptr(), ops._stream()),
+                "resample_along_rays_bwd")
+        return None, d_w, None, None
 
 
 def distloss(weight, samples):
@@ -210,16 +278,29 @@ def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_ra
         dz = dz.reshape(model.num_levels, -1)
     with torch.no_grad():
         venc = ops.pos_enc(rays.viewdirs, 0, model.deg_view, True, precision=model.precision, ld=32)
+    through = not model.stop_resample_grad          # mip.py:265-279: keep the resampler in the autograd graph
+    if through and native:
+        raise NotImplementedError("stop_resample_grad=False needs the gradient w.r.t. the MLP's input encoding, which the bf16 "
+                                  "dgrad kernel does not produce; use precision='fp32' for this option")
     ret = []
     t_samples, weights = None, None
     for lvl in range(model.num_levels):
-        with torch.no_grad():
-            if lvl == 0:
-                t_samples = ops.sample_t(N, rays.near, rays.far, randomized, model.disparity, t_rand)
-            else:
-                t_samples = ops.resample_t(t_samples, weights.detach(), randomized, model.resample_padding, u_rand)
-            enc = ops.cast_ipe(t_samples, rays.origins, rays.directions, rays.radii, model.min_deg_point,
-                               model.max_deg_point, model.disable_integration, precision=model.precision)
+        if through and lvl > 0:
+            B = rays.origins.shape[0]
+            u = None
+            if randomized:
+                u = torch.rand(B, N + 1, device=dev) if u_rand is None else u_rand
+            t_samples = _ResampleT.apply(t_samples, weights, model.resample_padding, u)
+            enc = _CastIPE.apply(t_samples, rays.origins, rays.directions, rays.radii, model.min_deg_point, model.max_deg_point,
+                                 model.disable_integration)
+        else:
+            with torch.no_grad():
+                if lvl == 0:
+                    t_samples = ops.sample_t(N, rays.near, rays.far, randomized, model.disparity, t_rand)
+                else:
+                    t_samples = ops.resample_t(t_samples, weights.detach(), randomized, model.resample_padding, u_rand)
+                enc = ops.cast_ipe(t_samples, rays.origins, rays.directions, rays.radii, model.min_deg_point,
+                                   model.max_deg_point, model.disable_integration, precision=model.precision)
         raw = mlp_native(model.mlp, enc, venc) if native else mlp_native_f32(model.mlp, enc, venc)
         comp_rgb, distance, acc, weights = render_from_raw(raw, t_samples, rays.directions, white_bkgd,
                                                            model.rgb_padding, model.density_bias,

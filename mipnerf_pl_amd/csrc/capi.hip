@@ -621,6 +621,41 @@ int mipnerf_distloss(int64_t B, int32_t N, const float* weights, const float* t,
     return MIPNERF_OK;
 }
 
+// ---- gradient through the resampler (stop_resample_grad=False, mip.py:265-279): the pieces autograd chains ------------------
+int mipnerf_volumetric_rendering_bwd_t(int64_t B, int32_t N, const float* rgb_sigma, const float* t, const float* dirs,
+                                       int32_t white_bkgd, const float* g_rgb, const float* g_dist, const float* g_acc,
+                                       const float* g_w, float rgb_padding, float* d_raw, float* d_t, void* stream) {
+    if (B < 1 || N < 1 || N > MIPNERF_MAX_SAMPLES || !rgb_sigma || !t || !dirs || !d_raw || !d_t)
+        return fail(MIPNERF_E_INVALID, "volumetric_rendering_bwd_t: bad argument");
+    HIP_TRY(mip::launch_volumetric_rendering_bwd(B, N, rgb_sigma, t, dirs, white_bkgd, g_rgb, g_dist, g_acc, g_w,
+                                                 rgb_padding, d_raw, S(stream), d_t));
+    return MIPNERF_OK;
+}
+
+int mipnerf_distloss_bwd(int64_t B, int32_t N, const float* weights, const float* t, const float* g_ray, float* d_w, float* d_t,
+                         void* stream) {
+    if (B < 1 || N < 1 || N > MIPNERF_MAX_SAMPLES || !weights || !t || !g_ray || !d_w || !d_t)
+        return fail(MIPNERF_E_INVALID, "distloss_bwd: bad argument");
+    HIP_TRY(mip::launch_distloss(B, N, weights, t, nullptr, g_ray, 0.0f, d_w, S(stream), d_t));
+    return MIPNERF_OK;
+}
+
+int mipnerf_cast_ipe_bwd(int64_t B, int32_t N, int32_t min_deg, int32_t max_deg, int32_t disable_integration, const float* t,
+                         const float* origins, const float* dirs, const float* radii, const float* d_enc, float* d_t, void* stream) {
+    if (B < 1 || N < 1 || !t || !origins || !dirs || !radii || !d_enc || !d_t || min_deg < 0 || max_deg > 31 || max_deg <= min_deg)
+        return fail(MIPNERF_E_INVALID, "cast_ipe_bwd: bad argument");
+    HIP_TRY(mip::launch_cast_ipe_bwd(B, N, min_deg, max_deg, disable_integration, t, origins, dirs, radii, d_enc, d_t, S(stream)));
+    return MIPNERF_OK;
+}
+
+int mipnerf_resample_along_rays_bwd(int64_t B, int32_t N, const float* t, const float* weights, const float* u_rand,
+                                    float resample_padding, const float* d_t_new, float* d_weights, void* stream) {
+    if (B < 1 || N < 1 || N > MIPNERF_MAX_SAMPLES || !t || !weights || !d_t_new || !d_weights)
+        return fail(MIPNERF_E_INVALID, "resample_along_rays_bwd: bad argument");
+    HIP_TRY(mip::launch_resample_bwd(B, N, t, weights, u_rand, resample_padding, d_t_new, d_weights, S(stream)));
+    return MIPNERF_OK;
+}
+
 // ---- native MLP training step (bf16) ------------------------------------------------------------------
 int mipnerf_mlp_train_sizes(const mipnerf_ctx* c, int64_t M, size_t* act_bytes, size_t* mask_bytes, size_t* delta_bytes,
                             size_t* partial_bytes) {
@@ -797,8 +832,25 @@ int mipnerf_mlp_forward_train_f32(mipnerf_ctx* c, int64_t M, int32_t N, const fl
     return MIPNERF_OK;
 }
 
+static int mlp_backward_f32_impl(mipnerf_ctx* c, int64_t M, int32_t N, const float* d_raw, const float* enc, const float* viewenc,
+                                 const float* save, void* workspace, float* grad_flat, int32_t accumulate, float* d_enc, void* stream);
+
 int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* d_raw, const float* enc, const float* viewenc,
                              const float* save, void* workspace, float* grad_flat, int32_t accumulate, void* stream) {
+    return mlp_backward_f32_impl(c, M, N, d_raw, enc, viewenc, save, workspace, grad_flat, accumulate, nullptr, stream);
+}
+
+// ... plus d_enc [M, xyz_dim] = dL/d(encoding) = delta_0 W_0 + delta_skip W_skip[:, W:] (the input gradient the reference's
+// autograd produces when the encoding requires grad, i.e. with stop_resample_grad=False)
+int mipnerf_mlp_backward_f32_enc(mipnerf_ctx* c, int64_t M, int32_t N, const float* d_raw, const float* enc, const float* viewenc,
+                                 const float* save, void* workspace, float* grad_flat, int32_t accumulate, float* d_enc,
+                                 void* stream) {
+    if (!d_enc) return fail(MIPNERF_E_INVALID, "mlp_backward_f32_enc: d_enc is null");
+    return mlp_backward_f32_impl(c, M, N, d_raw, enc, viewenc, save, workspace, grad_flat, accumulate, d_enc, stream);
+}
+
+static int mlp_backward_f32_impl(mipnerf_ctx* c, int64_t M, int32_t N, const float* d_raw, const float* enc, const float* viewenc,
+                                 const float* save, void* workspace, float* grad_flat, int32_t accumulate, float* d_enc, void* stream) {
     if (!c || M < 1 || N < 1 || !d_raw || !enc || !viewenc || !save || !workspace || !grad_flat)
         return fail(MIPNERF_E_INVALID, "mlp_backward_f32: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_backward_f32: mipnerf_set_params has not been called");
@@ -881,6 +933,7 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
         }
         HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, W, g0, W, D - 1, d_raw + 3, 4, P(tDensW)));
     }
+    bool d_enc_written = false;
     float* g = g0;          // delta of layer i (gradient w.r.t. its pre-activation)
     float* gn = g1;
     for (int i = D - 1; i >= 0; --i) {
@@ -889,6 +942,13 @@ int mipnerf_mlp_backward_f32(mipnerf_ctx* c, int64_t M, int32_t N, const float* 
         const int nin = i == 0 ? E : W;
         HIP_TRY(wgrad(g, W, W, xin, nin, 1, nin, G(2 * i), ld, G(2 * i + 1)));
         if (ld > nin) HIP_TRY(wgrad(g, W, W, enc, E, 1, E, G(2 * i) + W, ld, nullptr));      // skip concat (:96-97)
+        if (d_enc && (ld > nin || i == 0)) {
+            // the encoding columns of this layer's weight: [W, W + E) of the skip layer, [0, E) of layer 0
+            if (!mip::gemm_f32_big_ok(Mi, E, W, g, W)) return fail(MIPNERF_E_UNSUPPORTED, "mlp_backward_f32_enc: encoding narrower than 64");
+            HIP_TRY(mip::launch_gemm_f32_big(false, Mi, E, W, g, W, P(2 * i) + (i == 0 ? 0 : W), ld, d_enc, E, d_enc_written, 1, nullptr,
+                                             nullptr, nullptr, 0, nullptr, nullptr, st));
+            d_enc_written = true;
+        }
         if (i > 0) {
             HIP_TRY(dgrad(g, W, W, P(2 * i), ld, W, gn, W, i - 1));
             float* t = g; g = gn; gn = t;

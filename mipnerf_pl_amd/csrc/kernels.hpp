@@ -53,9 +53,10 @@ hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float
                            float dnoise_scale, float* out, hipStream_t st);
 hipError_t launch_volumetric_rendering_bwd(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs,
                                            int white_bkgd, const float* g_rgb, const float* g_dist, const float* g_acc,
-                                           const float* g_w, float rgb_padding, float* d_raw, hipStream_t st);
+                                           const float* g_w, float rgb_padding, float* d_raw, hipStream_t st,
+                                           float* d_t = nullptr);      // d_t [B, N+1]: gradient w.r.t. t_samples (stop_resample_grad=False)
 hipError_t launch_distloss(int64_t B, int N, const float* weights, const float* t, float* ray_loss, const float* g_ray,
-                           float g_const, float* d_w, hipStream_t st);
+                           float g_const, float* d_w, hipStream_t st, float* d_t = nullptr);
 hipError_t launch_loss_fused(int64_t B, int nlevels, const float* rgb0, const float* rgb1, const float* gt, const float* lossmult,
                              const float* ray_loss0, const float* ray_loss1, float coarse_mult, float dist_mult, float* g_rgb0,
                              float* g_rgb1, float* out, hipStream_t st);
@@ -110,6 +111,17 @@ hipError_t launch_mlp_bf16_dgrad(const void* stream_wT, const float* d_raw, cons
 MIP_DECL_TRAIN_VARIANT(_v1);
 MIP_DECL_TRAIN_VARIANT(_v2);
 #undef MIP_DECL_TRAIN_VARIANT
+
+// ---- kernels_resample_grad.hip: the gradient through the resampler (stop_resample_grad=False, mip.py:265-279) -------------
+// d_t[b, i] += dL/dt from dL/denc [M, 6 * ndeg] fp32 through integrated_pos_enc, lift_gaussian and conical_frustum_to_gaussian
+// (d_t must be zero-initialised or hold earlier contributions; two commutative atomic adds per element)
+hipError_t launch_cast_ipe_bwd(int64_t B, int N, int min_deg, int max_deg, int disable_integration, const float* t,
+                               const float* origins, const float* dirs, const float* radii, const float* d_enc, float* d_t,
+                               hipStream_t st);
+// d_weights [B, N] = dL/dweights of resample_along_rays' t part (blur pool + padding + sorted_piecewise_constant_pdf) for
+// dL/dt_new [B, N+1]; the same draws (u_rand or the deterministic linspace) as the forward
+hipError_t launch_resample_bwd(int64_t B, int N, const float* bins, const float* weights, const float* u_rand, float padding,
+                               const float* d_t_new, float* d_weights, hipStream_t st);
 
 // ---- kernels_wgrad.hip -----------------------------------------------------------------------
 constexpr int kWgradJobFloats = 8 * 9 * 64 * 16;     // fp32 partials per (job, split): [wave][slot][lane][reg]

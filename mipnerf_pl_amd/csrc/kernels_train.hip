@@ -59,7 +59,8 @@ __global__ void __launch_bounds__(256)
 k_volumetric_rendering_bwd(int64_t B, int N, const float4* __restrict__ rgb_sigma, const float* __restrict__ t,
                            const float* __restrict__ dirs, int white_bkgd, const float* __restrict__ g_rgb,
                            const float* __restrict__ g_dist, const float* __restrict__ g_acc,
-                           const float* __restrict__ g_w, float rgb_padding, float4* __restrict__ d_raw) {
+                           const float* __restrict__ g_w, float rgb_padding, float4* __restrict__ d_raw,
+                           float* __restrict__ d_t) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -102,10 +103,13 @@ k_volumetric_rendering_bwd(int64_t B, int N, const float4* __restrict__ rgb_sigm
         T1[k] = trans * ex;                     // T_{i+1}
         sd += (double)(w[k] * (0.5f * (tv[k] + tv[k + 1])));
     }
+    float gd_lo = 0.f, gd_hi = 0.f;     // clamp(distance, t_0, t_N): outside the bounds the gradient goes to the bound (d_t only)
     if (g_dist) {
         const float dsum = (float)wsum64(sd);
         const float tn = tb[0], tf = tb[N];
         gd = (dsum == dsum && dsum >= tn && dsum <= tf) ? g_dist[b] : 0.f;
+        if (dsum == dsum && dsum < tn) gd_lo = g_dist[b];
+        if (dsum == dsum && dsum > tf) gd_hi = g_dist[b];
     }
     double loc = 0.0;       // sum over this lane's samples of G_k w_k
     double suf[K];          // suffix within the lane (exclusive)
@@ -133,6 +137,33 @@ k_volumetric_rendering_bwd(int64_t B, int N, const float4* __restrict__ rgb_sigm
             d_raw[b * (int64_t)N + i0 + k] = o;
         }
     }
+    if (d_t) {
+        // t enters through delta_i = (t_{i+1} - t_i) |d| (x_i = sigma_i delta_i) and through tmid_i in `distance`:
+        //   dL/ddelta_i = sigma_i dL/dx_i ;  d_t[i] = |d| (a_{i-1} - a_i) + (h_{i-1} + h_i),  a = dL/ddelta / |d| * |d|, h = g_dist w / 2
+        float a[K], h[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool ok = i0 + k < N;
+            const float dxk = ok ? G[k] * T1[k] - (float)(soff + suf[k]) : 0.f;
+            a[k] = ok ? c[k].w * dxk * dn : 0.f;
+            h[k] = ok ? 0.5f * gd * w[k] : 0.f;
+        }
+        float pa = __shfl_up(a[K - 1], 1, 64), ph = __shfl_up(h[K - 1], 1, 64);
+        if (lane == 0) { pa = 0.f; ph = 0.f; }
+#pragma unroll
+        for (int k = 0; k <= K; ++k) {
+            const int i = i0 + k;
+            const float ak = k < K ? a[k < K ? k : 0] : 0.f, hk = k < K ? h[k < K ? k : 0] : 0.f;
+            // index i0 + K belongs to the next lane unless it is the last fence post of the ray
+            if (i <= N && (k < K || i == N)) {
+                float v = (pa - ak) + (ph + hk);
+                if (i == 0) v += gd_lo;
+                if (i == N) v += gd_hi;
+                d_t[b * (int64_t)(N + 1) + i] = v;
+            }
+            if (k < K) { pa = a[k]; ph = h[k]; }
+        }
+    }
 }
 
 // distloss (models/mip.py:8-20) per ray, O(N): t is sorted, so |m_i - m_j| = m_max - m_min and
@@ -142,7 +173,8 @@ k_volumetric_rendering_bwd(int64_t B, int N, const float4* __restrict__ rgb_sigm
 template <int K>
 __global__ void __launch_bounds__(256)
 k_distloss(int64_t B, int N, const float* __restrict__ weights, const float* __restrict__ t,
-           float* __restrict__ ray_loss, const float* __restrict__ g_ray, float g_const, float* __restrict__ d_w) {
+           float* __restrict__ ray_loss, const float* __restrict__ g_ray, float g_const, float* __restrict__ d_w,
+           float* __restrict__ d_t) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -184,6 +216,28 @@ k_distloss(int64_t B, int N, const float* __restrict__ weights, const float* __r
             }
         }
     }
+    if (d_t) {
+        // interval_i = t_{i+1} - t_i, m_i = (t_i + t_{i+1}) / 2:  dL/dinterval_i = w_i^2 / 3,
+        // dL/dm_i = 2 w_i (sum_{j<i} w_j - sum_{j>i} w_j)  (t sorted)  ->  d_t[i] = (A_{i-1} - A_i) + (C_{i-1} + C_i) / 2
+        const float g = g_ray ? g_ray[b] : g_const;
+        float A[K], C[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool ok = i0 + k < N;
+            const double P = oP + pP[k], wi = w[k];
+            A[k] = ok ? g * (float)(wi * wi / 3.0) : 0.f;
+            C[k] = ok ? g * (float)(2.0 * wi * (2.0 * P + wi - totP)) : 0.f;
+        }
+        float pa = __shfl_up(A[K - 1], 1, 64), pc = __shfl_up(C[K - 1], 1, 64);
+        if (lane == 0) { pa = 0.f; pc = 0.f; }
+#pragma unroll
+        for (int k = 0; k <= K; ++k) {
+            const int i = i0 + k;
+            const float ak = k < K ? A[k < K ? k : 0] : 0.f, ck = k < K ? C[k < K ? k : 0] : 0.f;
+            if (i <= N && (k < K || i == N)) d_t[b * (int64_t)(N + 1) + i] = (pa - ak) + 0.5f * (pc + ck);
+            if (k < K) { pa = A[k]; pc = C[k]; }
+        }
+    }
 }
 
 static inline unsigned gridf(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
@@ -197,12 +251,12 @@ hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float
 
 hipError_t launch_volumetric_rendering_bwd(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs,
                                            int white_bkgd, const float* g_rgb, const float* g_dist, const float* g_acc,
-                                           const float* g_w, float rgb_padding, float* d_raw, hipStream_t st) {
+                                           const float* g_w, float rgb_padding, float* d_raw, hipStream_t st, float* d_t) {
     const dim3 grid(gridf(B, 4)), block(256);
     const int K = (N + 63) / 64;
 #define MIP_VB(KK)                                                                                                  \
     hipLaunchKernelGGL((k_volumetric_rendering_bwd<KK>), grid, block, 0, st, B, N, (const float4*)rgb_sigma, t, dirs, \
-                       white_bkgd, g_rgb, g_dist, g_acc, g_w, rgb_padding, (float4*)d_raw)
+                       white_bkgd, g_rgb, g_dist, g_acc, g_w, rgb_padding, (float4*)d_raw, d_t)
     switch (K) {
         case 1: MIP_VB(1); break;
         case 2: MIP_VB(2); break;
@@ -215,10 +269,10 @@ hipError_t launch_volumetric_rendering_bwd(int64_t B, int N, const float* rgb_si
 }
 
 hipError_t launch_distloss(int64_t B, int N, const float* weights, const float* t, float* ray_loss, const float* g_ray,
-                           float g_const, float* d_w, hipStream_t st) {
+                           float g_const, float* d_w, hipStream_t st, float* d_t) {
     const dim3 grid(gridf(B, 4)), block(256);
     const int K = (N + 63) / 64;
-#define MIP_DL(KK) hipLaunchKernelGGL((k_distloss<KK>), grid, block, 0, st, B, N, weights, t, ray_loss, g_ray, g_const, d_w)
+#define MIP_DL(KK) hipLaunchKernelGGL((k_distloss<KK>), grid, block, 0, st, B, N, weights, t, ray_loss, g_ray, g_const, d_w, d_t)
     switch (K) {
         case 1: MIP_DL(1); break;
         case 2: MIP_DL(2); break;

@@ -313,8 +313,6 @@ class MipNerf(torch.nn.Module):
             raise NotImplementedError  # mip.py:97-98
         if rgb_activation != 'sigmoid' or density_activation != 'softplus':
             raise NotImplementedError  # mip_nerf.py:165,170
-        if not stop_resample_grad:
-            raise NotImplementedError("stop_resample_grad=False is not implemented")
         if not use_viewdirs and mlp_net_width_condition != mlp_net_width:
             # MLP.forward(x, None) feeds the trunk output to color_layer (mip_nerf.py:99-110): a shape error in the reference
             raise NotImplementedError("use_viewdirs=False needs mlp_net_width_condition == mlp_net_width "
@@ -373,6 +371,9 @@ class MipNerf(torch.nn.Module):
         distloss_c, distloss_f, psnr_fine, outputs or None).  bf16 precision only."""
         if self.precision != L.PREC_BF16:
             raise NotImplementedError("train_step_native is the bf16 path; fp32 parity mode trains through autograd")
+        if not self.stop_resample_grad:
+            raise NotImplementedError("stop_resample_grad=False trains through autograd in fp32 precision (the one-call native step "
+                                      "implements the shipped stop-gradient resampler)")
         dev = rays.origins.device
         if not rays.origins.is_cuda:
             raise RuntimeError("train_step_native needs rays on a HIP device; there is no CPU fallback")

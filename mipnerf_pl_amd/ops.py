@@ -91,7 +91,7 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u_rand
 def resample_t(t_samples, weights, randomized, resample_padding, u_rand=None):
     """t part of resample_along_rays (mip.py:250-271): blur-pool + padding + PDF inversion."""
     t_samples = _f32c(t_samples, "t_samples")
-    weights = _f32c(weights.detach(), "weights")     # stop_grad=True is the only supported mode
+    weights = _f32c(weights.detach(), "weights")     # no graph here; the differentiable form is autograd._ResampleT
     B, N = weights.shape
     if randomized and u_rand is None:
         u_rand = torch.rand(B, N + 1, device=weights.device)
@@ -105,9 +105,14 @@ def resample_t(t_samples, weights, randomized, resample_padding, u_rand=None):
 def resample_along_rays(origins, directions, radii, t_samples, weights, randomized, ray_shape, stop_grad,
                         resample_padding, u_rand=None):
     """models/mip.py:232-280 -> (new_t_vals [B,N+1], (means, covs))."""
-    if not stop_grad:
-        raise NotImplementedError("stop_resample_grad=False (gradient through the PDF sampler) is not implemented; "
-                                  "the shipped config uses stop_resample_grad=True")
+    if not stop_grad and torch.is_grad_enabled() and weights.requires_grad:
+        # mip.py:265-279: new_t_vals stays differentiable w.r.t. the weights (native backward, autograd._ResampleT); the Gaussians
+        # below are computed without a graph -- inside MipNerf the fused encoding (autograd._CastIPE) carries that gradient
+        from .autograd import _ResampleT
+        if randomized and u_rand is None:
+            u_rand = torch.rand(weights.shape[0], weights.shape[1] + 1, device=weights.device)
+        t = _ResampleT.apply(t_samples, weights, resample_padding, u_rand if randomized else None)
+        return t, cast_rays(t.detach(), origins, directions, radii, ray_shape)
     t = resample_t(t_samples, weights, randomized, resample_padding, u_rand)
     return t, cast_rays(t, origins, directions, radii, ray_shape)
 

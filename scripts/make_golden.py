@@ -14,6 +14,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-noise             round 2: density_noise > 0 with the reference's four draws replayed
     --only-variants          round 2: 128-wide trunk; use_viewdirs=False
     --only-datasets          round 2: Blender / Multicam / RealData360 / RenderGen on the synthetic datasets of tests/dataset_fixture.py
+    --only-resample-grad     round 2: stop_resample_grad=False -- loss and gradients with the cross-level path through the PDF sampler
     --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
     --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
 
@@ -581,6 +582,9 @@ if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
     if "--only-datasets" in sys.argv:       # round 2: the on-disk formats through the reference's dataset classes
         datasets_case("datasets_tiny")
+        sys.exit(0)
+    if "--only-resample-grad" in sys.argv:  # round 2: gradient through the resampler (stop_resample_grad=False, mip.py:265-279)
+        variant_case("var_resamplegrad_48x64", 48, 64, 5, 40.0, 23, stop_resample_grad=False)
         sys.exit(0)
     if "--only-variants" in sys.argv:       # round 2: other reference-legal MLP shapes
         variant_case("var_w128_48x64", 48, 64, param_seed=12, gain=20.0, ray_seed=12, mlp_net_width=128, mlp_net_width_condition=128)
