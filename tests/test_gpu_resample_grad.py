@@ -240,3 +240,21 @@ def test_training_step_matches_reference_gradients():
         s3.training_step((rays, gt), 0)
     with pytest.raises(NotImplementedError, match="autograd"):
         s3.training_step_native((rays, gt), 0)
+
+
+def test_ops_resample_along_rays_stop_grad_false():
+    """The free function of mip.py:232-280 with stop_grad=False: new_t_vals carries the gradient to the weights."""
+    from mipnerf_pl_amd import ops
+    B, N = 6, 40
+    o, d, _, r = some_rays(B, 9)[:4]
+    bins = sorted_t(B, N, 8)
+    w = torch.rand(B, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)).requires_grad_(True)
+    t_new, (means, covs) = ops.resample_along_rays(o, d, r, bins, w, False, "cone", False, 0.01)
+    assert t_new.requires_grad and means.shape == (B, N, 3) and covs.shape == (B, N, 3)
+    coef = torch.randn(B, N + 1, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    (t_new * coef).sum().backward()
+    w2 = w.detach().clone().requires_grad_(True)
+    (t_resample(bins, w2, 0.01, draws(B, N, False, 0)[1]) * coef).sum().backward()
+    assert rel(w.grad, w2.grad) <= 2e-3
+    t_sg, _ = ops.resample_along_rays(o, d, r, bins, w, False, "cone", True, 0.01)      # the shipped mode: no graph
+    assert not t_sg.requires_grad and torch.equal(t_sg, t_new.detach())
