@@ -15,6 +15,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-variants          round 2: 128-wide trunk; use_viewdirs=False
     --only-datasets          round 2: Blender / Multicam / RealData360 / RenderGen on the synthetic datasets of tests/dataset_fixture.py
     --only-resample-grad     round 2: stop_resample_grad=False -- loss and gradients with the cross-level path through the PDF sampler
+    --only-init              round 2: checksums of the freshly initialised parameters under a fixed torch seed
     --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
     --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
 
@@ -578,6 +579,24 @@ def datasets_case(name):
     print(f"[golden] {name}: {len(out)} arrays")
 
 
+
+def init_case(name):
+    """Same-seed initialisation (mip_nerf.py:19-73: xavier_uniform on every Linear except color_layer, in construction order):
+    checksums of `MipNerf(**kw).state_dict()` under torch.manual_seed(seed) for the shipped shape and the two variants."""
+    out = {}
+    for tag, seed, kw in (("default", 0, {}), ("w128", 3, dict(mlp_net_width=128)),
+                          ("noview", 3, dict(use_viewdirs=False, mlp_net_width_condition=256))):
+        torch.manual_seed(seed)
+        sd = RefMipNerf(**kw).state_dict()
+        out[tag + "_seed"] = np.int64(seed)
+        for k, v in sd.items():
+            a = v.numpy().ravel()
+            out[f"{tag}_sum_{k}"] = np.float64(a.astype(np.float64).sum())
+            out[f"{tag}_head_{k}"] = a[:8].copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz ({len(out)} arrays)")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "reference not mounted"
     if "--only-datasets" in sys.argv:       # round 2: the on-disk formats through the reference's dataset classes
@@ -585,6 +604,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-resample-grad" in sys.argv:  # round 2: gradient through the resampler (stop_resample_grad=False, mip.py:265-279)
         variant_case("var_resamplegrad_48x64", 48, 64, 5, 40.0, 23, stop_resample_grad=False)
+        sys.exit(0)
+    if "--only-init" in sys.argv:           # round 2: same-seed parameter initialisation
+        init_case("init_seeded")
         sys.exit(0)
     if "--only-variants" in sys.argv:       # round 2: other reference-legal MLP shapes
         variant_case("var_w128_48x64", 48, 64, param_seed=12, gain=20.0, ray_seed=12, mlp_net_width=128, mlp_net_width_condition=128)

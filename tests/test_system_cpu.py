@@ -162,3 +162,19 @@ def test_system_derives_from_lightning_module_when_available():
         del sys.modules["pytorch_lightning"]
         importlib.reload(system_mod)
     assert not system_mod._HAVE_PL
+
+
+def test_same_seed_initialisation_equals_reference():
+    """mip_nerf.py:19-73: a user who seeds torch and constructs MipNerf gets bit-for-bit the reference's initial weights
+    (same Linear construction order, xavier_uniform on everything but color_layer) -- golden from the reference itself."""
+    import os
+    import numpy as np
+    from mipnerf_pl_amd import MipNerf
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "init_seeded.npz"))
+    for tag, kw in (("default", {}), ("w128", dict(mlp_net_width=128)), ("noview", dict(use_viewdirs=False, mlp_net_width_condition=256))):
+        torch.manual_seed(int(g[tag + "_seed"]))
+        sd = MipNerf(**kw).state_dict()
+        for k, v in sd.items():
+            a = v.numpy().ravel()
+            assert np.array_equal(a[:8], g[f"{tag}_head_{k}"]), (tag, k)
+            assert float(a.astype(np.float64).sum()) == float(g[f"{tag}_sum_{k}"]), (tag, k)
