@@ -16,6 +16,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-datasets          round 2: Blender / Multicam / RealData360 / RenderGen on the synthetic datasets of tests/dataset_fixture.py
     --only-resample-grad     round 2: stop_resample_grad=False -- loss and gradients with the cross-level path through the PDF sampler
     --only-init              round 2: checksums of the freshly initialised parameters under a fixed torch seed
+    --only-grad-options      round 2: training step on a black background, disparity sampling, multiscale loss off, randomized draws replayed
     --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
     --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
 
@@ -290,6 +291,46 @@ def grad_case(name, batch, num_samples, param_seed, gain, ray_seed):
         out["g_smp_" + key] = g[::stride][:64].copy()
     oloss = orc.training_loss([tuple(x.detach().numpy() for x in lv) for lv in ret], rays, gt)
     assert abs(float(oloss) - float(loss.item())) < 1e-5, (oloss, loss.item())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz loss={loss.item():.6f}")
+
+
+
+def grad_options_case(name, batch, num_samples, param_seed, gain, ray_seed, torch_seed):
+    """Training-step golden for the OTHER settings of the boundary (nerf_system.py:17-21, 95-111; mip_nerf.py:186-214): black
+    background, disparity sampling, `loss.disable_multiscale_loss` (mask = ones), randomized=True with the reference's two CPU
+    draws captured (torch.rand at mip.py:159, Tensor.uniform_ at mip.py:201) so that they can be replayed."""
+    rays = orc.synthetic_rays(batch, seed=ray_seed, multiscale=True)
+    R = to_ref_rays(rays)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples, disparity=True)
+    load_params(model, params)
+    gt = np.random.default_rng(4).uniform(0, 1, size=(batch, 3)).astype(np.float32)
+    rgbs = torch.from_numpy(gt)
+    # the two draws of the randomized forward, replayed from the same generator state (as randomized_case does): the
+    # reference's uniform_(to=s-eps) is s-eps times the unit draw the kernels scale themselves
+    torch.manual_seed(torch_seed)
+    t_rand = torch.rand(batch, num_samples + 1)
+    u_unit = torch.empty(batch, num_samples + 1).uniform_(0, 1)
+    torch.manual_seed(torch_seed)
+    ret = model(R, True, False)
+    mask = torch.ones_like(R.lossmult)
+    losses = [(mask * (rgb - rgbs[..., :3]) ** 2).sum() / mask.sum() for rgb, _, _, w, t in ret]
+    dls = [refmip.distloss(w, t) for _, _, _, w, t in ret]
+    loss = 0.1 * (losses[0] + 0.01 * dls[0]) + losses[1] + 0.01 * dls[-1]
+    loss.backward()
+    u_rand = u_unit.numpy()
+    out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain, gt=gt,
+               loss=np.float32(loss.item()), t_rand=t_rand.numpy(), u_rand=u_rand.astype(np.float32))
+    out.update(ret_dict(ret, prefix="wb0_"))
+    for k, p in model.named_parameters():
+        g = p.grad.detach().numpy().ravel()
+        stride = max(1, g.size // 64)
+        key = k.replace("mlp.", "")
+        out["g_l2_" + key] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["g_smp_" + key] = g[::stride][:64].copy()
+    oret = orc.mipnerf_forward(params, rays, True, False, num_samples=num_samples, disparity=True, t_rand=out["t_rand"], u_rand=out["u_rand"])
+    check_oracle(name, ret, oret, 2e-4)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"wrote {name}.npz loss={loss.item():.6f}")
 
@@ -607,6 +648,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-init" in sys.argv:           # round 2: same-seed parameter initialisation
         init_case("init_seeded")
+        sys.exit(0)
+    if "--only-grad-options" in sys.argv:   # round 2: training step with the other boundary settings
+        grad_options_case("train_options_40x64", 40, 64, 6, 40.0, 31, 77)
         sys.exit(0)
     if "--only-variants" in sys.argv:       # round 2: other reference-legal MLP shapes
         variant_case("var_w128_48x64", 48, 64, param_seed=12, gain=20.0, ray_seed=12, mlp_net_width=128, mlp_net_width_condition=128)

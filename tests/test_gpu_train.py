@@ -633,3 +633,55 @@ def test_native_mlp_backward_variant_noview(G):
     G.record("native_mlp_bwd_noview", raw_vs_emul=e_raw, grad_rel_l2_vs_emul=worst_em, grad_rel_l2_vs_fp32=worst_or)
     assert worst_em <= 1e-2 and worst_or <= 0.2, (worst_em, worst_or)
     assert e_raw <= 2e-2 * max(1.0, float(np.abs(raw_em).max()))
+
+
+def test_training_step_other_boundary_settings_vs_reference(G):
+    """The settings of the boundary the main training golden leaves at their defaults (nerf_system.py:17-21, 95-111;
+    mip_nerf.py:186-214): black background, disparity sampling, `loss.disable_multiscale_loss`, randomized=True with the
+    reference's two draws replayed -- loss and every gradient vs the reference's autograd in fp32 mode; the bf16 autograd path and
+    the one-call native step against that."""
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    g = G.load_golden("train_options_40x64")
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({'nerf.num_samples': int(g["num_samples"]), 'nerf.disparity': True, 'train.white_bkgd': False,
+               'loss.disable_multiscale_loss': True})
+    rays, gt = G.to_dev(G.rays_of(g)), torch.from_numpy(g["gt"]).to(DEV)
+    t_rand, u_rand = torch.from_numpy(g["t_rand"]).to(DEV), torch.from_numpy(g["u_rand"]).to(DEV)
+    grads = {}
+    for precision in ("fp32", "bf16"):
+        system = MipNeRFSystem(hp, precision=precision)
+        system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        system = system.to(DEV)
+        ret = system.mip_nerf(rays, True, False, t_rand=t_rand, u_rand=u_rand)
+        if precision == "fp32":
+            for lvl in range(2):
+                for nm, val in zip(G.NAMES, ret[lvl]):
+                    assert G.maxdiff(val, g[f"wb0_l{lvl}_{nm}"]) <= G.TOL_FP32[nm], (lvl, nm)
+        loss = system.compute_loss(ret, rays, gt)[0]
+        loss.backward()
+        grads[precision] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in system.mip_nerf.mlp.named_parameters()})
+    l32, g32 = grads["fp32"]
+    assert abs(l32 - float(g["loss"])) <= 2e-5 * max(1.0, float(g["loss"]))
+    worst = 0.0
+    for k, gr in g32.items():
+        a = gr.cpu().numpy().ravel()
+        l2 = float(g["g_l2_" + k])
+        stride = max(1, a.size // 64)
+        es = float(np.max(np.abs(a[::stride][:64] - g["g_smp_" + k]))) / max(float(np.abs(g["g_smp_" + k]).max()), l2 / np.sqrt(a.size), 1e-12)
+        worst = max(worst, es, abs(float(np.sqrt((a.astype(np.float64) ** 2).sum())) - l2) / max(l2, 1e-12))
+        assert es <= 5e-3 and abs(float(np.sqrt((a.astype(np.float64) ** 2).sum())) - l2) <= 2e-3 * max(l2, 1e-12), (k, es)
+    lb, gb = grads["bf16"]
+    assert abs(lb - l32) <= 2e-2 * max(1.0, abs(l32))
+    cos_worst = min(float((gb[k].double() * g32[k].double()).sum() / (gb[k].double().norm() * g32[k].double().norm()).clamp_min(1e-30))
+                    for k in g32)
+    assert cos_worst >= 0.97, cos_worst
+    # the one-call native step with the same draws
+    nsys = MipNeRFSystem(hp, precision="bf16")
+    nsys.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    nsys = nsys.to(DEV)
+    sc, _ = nsys.mip_nerf.train_step_native(rays, gt, True, False, disable_multiscale_loss=True, t_rand=t_rand, u_rand=u_rand)
+    assert abs(float(sc[0]) - lb) <= 1e-4 * max(1.0, abs(lb))
+    for k, p in nsys.mip_nerf.mlp.named_parameters():
+        assert G.maxdiff(p.grad, gb[k]) <= 2e-3 * max(1e-6, float(gb[k].abs().max())), k
+    G.record("training_step_other_settings", worst_grad_rel_fp32=worst, loss_fp32=l32, loss_bf16=lb, worst_cos_bf16=cos_worst)
