@@ -10,12 +10,11 @@
 
 #include "../../include/mipnerf_hip.h"
 #include "kernels.hpp"
+#include "mlp_variants_gen.hpp"
+#include "mlp_train_variants_gen.hpp"
 #include "mlp_plan_gen.hpp"
 
 // binary tables of the training kernels (mlp_train_plan.TrainPlan.blob()), linked in through train_tables.c (.incbin)
-extern "C" const unsigned char mip_train_tables[];       // variant 0
-extern "C" const unsigned char mip_train_tables_v1[];    // variants 1, 2 (build.py TRAIN_TABLE_VARIANTS)
-extern "C" const unsigned char mip_train_tables_v2[];
 
 namespace {
 
@@ -189,9 +188,8 @@ struct TrainTables {
 };
 
 bool train_tables(TrainTables& T, int variant = 0) {
-    if (variant < 0 || variant > 2) return false;
-    const unsigned char* blobs[3] = {mip_train_tables, mip_train_tables_v1, mip_train_tables_v2};
-    const int32_t* h = reinterpret_cast<const int32_t*>(blobs[variant]);
+    if (variant < 0 || variant >= mip::plan::kNumVariants || !mip::kTrainTableBlobs[variant]) return false;
+    const int32_t* h = reinterpret_cast<const int32_t*>(mip::kTrainTableBlobs[variant]);
     if (h[0] != 0x54524E31) return false;
     T.n_bchunks = h[1]; T.njobs = h[2]; T.NH = h[3]; T.NG = h[4]; T.NMASK = h[5]; T.job_floats = h[6]; T.nparams = h[7];
     T.n_scratch = h[11]; T.off_extra_w = h[12]; T.off_extra_b = h[13]; T.off_view_w = h[14]; T.off_view_b = h[15];
@@ -240,23 +238,22 @@ namespace {
 // the bf16 inference kernel generated for this context's architecture variant
 hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* viewenc, float* rgb_sigma, float* raw, int64_t M, int N,
                                bool dma, const mip::RayInputs* rays, hipStream_t st) {
-    typedef hipError_t (*Fn)(const void*, const float*, const void*, const void*, float*, float*, int64_t, int, float, float, int, bool,
-                             const mip::RayInputs*, const float*, float, hipStream_t);
-    static const Fn table[mip::plan::kNumVariants] = {mip::launch_mlp_bf16, mip::launch_mlp_bf16_v1, mip::launch_mlp_bf16_v2};
-    return table[c->P->variant](c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
+    return mip::kLaunchBf16[c->P->variant](c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
                                 c->grid_limit, dma, rays, c->dnoise, c->cfg.density_noise, st);
 }
 
-// ... and its training kernels (variants with has_bf16_train)
+// ... and its training kernels (variants whose row of the generated kLaunchTrainFwd table is not null)
+static inline bool has_bf16_train(const PlanDesc* P) { return mip::kLaunchTrainFwd[P->variant] != nullptr; }
 hipError_t launch_trainfwd_variant(mipnerf_ctx* c, const void* enc, const void* viewenc, float* rgb_sigma, float* raw, void* act,
                                    void* masks, int64_t M, int N, const mip::RayInputs* rays, hipStream_t st) {
-    auto fn = c->P->variant == 1 ? mip::launch_mlp_bf16_trainfwd_v1
-                                 : (c->P->variant == 2 ? mip::launch_mlp_bf16_trainfwd_v2 : mip::launch_mlp_bf16_trainfwd);
+    const mip::LaunchTrainFwdFn fn = mip::kLaunchTrainFwd[c->P->variant];
+    if (!fn) return hipErrorInvalidValue;
     return fn(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, act, masks, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
               c->grid_limit, rays, c->dnoise, c->cfg.density_noise, st);
 }
 hipError_t launch_dgrad_variant(mipnerf_ctx* c, const float* d_raw, const void* masks, void* delta, int64_t M, hipStream_t st) {
-    auto fn = c->P->variant == 1 ? mip::launch_mlp_bf16_dgrad_v1 : (c->P->variant == 2 ? mip::launch_mlp_bf16_dgrad_v2 : mip::launch_mlp_bf16_dgrad);
+    const mip::LaunchDgradFn fn = mip::kLaunchDgrad[c->P->variant];
+    if (!fn) return hipErrorInvalidValue;
     return fn(c->d_stream_dgrad, d_raw, masks, delta, M, c->grid_limit, st);
 }
 
@@ -276,7 +273,7 @@ mip::F32Net f32net_with_heads(const mipnerf_ctx* c) {
 }
 
 #define NEED_BF16_TRAIN(what)                                                                                               \
-    if (!c->P->has_bf16_train)                                                                                               \
+    if (!has_bf16_train(c->P))                                                                                               \
         return fail(MIPNERF_E_UNSUPPORTED, what ": no bf16 training kernels were generated for this architecture variant " \
                                                 "(gen_mlp_train.train_variants); train this shape in fp32 precision")
 
@@ -318,7 +315,7 @@ int mipnerf_num_variants(void) { return mip::plan::kNumVariants; }
 int mipnerf_variant_arch(int variant, mipnerf_config* cfg, int* has_bf16_training) {
     if (!cfg || variant < 0 || variant >= mip::plan::kNumVariants) return fail(MIPNERF_E_INVALID, "variant_arch: bad argument");
     variant_to_cfg(mip::plan::kPlans[variant], cfg);
-    if (has_bf16_training) *has_bf16_training = mip::plan::kPlans[variant].has_bf16_train;
+    if (has_bf16_training) *has_bf16_training = mip::kLaunchTrainFwd[variant] != nullptr;
     return MIPNERF_OK;
 }
 
@@ -385,11 +382,11 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
         c->grid_limit = cus;
     // ---- training tables (one blob per variant with generated bf16 training kernels) ----
-    if (P->has_bf16_train && (!train_tables(c->tt, P->variant) || c->tt.nparams != off_total(c->tab))) {
+    if (has_bf16_train(P) && (!train_tables(c->tt, P->variant) || c->tt.nparams != off_total(c->tab))) {
         mipnerf_destroy(c);
         return fail(MIPNERF_E_INVALID, "mipnerf_create: embedded training tables are inconsistent with the compiled plan");
     }
-    if (P->has_bf16_train) {
+    if (has_bf16_train(P)) {
         const TrainTables& tt = c->tt;
         const std::vector<int32_t> flat(tt.bpack, tt.bpack + (size_t)tt.n_bchunks * 512);
         const std::vector<int32_t> e_dg = encode(flat, c->tab.tensor_off);
@@ -410,7 +407,7 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
             return fail(MIPNERF_E_HIP, "mipnerf_create (training tables): %s", hipGetErrorString(er));
         }
     }
-    if (P->has_bf16_train) {
+    if (has_bf16_train(P)) {
         const int rc = mipnerf_set_wgrad_splits(c, nullptr);
         if (rc) { mipnerf_destroy(c); return rc; }
     }
@@ -453,7 +450,7 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
     HIP_TRY(mip::launch_pack(c->d_pack_bf16, nst, pp, c->d_stream_bf16, true, S(stream)));
     HIP_TRY(mip::launch_pack(c->d_pack_f32, nst, pp, c->d_stream_f32, false, S(stream)));
     HIP_TRY(mip::launch_pack(c->d_bias_idx, (int64_t)P.num_tiles * 32, pp, c->d_bias, false, S(stream)));
-    if (P.has_bf16_train) {
+    if (has_bf16_train(&P)) {
         HIP_TRY(mip::launch_pack(c->d_pack_dgrad, (int64_t)c->tt.n_bchunks * 512, pp, c->d_stream_dgrad, true, S(stream)));
         HIP_TRY(mip::launch_transpose_sq(P.net_width, pp.p[2 * P.net_depth + 2], c->d_extra_wT, S(stream)));
     }
@@ -961,7 +958,7 @@ static int mlp_backward_f32_impl(mipnerf_ctx* c, int64_t M, int32_t N, const flo
 // MipNeRFSystem.training_step (nerf_system.py:95-111) = MipNerf.forward(randomized) + loss, followed by what
 // loss.backward() does to the 24 MLP parameters -- native kernels only, no autograd graph, graph-capturable.
 size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
-    if (!c || B < 1 || !c->P->has_bf16_train) return 0;
+    if (!c || B < 1 || !has_bf16_train(c->P)) return 0;
     const size_t N = c->cfg.num_samples, M = (size_t)B * N, L = c->cfg.num_levels;
     size_t act, masks, delta, partials;
     if (mipnerf_mlp_train_sizes(c, (int64_t)M, &act, &masks, &delta, &partials)) return 0;
@@ -1194,7 +1191,7 @@ int64_t mipnerf_debug_table_variant(int variant, int which, int32_t* out_host, i
     if (variant < 0 || variant >= mip::plan::kNumVariants || which < 0 || which > 5) return -1;
     if (which >= 3) {               // training tables of the variant (3 dgrad pack, 4 wgrad partial -> parameter, 5 jobs)
         TrainTables tt;
-        if (!mip::plan::kPlans[variant].has_bf16_train || !train_tables(tt, variant)) return -1;
+        if (!train_tables(tt, variant)) return -1;
         const int32_t* src = which == 3 ? tt.bpack : (which == 4 ? tt.otab : tt.jobs);
         const int64_t n = which == 3 ? (int64_t)tt.n_bchunks * 512 : (which == 4 ? (int64_t)tt.njobs * tt.job_floats : tt.njobs * 20);
         if (out_host && cap >= n) memcpy(out_host, src, (size_t)n * 4);

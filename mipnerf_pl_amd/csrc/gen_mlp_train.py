@@ -119,6 +119,17 @@ class Prog:
         self.panels = []      # dict(first, n, pair, spk, post (list of stmts run during the next panel), pre)
 
 
+_WRITES_REG = __import__("re").compile(r"epilogue_half<[^>]*>\(\w+, (?:[\w\[\]]+, )?([XY]\[\d+\])\)")
+
+
+def _slot_b(sl):
+    """B-operand expression of a slot: 'X[3]' / 'Y[0]' / 'R' / an E register (forward slots carry ('reg', expr) until assign_lds_b)."""
+    if "bexpr" in sl:
+        return sl["bexpr"]
+    b = sl.get("b")
+    return b[1] if isinstance(b, tuple) and b[0] == "reg" else None
+
+
 def place_sides(prog, nchunks, which=""):
     """Spread each panel's `post` statements (and the next-next panel's `pre`) over the next panel's slots: the
     register work (epilogue, transposing MFMAs, masks) right away, one statement per slot; the T-block STORES evenly
@@ -143,7 +154,15 @@ def place_sides(prog, nchunks, which=""):
         stores = [st for st in post if count_stores(st) > 0]
         pos = 2
         for st in compute:
-            side[first + min(pos, n - 1)].append(st)
+            at = min(pos, n - 1)
+            # a statement that writes an activation register goes in front of this panel's first reader of it (one-panel
+            # producers feed slot 0 of their consumer); the statements that follow only read that register
+            m = _WRITES_REG.search(st)
+            if m:
+                readers = [c for c in range(first, first + n) if _slot_b(prog.slots[c]) == m.group(1)]
+                if readers:
+                    at = min(at, readers[0] - first - 1)
+            side[first + at].append(st)
             pos += 1
         lo = min(pos + 1, n - 1)                 # >= 2 slots after the last transposing MFMA
         hi = max(lo, n - 2)
@@ -648,25 +667,64 @@ def gen_dgrad(tp: TrainPlan, variant: int = 0) -> str:
 
 
 def train_variants():
-    """(variant index, TrainPlan) of every architecture of gen_mlp_bf16.VARIANTS the training plan covers (variant 0 = shipped)."""
+    """(variant index, TrainPlan, forward source, dgrad source) of every architecture of gen_mlp_bf16.VARIANTS the training plan
+    covers AND whose generated schedule passes the hazard check (variant 0 = shipped).  A shape that fails either (e.g. a
+    view layer so narrow that the colour head would read activations its epilogue has not written yet) simply has no bf16
+    training kernels: it trains in fp32 mode, and the library says so."""
     from gen_mlp_bf16 import VARIANTS
     out = []
     for vi, arch in enumerate(VARIANTS):
         try:
-            out.append((vi, TrainPlan.build(arch)))
-        except NotImplementedError:
-            pass
+            tp = TrainPlan.build(arch)
+            out.append((vi, tp, gen_trainfwd(tp, vi), gen_dgrad(tp, vi)))
+        except (NotImplementedError, AssertionError) as ex:
+            if vi == 0:
+                raise
+            print(f"variant {vi}: no bf16 training kernels ({type(ex).__name__}: {str(ex)[:120]})")
     return out
+
+
+def gen_train_variants_header(trainable, n):
+    """Declarations + dispatch tables of the per-variant training launchers and table blobs (nullptr: no bf16 training kernels)."""
+    L = ["// AUTO-GENERATED by gen_mlp_train.py from gen_mlp_bf16.VARIANTS -- do not edit by hand.", "#pragma once", '#include "kernels.hpp"']
+    for vi in trainable:
+        sfx = f"_v{vi}" if vi else ""
+        L.append(f'extern "C" const unsigned char mip_train_tables{sfx}[];')
+    L += ["namespace mip {",
+          "typedef hipError_t (*LaunchTrainFwdFn)(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,",
+          "                                       float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,",
+          "                                       float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,",
+          "                                       const float* dnoise, float dnoise_scale, hipStream_t st);",
+          "typedef hipError_t (*LaunchDgradFn)(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,",
+          "                                    int grid_limit, hipStream_t st);"]
+    for vi in trainable:
+        if vi == 0:
+            continue
+        L.append(f"hipError_t launch_mlp_bf16_trainfwd_v{vi}(const void*, const float*, const void*, const void*, float*, float*, void*, void*,")
+        L.append("                                        int64_t, int, float, float, int, const RayInputs*, const float*, float, hipStream_t);")
+        L.append(f"hipError_t launch_mlp_bf16_dgrad_v{vi}(const void*, const float*, const void*, void*, int64_t, int, hipStream_t);")
+
+    def tab(fmt0, fmtv):
+        return ", ".join((fmt0 if vi == 0 else fmtv.format(vi)) if vi in trainable else "nullptr" for vi in range(n))
+    L.append(f"static const LaunchTrainFwdFn kLaunchTrainFwd[{n}] = {{{tab('launch_mlp_bf16_trainfwd', 'launch_mlp_bf16_trainfwd_v{}')}}};")
+    L.append(f"static const LaunchDgradFn kLaunchDgrad[{n}] = {{{tab('launch_mlp_bf16_dgrad', 'launch_mlp_bf16_dgrad_v{}')}}};")
+    L.append(f"static const unsigned char* const kTrainTableBlobs[{n}] = {{{tab('mip_train_tables', 'mip_train_tables_v{}')}}};")
+    L.append("}  // namespace mip")
+    return "\n".join(L) + "\n"
 
 
 def main():
     outdir = sys.argv[1] if len(sys.argv) > 1 else HERE
-    for vi, tp in train_variants():
+    from gen_mlp_bf16 import VARIANTS
+    tvs = train_variants()
+    with open(os.path.join(outdir, "mlp_train_variants_gen.hpp"), "w") as f:
+        f.write(gen_train_variants_header([v[0] for v in tvs], len(VARIANTS)))
+    for vi, tp, src_fwd, src_dgrad in tvs:
         sfx = f"_v{vi}" if vi else ""
         with open(os.path.join(outdir, f"mlp_bf16_trainfwd_gen{sfx}.hip"), "w") as f:
-            f.write(gen_trainfwd(tp, vi))
+            f.write(src_fwd)
         with open(os.path.join(outdir, f"mlp_bf16_dgrad_gen{sfx}.hip"), "w") as f:
-            f.write(gen_dgrad(tp, vi))
+            f.write(src_dgrad)
         with open(os.path.join(outdir, f"_gen_train_tables{sfx}.bin"), "wb") as f:
             f.write(tp.blob())
         print(f"generated training kernels (variant {vi}): fwd {tp.fwd.n_real_chunks} chunks, dgrad {tp.n_bchunks_real} "

@@ -82,14 +82,8 @@ hipError_t launch_mlp_bf16(const void* stream_w, const float* bias_tab, const vo
                            float rgb_padding, int grid_limit, bool dma, const RayInputs* rays, const float* dnoise,
                            float dnoise_scale, hipStream_t st);
 
-// architecture variants (gen_mlp_bf16.VARIANTS): mlp_bf16_gen_v<i>.hip
-#define MIP_DECL_BF16_VARIANT(name)                                                                                          \
-    hipError_t name(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc, float* rgb_sigma,       \
-                    float* raw_out, int64_t M, int num_samples, float density_bias, float rgb_padding, int grid_limit, bool dma, \
-                    const RayInputs* rays, const float* dnoise, float dnoise_scale, hipStream_t st)
-MIP_DECL_BF16_VARIANT(launch_mlp_bf16_v1);
-MIP_DECL_BF16_VARIANT(launch_mlp_bf16_v2);
-#undef MIP_DECL_BF16_VARIANT
+// architecture variants (gen_mlp_bf16.VARIANTS): declared and tabulated in the generated mlp_variants_gen.hpp /
+// mlp_train_variants_gen.hpp
 
 // ---- mlp_bf16_trainfwd_gen.hip / mlp_bf16_dgrad_gen.hip (generated by gen_mlp_train.py) -------
 int mlp_trainfwd_lds_bytes();
@@ -100,17 +94,6 @@ hipError_t launch_mlp_bf16_trainfwd(const void* stream_w, const float* bias_tab,
 int mlp_dgrad_lds_bytes();
 hipError_t launch_mlp_bf16_dgrad(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,
                                  int grid_limit, hipStream_t st);
-// the same two kernels generated for the other architecture variants (gen_mlp_train.train_variants): *_gen_v<i>.hip
-#define MIP_DECL_TRAIN_VARIANT(sfx)                                                                                             \
-    hipError_t launch_mlp_bf16_trainfwd##sfx(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,    \
-                                             float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples, \
-                                             float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,        \
-                                             const float* dnoise, float dnoise_scale, hipStream_t st);                            \
-    hipError_t launch_mlp_bf16_dgrad##sfx(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,       \
-                                          int grid_limit, hipStream_t st)
-MIP_DECL_TRAIN_VARIANT(_v1);
-MIP_DECL_TRAIN_VARIANT(_v2);
-#undef MIP_DECL_TRAIN_VARIANT
 
 // ---- kernels_resample_grad.hip: the gradient through the resampler (stop_resample_grad=False, mip.py:265-279) -------------
 // d_t[b, i] += dL/dt from dL/denc [M, 6 * ndeg] fp32 through integrated_pos_enc, lift_gaussian and conical_frustum_to_gaussian

@@ -153,3 +153,20 @@ def test_generator_schedule_passes_hazard_check(tmp_path):
         gen = open(os.path.join(tmp_path, f)).read()
         committed = open(os.path.join(REPO, "mipnerf_pl_amd", "csrc", f)).read()
         assert gen == committed, f"{f} is stale: re-run python -m mipnerf_pl_amd.build"
+
+
+@pytest.mark.parametrize("arch_kw", [dict(net_width=192, net_width_condition=64), dict(net_width=64, net_width_condition=64)])
+def test_generators_schedule_narrow_layers_without_hazards(arch_kw):
+    """Shapes outside VARIANTS whose layers have a single two-tile panel (64-wide view layer / trunk): the consumer's first slot
+    needs the producer's activations, so the producer's epilogue must not be spread into the consumer's panel.  The inference
+    generator used to emit such a kernel silently (bf16 rgb off by 0.2 on an ad-hoc 8 x 192 / 64 build); both generators now place
+    register writes in front of their first reader and replay the schedule with a hazard check."""
+    sys.path.insert(0, os.path.join(REPO, "mipnerf_pl_amd", "csrc"))
+    import gen_mlp_bf16 as GI
+    import gen_mlp_train as GT
+    from mipnerf_pl_amd.mlp_plan import Arch, Plan
+    a = Arch(**arch_kw)
+    src = GI.gen_kernel(Plan.build(a), 9)
+    assert "namespace v9" in src and "epilogue_half" in src
+    tpv = TrainPlan.build(a)
+    assert "launch_mlp_bf16_trainfwd_v9" in GT.gen_trainfwd(tpv, 9) and "launch_mlp_bf16_dgrad_v9" in GT.gen_dgrad(tpv, 9)
