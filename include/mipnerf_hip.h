@@ -130,9 +130,12 @@ int mipnerf_compiled_arch(mipnerf_config* cfg);
 int mipnerf_num_variants(void);
 int mipnerf_variant_arch(int variant, mipnerf_config* cfg, int* has_bf16_training);
 
+/* Number of parameter tensors of the context's architecture = 2 x (net_depth + 3 + net_depth_condition) in the reference
+ * MLP's state_dict order (MIPNERF_NUM_PARAM_TENSORS = 24 for the shipped 8-layer shape). */
+int mipnerf_num_param_tensors(const mipnerf_ctx* ctx);
 /* (Re)pack the fp32 master parameters into the MFMA operand streams (bf16 fragment stream,
  * fp32 fragment stream, bias tables).  `params` is a HOST array of
- * MIPNERF_NUM_PARAM_TENSORS device pointers in state_dict order of the reference MLP
+ * mipnerf_num_param_tensors(ctx) device pointers (24 for the shipped shape) in state_dict order of the reference MLP
  * (mip_nerf.py:19-73): layers.{0..7}.0.{weight,bias}, density_layer.{weight,bias},
  * extra_layer.{weight,bias}, view_layers.0.0.{weight,bias}, color_layer.{weight,bias}.
  * Call after every optimizer step / load_state_dict. */

@@ -47,6 +47,7 @@ _P, _I32, _I64, _F, _SZ = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_
 SIGNATURES = {
     "mipnerf_last_error": (C.c_char_p, []),
     "mipnerf_abi_version": (C.c_int, []),
+    "mipnerf_num_param_tensors": (C.c_int, [_P]),
     "mipnerf_create": (C.c_int, [C.POINTER(Config), C.POINTER(_P)]),
     "mipnerf_destroy": (C.c_int, [_P]),
     "mipnerf_compiled_arch": (C.c_int, [C.POINTER(Config)]),

@@ -350,8 +350,8 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         return fail(MIPNERF_E_UNSUPPORTED, "no kernels / tables were generated for this MLP shape; generated: %s.  Add the shape to "
                                            "VARIANTS in csrc/gen_mlp_bf16.py and rebuild", have.c_str());
     }
-    if (P->num_param_tensors != MIPNERF_NUM_PARAM_TENSORS)
-        return fail(MIPNERF_E_UNSUPPORTED, "variant has %d parameter tensors, the ABI passes %d", P->num_param_tensors, MIPNERF_NUM_PARAM_TENSORS);
+    if (P->num_param_tensors > mip::kMaxParamTensors)
+        return fail(MIPNERF_E_UNSUPPORTED, "variant has %d parameter tensors, the library handles up to %d", P->num_param_tensors, mip::kMaxParamTensors);
     mipnerf_ctx* c = new mipnerf_ctx();
     c->cfg = *cfg;
     c->P = P;
@@ -436,6 +436,8 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
         default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
     }
 }
+
+int mipnerf_num_param_tensors(const mipnerf_ctx* c) { return c ? c->P->num_param_tensors : -1; }
 
 int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* stream) {
     if (!c || !params_host) return fail(MIPNERF_E_INVALID, "null argument");

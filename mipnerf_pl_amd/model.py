@@ -57,10 +57,11 @@ class NativeContext:
         key = tuple((p.data_ptr(), p._version) for p in params)
         if key == self._packed_key:
             return
-        if len(params) != L.NUM_PARAM_TENSORS:
-            raise NotImplementedError(f"expected {L.NUM_PARAM_TENSORS} parameter tensors, got {len(params)}")
+        want = int(L.lib().mipnerf_num_param_tensors(self._h))
+        if len(params) != want:
+            raise NotImplementedError(f"expected {want} parameter tensors for this architecture, got {len(params)}")
         keep = []
-        arr = (C.c_void_p * L.NUM_PARAM_TENSORS)()
+        arr = (C.c_void_p * want)()
         for i, p in enumerate(params):
             if not p.is_cuda or p.device != self.device:
                 raise RuntimeError(f"parameter {i} is on {p.device}, context is on {self.device}")

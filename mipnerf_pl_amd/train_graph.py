@@ -58,7 +58,8 @@ class GraphedTrainStep:
         self.ws = self.ctx.scratch("train_step", need)
         mlp.gather_foreign_grads()
         self._rp = L.RaysPtrs(*[t.data_ptr() for t in self.rays])
-        self._params = (C.c_void_p * L.NUM_PARAM_TENSORS)(*[p.data_ptr() for p in mlp.ordered_params()])
+        ptrs = [p.data_ptr() for p in mlp.ordered_params()]
+        self._params = (C.c_void_p * len(ptrs))(*ptrs)
 
     # ---- the two halves ------------------------------------------------------------------------------------------------
     def _fwd_bwd(self):

@@ -17,6 +17,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-resample-grad     round 2: stop_resample_grad=False -- loss and gradients with the cross-level path through the PDF sampler
     --only-init              round 2: checksums of the freshly initialised parameters under a fixed torch seed
     --only-grad-options      round 2: training step on a black background, disparity sampling, multiscale loss off, randomized draws replayed
+    --only-variant-depth     round 2: a 6-layer trunk with skip_index 3
     --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
     --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
 
@@ -165,7 +166,8 @@ def variant_case(name, batch, num_samples, param_seed, gain, ray_seed, **ctor):
     (deterministic, white background) + the training loss of nerf_system.py:99-111 and its gradients (l2, sum, samples) --
     parameters the forward never touches (extra_layer / view_layers without view directions) have grad None there: stored
     as zeros."""
-    arch = dict(net_width=ctor.get("mlp_net_width", 256), net_width_condition=ctor.get("mlp_net_width_condition", 128))
+    arch = dict(net_width=ctor.get("mlp_net_width", 256), net_width_condition=ctor.get("mlp_net_width_condition", 128),
+                net_depth=ctor.get("mlp_net_depth", 8), skip_index=ctor.get("mlp_skip_index", 4))
     rays = orc.synthetic_rays(batch, seed=ray_seed, multiscale=True)
     R = to_ref_rays(rays)
     params = orc.make_params(seed=param_seed, density_gain=gain, **arch)
@@ -183,7 +185,7 @@ def variant_case(name, batch, num_samples, param_seed, gain, ray_seed, **ctor):
     loss.backward()
     out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain, gt=gt,
                loss=np.float32(loss.item()), net_width=arch["net_width"], net_width_condition=arch["net_width_condition"],
-               use_viewdirs=int(ctor.get("use_viewdirs", True)))
+               net_depth=arch["net_depth"], skip_index=arch["skip_index"], use_viewdirs=int(ctor.get("use_viewdirs", True)))
     out.update(ret_dict(ret, prefix="wb1_"))
     for k, p in model.named_parameters():
         g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().ravel()
@@ -192,7 +194,8 @@ def variant_case(name, batch, num_samples, param_seed, gain, ray_seed, **ctor):
         out["g_l2_" + key] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
         out["g_sum_" + key] = np.float64(g.astype(np.float64).sum())
         out["g_smp_" + key] = g[::stride][:64].copy()
-    oret = orc.mipnerf_forward(params, rays, False, True, num_samples=num_samples, use_viewdirs=ctor.get("use_viewdirs", True))
+    oret = orc.mipnerf_forward(params, rays, False, True, num_samples=num_samples, use_viewdirs=ctor.get("use_viewdirs", True),
+                               net_depth=arch["net_depth"], skip_index=arch["skip_index"])
     check_oracle(name, ret, oret, 2e-4)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"wrote {name}.npz loss={loss.item():.6f}")
@@ -651,6 +654,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-grad-options" in sys.argv:   # round 2: training step with the other boundary settings
         grad_options_case("train_options_40x64", 40, 64, 6, 40.0, 31, 77)
+        sys.exit(0)
+    if "--only-variant-depth" in sys.argv:  # round 2: another depth / skip period (20 parameter tensors)
+        variant_case("var_d6s3_48x64", 48, 64, 9, 40.0, 19, mlp_net_depth=6, mlp_skip_index=3)
         sys.exit(0)
     if "--only-variants" in sys.argv:       # round 2: other reference-legal MLP shapes
         variant_case("var_w128_48x64", 48, 64, param_seed=12, gain=20.0, ray_seed=12, mlp_net_width=128, mlp_net_width_condition=128)
