@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--torch-adam", action="store_true", help="train: torch.optim.Adam on per-tensor gradients "
                     "(what the reference configures) instead of the fused flat Adam kernel")
     ap.add_argument("--no-graph", action="store_true", help="render / train: eager launches instead of the captured hipGraph")
+    ap.add_argument("--ceiling-seconds", type=float, default=1.2, help="all / inference at N=1: seconds per variant of the in-process MFMA "
+                    "ceiling measurement (0 = skip)")
+    ap.add_argument("--no-fp32", action="store_true", help="all: skip the fp32 configs[3] sub-record")
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="inference: extra steps after the timed region")
     ap.add_argument("--host-rays", action="store_true", help="inference: the 52 B/ray batch comes from pinned host memory every step "
                     "(what the reference's DataLoader hands over): the PCIe-inclusive rate quoted in DESIGN.md, never `value` of the default line")
@@ -98,11 +101,21 @@ def setup(args):
         # "nccl" is RCCL on ROCm; the override exists only for the shared-GPU plumbing test (RCCL refuses two ranks per GPU)
         dist.init_process_group(os.environ.get("MIPNERF_BENCH_BACKEND", "nccl"), rank=e.rank, world_size=e.world)
         assert dist.get_world_size() == args.gpus
+    elif os.environ.get("MIPNERF_FORCE_COLLECTIVE_PATH") == "1":
+        # a 1-rank RCCL communicator: the training record then runs graph A -> all_reduce -> graph B like every world > 1 run
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
+        dist.init_process_group(os.environ.get("MIPNERF_BENCH_BACKEND", "nccl"), rank=0, world_size=1)
     return e
 
 
-def timed(e, step, warmup, steps):
-    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks (seconds)."""
+def timed(e, step, warmup, steps, return_local=False):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks (seconds).
+    return_local: also this rank's own elapsed time, stopped after its OWN synchronize, before the closing barrier."""
     import torch
     import torch.distributed as dist
 
@@ -117,12 +130,17 @@ def timed(e, step, warmup, steps):
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
+    if return_local:
+        torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     if e.world > 1:
         tt = torch.tensor([dt], device=e.dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    if return_local:
+        return dt, out, dt_local
     return dt, out
 
 
@@ -246,6 +264,7 @@ def run_train(args, e):
         # captured hipGraph(s); MipLRDecay runs on the device, the scheduler object only mirrors the epoch on the host
         from mipnerf_pl_amd.train_graph import GraphedTrainStep
         gstep = GraphedTrainStep(system, opt, B, e.dev, use_graph=not args.no_graph)
+        gstep.time_allreduce = gstep.collective
         for dst, src in zip(gstep.rays, R):
             dst.copy_(src)
         gstep.gt.copy_(gt)
@@ -267,11 +286,30 @@ def run_train(args, e):
             sch["scheduler"].step()
             return [(loss.detach().reshape(1),)]
     step()
-    dt, out = timed(e, step, args.warmup, args.steps)
+    if graphed:
+        gstep.allreduce_stats()                              # drop the events of the first (capturing) step
+    dt, out, dt_local = timed(e, step, args.warmup, args.steps, return_local=True)
     assert bool(torch.isfinite(out[-1][0]).all())
     samples_per_step = B * N * model.num_levels
     value = samples_per_step * e.world * args.steps / dt
     ms = dt / args.steps * 1e3
+    # per-rank step time (each rank's own clock between the same two barriers) and the gradient all-reduce as the launch stream
+    # sees it (HIP events around all_reduce + wait): what a first multi-GPU run needs to explain itself
+    per_rank = {"ms_per_step_min": round(dt_local / args.steps * 1e3, 4), "ms_per_step_max": round(dt_local / args.steps * 1e3, 4)}
+    ar_ms, ar_n = (gstep.allreduce_stats() if graphed else (None, 0))
+    if e.world > 1:
+        import torch.distributed as dist
+        lo = torch.tensor([dt_local], device=e.dev, dtype=torch.float64)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        per_rank = {"ms_per_step_min": round(float(lo) / args.steps * 1e3, 4), "ms_per_step_max": round(float(hi) / args.steps * 1e3, 4)}
+        if ar_ms is not None:
+            am = torch.tensor([ar_ms], device=e.dev, dtype=torch.float64)
+            dist.all_reduce(am, op=dist.ReduceOp.MAX)
+            ar_ms = float(am)
+    per_rank["allreduce_ms"] = None if ar_ms is None else round(ar_ms, 4)
+    per_rank["allreduce_timed"] = ar_n
     peak = PEAK_TFLOPS[args.precision]
     tflops = FLOP_PER_SAMPLE_TRAIN * samples_per_step / (ms * 1e-3) / 1e12
     traffic, tsrc = None, None
@@ -284,12 +322,16 @@ def run_train(args, e):
                 "traffic_source": tsrc,
                 "flop_per_sample": FLOP_PER_SAMPLE_TRAIN, "samples_per_step": samples_per_step}
     rec = {"value": round(value, 1), "ms_per_step": round(ms, 4), "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
-           "roofline": roofline,
+           "roofline": roofline, "ranks": per_rank,
            "config": {"workload": (f"training step (randomized forward + loss incl. distloss + backward + one flat gradient all-reduce + "
                                    f"Adam + MipLRDecay), {B} rays x ({N}+{N}) samples per GPU"),
                       "mode": "train", "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
                       "native_step": native, "fused_adam": bool(system.fused_adam),
-                      "hip_graph": bool(graphed and not args.no_graph), "lr_schedule": "device" if graphed else "host",
+                      "hip_graph": bool(graphed and gstep.use_graph),          # what actually ran (a failed capture falls back)
+                      "hip_graph_requested": bool(graphed and not args.no_graph),
+                      "hip_graph_capture_error": gstep.capture_error if graphed else None,
+                      "collective_path": bool(graphed and gstep.collective),
+                      "lr_schedule": "device" if graphed else "host",
                       "parallelism": f"data-parallel x{e.world}, one {4 * sum(p.numel() for p in model.parameters())} B all-reduce per step"}}
     return rec
 
@@ -342,6 +384,67 @@ def run_render(args, e):
     return rec
 
 
+def run_ceiling(args, e):
+    """What an MFMA stream sustains on THIS chip, in THIS process (VERDICT r02 #2a): back-to-back v_mfma_f32_32x32x16_bf16 on
+    MLP-like random operands, 2 waves per SIMD, with the operands in registers and with one LDS weight-fragment read per MFMA
+    (what k_mlp_bf16 does); each variant runs >= 1 s (first half heat-up).  The datasheet's 2.5 PFLOP/s assumes 2.4 GHz."""
+    import ctypes as C
+    import torch
+    from mipnerf_pl_amd import _lib as L
+    out = {"unit": "TFLOP/s", "operands": "weights U(-0.1,0.1), activations relu(N(0,1)), bf16", "waves_per_simd": 2,
+           "seconds_per_variant": args.ceiling_seconds, "peak": PEAK_TFLOPS["bf16"], "variants": []}
+    st = torch.cuda.current_stream().cuda_stream
+    for lds in (0, 1):
+        r = (C.c_double * 3)()
+        L.check(L.lib().mipnerf_mfma_ceiling(lds, 2, 1, float(args.ceiling_seconds), r, st), "mfma_ceiling")
+        out["variants"].append({"lds_weight_reads_per_mfma": lds, "tflops": round(r[0], 1), "frac_of_peak": round(r[0] / PEAK_TFLOPS["bf16"], 4),
+                                "ms_per_launch": round(r[1], 4), "effective_clock_ghz": round(r[2], 3)})
+    out["register_fed"] = out["variants"][0]["frac_of_peak"]
+    out["lds_fed"] = out["variants"][1]["frac_of_peak"]
+    return out
+
+
+def run_fp32_c4(args, e):
+    """BASELINE.json configs[3]-shaped forward in fp32 parity mode: 8192 rays x (256 + 256) samples, per-ray near / far, exact-fp32
+    MFMA (v_mfma_f32_32x32x2_f32) -- so the driver's record carries the fp32 kernel's roofline too (VERDICT r02 #2b)."""
+    import torch
+    import synthetic_inputs as syn
+    from mipnerf_pl_amd import MipNerf, Rays
+    B, N = 8192, 256
+    rays_np = syn.synthetic_rays(B, seed=100 + e.rank, unbounded=True)
+    params = syn.make_params(seed=0, density_gain=40.0)
+    model = MipNerf(num_samples=N, precision="fp32")
+    model.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model = model.to(e.dev)
+    R = Rays(*[torch.from_numpy(a).to(e.dev) for a in rays_np])
+
+    def step():
+        with torch.no_grad():
+            return model(R, False, True)
+    step()
+    ctx = model.mlp.native(e.dev)
+    steps, warm = max(3, args.steps // 10), 1
+    for _ in range(warm):
+        step()
+    ctx.set_option(2, 1)
+    dt, out = timed(e, step, 0, steps)
+    tot_ms, nl = launch_stats(ctx)
+    ctx.set_option(2, 0)
+    assert bool(torch.isfinite(out[-1][0]).all())
+    M = B * N
+    launch_ms = tot_ms / max(nl, 1)
+    tflops = FLOP_PER_SAMPLE * M / (launch_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS["fp32"]
+    return {"value": round(B * N * 2 * e.world * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warm,
+            "scaling": "weak", "dtype": "fp32",
+            "roofline": {"bound": "mfma", "kernel": "k_mlp_f32", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(tflops / peak, 4), "traffic": None, "launch_ms": round(launch_ms, 4), "launches_timed": nl,
+                         "samples_per_launch": M, "flop_per_sample": FLOP_PER_SAMPLE},
+            "config": {"workload": (f"BASELINE.json configs[3] shape: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) samples per GPU, "
+                                    f"per-ray near/far, fp32 parity mode"), "mode": "fp32", "rays_per_gpu": B, "samples_per_level": N,
+                       "parallelism": f"ray-split x{e.world} (no data-path collective)"}}
+
+
 def cpu_baseline(args, rays_np, params):
     """The reference's own CPU path on this host (rank 0, N=1): MipNerf.forward of the staged reference (oracle/_ref) under
     no_grad, fp32, all host cores, on the FULL headline batch; falls back to the numpy port on a 256-ray sample."""
@@ -367,19 +470,24 @@ def cpu_baseline(args, rays_np, params):
         with torch.no_grad():
             # torch's CPU ops stop scaling long before 256 hardware threads (measured on the 2x64-core EPYC host: 32 threads
             # 2.2e5 ray-samples/s, 256 threads 1.2e4): give the reference the thread count that is FASTEST for it here
-            sub = r.Rays(*[x[:512] for x in RR])
-            best, best_t = None, None
+            # the count is chosen on the FULL batch (a 512-ray probe picked 8 threads on one box where 16-32 are 20 % faster on
+            # 4096 rays): one forward per candidate, ascending, stop at the first that is slower
+            torch.set_num_threads(min(16, os.cpu_count()))
+            model(RR, False, True)                                   # warm-up on the full batch (pages, allocator)
+            best, best_t, probe = None, None, {}
             for th in sorted({t for t in (8, 16, 32, 64, os.cpu_count()) if t <= os.cpu_count()}):
                 torch.set_num_threads(th)
-                model(sub, False, True)
                 c0 = time.perf_counter()
-                model(sub, False, True)
+                model(RR, False, True)
                 dt_ = time.perf_counter() - c0
+                probe[th] = round(dt_, 3)
                 if best_t is None or dt_ < best_t:
                     best, best_t = th, dt_
+                elif dt_ > 1.05 * best_t:
+                    break
             torch.set_num_threads(best)
-            model(RR, False, True)                                   # warm-up on the full batch
-            for _ in range(3):
+            ts.append(best_t)
+            for _ in range(2):
                 c0 = time.perf_counter()
                 model(RR, False, True)
                 ts.append(time.perf_counter() - c0)
@@ -387,7 +495,8 @@ def cpu_baseline(args, rays_np, params):
         return {"value": round(B * N * 2 / med, 1), "unit": "ray-samples/s", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(),
                 "kind": "reference", "cpu": cpu, "seconds_per_forward": round(med, 3),
                 "sample": f"median of 3 x the reference's MipNerf.forward (oracle/_ref, torch {torch.__version__} CPU, fp32, no_grad, "
-                          f"{torch.get_num_threads()} threads = the fastest of 8/16/32/64/all on this host) on the full {B} rays x {N} samples x 2 levels batch"}
+                          f"{torch.get_num_threads()} threads = the fastest on the full batch, seconds per forward by thread count: {probe}) on the full "
+                          f"{B} rays x {N} samples x 2 levels batch"}
     from oracle import mipnerf_oracle as orc
     nb = 256
     sub = orc.Rays(*[a[:nb] for a in rays_np])
@@ -467,6 +576,14 @@ def main():
         recs["train"] = sub("train", run_train)
     if args.mode in ("all", "render"):
         recs["render"] = sub("render", run_render)
+    if args.mode == "all" and not args.no_fp32 and args.precision == "bf16":
+        recs["fp32"] = sub("fp32", run_fp32_c4)
+    ceiling = None
+    if args.mode in ("all", "inference") and args.precision == "bf16" and e.world == 1 and args.ceiling_seconds > 0:
+        try:
+            ceiling = run_ceiling(args, e)
+        except Exception as ex:  # noqa: BLE001  (a diagnostic must not take the line down)
+            ceiling = {"error": f"{type(ex).__name__}: {ex}"}
     head_mode = "inference" if "inference" in recs else args.mode
     head = recs.pop(head_mode)
     cpu = None
@@ -485,6 +602,10 @@ def main():
                 "cpu_baseline": cpu}
         if head.get("sustained") is not None:
             line["sustained"] = head["sustained"]
+        if ceiling is not None:
+            line["ceiling"] = ceiling
+            if line.get("roofline") and "lds_fed" in ceiling and ceiling["lds_fed"] > 0:
+                line["roofline"]["frac_of_measured_lds_fed_ceiling"] = round(line["roofline"]["frac"] / ceiling["lds_fed"], 4)
         for k, r in recs.items():
             r.update({"metric": "ray-samples/sec", "unit": "ray-samples/s", "n_gpus": e.world, "per_gpu": round(r["value"] / e.world, 1)})
             line[k] = r

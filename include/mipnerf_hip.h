@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MIPNERF_ABI_VERSION 3
+#define MIPNERF_ABI_VERSION 4
 
 enum {
     MIPNERF_OK = 0,
@@ -296,9 +296,10 @@ int mipnerf_mlp_dgrad(mipnerf_ctx* ctx, int64_t num_points, const float* d_raw, 
 int mipnerf_mlp_wgrad(mipnerf_ctx* ctx, int64_t num_points, const void* act, const void* delta,
                       float* partials, float* grad_flat, int32_t accumulate, void* stream);
 /* torch.optim.Adam.step() of nerf_system.py:71-72 (betas, eps as given; no weight decay / amsgrad) over ONE flat
- * buffer of n parameters: param, grad, exp_avg, exp_avg_sq [n] fp32; `step` = 1-based step count. */
+ * buffer of n parameters: param, grad, exp_avg, exp_avg_sq [n] fp32; `step` = 1-based step count.  The hyper-parameters are the
+ * doubles torch holds (ABI 4; floats before): bias corrections, lr / (1 - beta1^t) and 1 - beta are formed in double. */
 int mipnerf_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                      float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+                      double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
 /* Tuning: workgroups per weight-gradient job (HOST array, 14 entries for the compiled MLP; 0 skips a job, for
  * timing only).  NULL restores the default.  Changes partial_bytes of mipnerf_mlp_train_sizes; synchronises. */
 int mipnerf_set_wgrad_splits(mipnerf_ctx* ctx, const int32_t* splits_host);
@@ -371,6 +372,20 @@ int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
 /* Sum of the elapsed times (ms) and the number of MLP launches recorded since the last call
  * (option 2); synchronises on the recorded events. */
 int mipnerf_mlp_launch_stats(mipnerf_ctx* ctx, double* total_ms, int64_t* launches);
+/* What a back-to-back v_mfma_f32_32x32x16_bf16 stream sustains on THIS chip (the ceiling k_mlp_bf16's roofline fraction is
+ * read against): 256 workgroups of waves_per_simd x 4 waves, register-resident operands (lds_reads_per_mfma = 0) or one
+ * ds_read_b128 weight fragment per MFMA as in k_mlp_bf16 (1); operands all zero or MLP-like random (weights U(-0.1,0.1),
+ * activations relu(N(0,1))).  Runs for `seconds` (first half un-measured heat-up).  out3 = {TFLOP/s, ms per launch,
+ * shader clock in GHz implied by the MFMA issue rate}.  Diagnostic: allocates and synchronises. */
+int mipnerf_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_operands, double seconds, double* out3,
+                         void* stream);
+/* CU -> CU hand-off probe: 128 producer workgroups stream `tiles` tiles of tile_bytes each to 128 consumer workgroups through
+ * `ring`-slot rings in global memory with counter flags (producer and consumer on the same XCD or on neighbouring XCDs;
+ * store_flavour 0 = plain stores + agent release, 1 = write-through sc1 stores), mfma_per_wave register-only MFMAs per tile
+ * on both sides, every word verified.  out6 = {aggregate GB/s, ms, producer stall fraction, consumer stall fraction,
+ * mismatching 16-B words, 1 if a bounded poll timed out}.  Diagnostic: allocates and synchronises. */
+int mipnerf_handoff_probe(int same_xcd, int store_flavour, int tiles, int ring, int tile_bytes, int mfma_per_wave, int reps,
+                          double* out6, void* stream);
 /* Host-only exports of the static plan tables (no GPU needed), used by the CPU tests to
  * prove the C++ plan expansion equals mipnerf_pl_amd/mlp_plan.py.  which: 0 = bf16 stream
  * pack table, 1 = bias table, 2 = fp32 stream pack table (flat parameter indices, -1 = 0),

@@ -82,7 +82,7 @@ SIGNATURES = {
     "mipnerf_mlp_train_sizes": (C.c_int, [_P, _I64, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ)]),
     "mipnerf_mlp_forward_train": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "mipnerf_mlp_backward": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _P]),
-    "mipnerf_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, _F, _F, _F, _F, _I32, _P]),
+    "mipnerf_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, _I32, _P]),
     "mipnerf_adam_step_scheduled": (C.c_int, [_I64, _P, _P, _P, _P, C.POINTER(LrSchedule), _P, _P, _P]),
     "mipnerf_mlp_dgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P]),
     "mipnerf_mlp_wgrad": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I32, _P]),
@@ -98,6 +98,8 @@ SIGNATURES = {
     "mipnerf_selftest": (C.c_int, [_P]),
     "mipnerf_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
     "mipnerf_mlp_launch_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
+    "mipnerf_mfma_ceiling": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), _P]),
+    "mipnerf_handoff_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     "mipnerf_debug_table": (_I64, [C.c_int, _P, _I64]),
     "mipnerf_debug_table_variant": (_I64, [C.c_int, C.c_int, _P, _I64]),
     "mipnerf_debug_f32net": (_I64, [_P, _I64]),

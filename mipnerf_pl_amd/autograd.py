@@ -231,6 +231,22 @@ class _CastIPE(torch.autograd.Function):
         return d_t, None, None, None, None, None, None
 
 
+class _CastRaysNoBackward(torch.autograd.Function):
+    """cast_rays(t) of ops.resample_along_rays(stop_grad=False): forward only.  A gradient arriving here means the caller
+    differentiates means / covs w.r.t. the resampled t outside MipNerf (which routes that link through _CastIPE)."""
+
+    @staticmethod
+    def forward(ctx, t, origins, directions, radii, ray_shape):
+        from . import ops
+        means, covs = ops.cast_rays(t.detach(), origins, directions, radii, ray_shape)
+        return means, covs
+
+    @staticmethod
+    def backward(ctx, g_means, g_covs):
+        raise NotImplementedError("gradient of cast_rays w.r.t. the resampled t_samples: use ops.cast_ipe / MipNerf "
+                                  "(stop_resample_grad=False, fp32), whose fused cast_rays + integrated_pos_enc has a native backward")
+
+
 class _ResampleT(torch.autograd.Function):
     """The t part of resample_along_rays (mip.py:232-280: blur pool, padding, sorted_piecewise_constant_pdf), differentiable
     w.r.t. the coarse weights (stop_grad=False branch, mip.py:265-279)."""

@@ -228,7 +228,6 @@ struct mipnerf_ctx {
     int fused_ipe = 1;               // bf16 mipnerf_forward: IPE computed inside the MLP kernel (0: k_cast_ipe + enc buffer)
     int grid_limit = 256;            // persistent workgroups of the bf16 MLP kernel (= CUs)
     // optional instrumentation: HIP events around every MLP launch made by mipnerf_forward
-    const float* dnoise = nullptr;   // density noise draws of the level being evaluated (set by mipnerf_forward / _train_step only)
     int time_mlp = 0;
     std::vector<hipEvent_t> ev;      // pairs (start, stop)
     size_t ev_used = 0;
@@ -237,19 +236,21 @@ struct mipnerf_ctx {
 namespace {
 // the bf16 inference kernel generated for this context's architecture variant
 hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* viewenc, float* rgb_sigma, float* raw, int64_t M, int N,
-                               bool dma, const mip::RayInputs* rays, hipStream_t st) {
+                               bool dma, const mip::RayInputs* rays, const float* dnoise, hipStream_t st) {
+    // dnoise: density-noise draws of the level being evaluated, an ARGUMENT (not context state): two host threads / streams
+    // driving the same context cannot see each other's pointer
     return mip::kLaunchBf16[c->P->variant](c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
-                                c->grid_limit, dma, rays, c->dnoise, c->cfg.density_noise, st);
+                                c->grid_limit, dma, rays, dnoise, c->cfg.density_noise, st);
 }
 
 // ... and its training kernels (variants whose row of the generated kLaunchTrainFwd table is not null)
 static inline bool has_bf16_train(const PlanDesc* P) { return mip::kLaunchTrainFwd[P->variant] != nullptr; }
 hipError_t launch_trainfwd_variant(mipnerf_ctx* c, const void* enc, const void* viewenc, float* rgb_sigma, float* raw, void* act,
-                                   void* masks, int64_t M, int N, const mip::RayInputs* rays, hipStream_t st) {
+                                   void* masks, int64_t M, int N, const mip::RayInputs* rays, const float* dnoise, hipStream_t st) {
     const mip::LaunchTrainFwdFn fn = mip::kLaunchTrainFwd[c->P->variant];
     if (!fn) return hipErrorInvalidValue;
     return fn(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, act, masks, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
-              c->grid_limit, rays, c->dnoise, c->cfg.density_noise, st);
+              c->grid_limit, rays, dnoise, c->cfg.density_noise, st);
 }
 hipError_t launch_dgrad_variant(mipnerf_ctx* c, const float* d_raw, const void* masks, void* delta, int64_t M, hipStream_t st) {
     const mip::LaunchDgradFn fn = mip::kLaunchDgrad[c->P->variant];
@@ -501,15 +502,23 @@ int mipnerf_pos_enc(int64_t B, int32_t deg, const float* viewdirs, void* out, in
     return MIPNERF_OK;
 }
 
+static int mlp_forward_noise(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, int precision,
+                             float* rgb_sigma, float* raw, const float* dnoise, void* stream);
+
 int mipnerf_mlp_forward(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, int precision,
                         float* rgb_sigma, float* raw, void* stream) {
+    return mlp_forward_noise(c, M, N, enc, viewenc, precision, rgb_sigma, raw, nullptr, stream);
+}
+
+static int mlp_forward_noise(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, int precision,
+                             float* rgb_sigma, float* raw, const float* dnoise, void* stream) {
     if (!c || M < 1 || N < 1 || !enc || !viewenc || !rgb_sigma) return fail(MIPNERF_E_INVALID, "mlp_forward: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward: mipnerf_set_params has not been called");
     if (precision == MIPNERF_PREC_BF16) {
-        HIP_TRY(launch_bf16_variant(c, enc, viewenc, rgb_sigma, raw, M, N, c->mlp_dma != 0, nullptr, S(stream)));
+        HIP_TRY(launch_bf16_variant(c, enc, viewenc, rgb_sigma, raw, M, N, c->mlp_dma != 0, nullptr, dnoise, S(stream)));
     } else if (precision == MIPNERF_PREC_FP32) {
         HIP_TRY(mip::launch_mlp_f32(f32net_with_heads(c), c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
-                                    rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, nullptr, c->dnoise,
+                                    rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, nullptr, dnoise,
                                     c->cfg.density_noise, S(stream)));
     } else {
         return fail(MIPNERF_E_INVALID, "unknown precision %d", precision);
@@ -668,14 +677,19 @@ int mipnerf_mlp_train_sizes(const mipnerf_ctx* c, int64_t M, size_t* act_bytes, 
     return MIPNERF_OK;
 }
 
-int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, float* rgb_sigma,
-                              float* raw, void* act, void* masks, void* stream) {
+static int mlp_forward_train_noise(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, float* rgb_sigma,
+                                   float* raw, void* act, void* masks, const float* dnoise, void* stream) {
     if (!c || M < 1 || N < 1 || !enc || !viewenc || !rgb_sigma || !raw || !act || !masks)
         return fail(MIPNERF_E_INVALID, "mlp_forward_train: bad argument");
     NEED_BF16_TRAIN("mlp_forward_train");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train: mipnerf_set_params has not been called");
-    HIP_TRY(launch_trainfwd_variant(c, enc, viewenc, rgb_sigma, raw, act, masks, M, N, nullptr, S(stream)));
+    HIP_TRY(launch_trainfwd_variant(c, enc, viewenc, rgb_sigma, raw, act, masks, M, N, nullptr, dnoise, S(stream)));
     return MIPNERF_OK;
+}
+
+int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, float* rgb_sigma,
+                              float* raw, void* act, void* masks, void* stream) {
+    return mlp_forward_train_noise(c, M, N, enc, viewenc, rgb_sigma, raw, act, masks, nullptr, stream);
 }
 
 int mipnerf_mlp_dgrad(mipnerf_ctx* c, int64_t M, const float* d_raw, const void* masks, void* delta, void* stream) {
@@ -742,8 +756,8 @@ int mipnerf_mlp_backward(mipnerf_ctx* c, int64_t M, const float* d_raw, const vo
     return mipnerf_mlp_wgrad(c, M, act, delta, partials, grad_flat, accumulate, stream);
 }
 
-int mipnerf_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                      float beta2, float eps, int32_t step, void* stream) {
+int mipnerf_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                      double beta2, double eps, int32_t step, void* stream) {
     if (n < 1 || !param || !grad || !exp_avg || !exp_avg_sq || step < 1) return fail(MIPNERF_E_INVALID, "adam_step: bad argument");
     HIP_TRY(mip::launch_adam_flat(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, S(stream)));
     return MIPNERF_OK;
@@ -1013,12 +1027,8 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
     // ---- forward (mip_nerf.py:182-246), activations saved for the backward -------------------------------------------
     if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, MIPNERF_PREC_BF16, stream))) return rc;
-    struct NoiseScope {            // the per-level noise pointer is visible to the MLP launches of THIS call only
-        mipnerf_ctx* c;
-        ~NoiseScope() { c->dnoise = nullptr; }
-    } noise_scope{c};
     for (int l = 0; l < L; ++l) {
-        c->dnoise = density_randn ? density_randn + (size_t)l * M : nullptr;
+        const float* dnoise = density_randn ? density_randn + (size_t)l * M : nullptr;      // this level's draws (mip_nerf.py:232-233)
         if (l == 0) {
             if ((rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, lv[0].t, stream))) return rc;
         } else {
@@ -1028,12 +1038,12 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
             const mip::RayInputs ri = {lv[l].t, rays->origins, rays->directions, rays->radii, cfg.min_deg_point,
                                        cfg.disable_integration};
             HIP_TRY(launch_trainfwd_variant(c, nullptr, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act, lv[l].masks, (int64_t)M, N, &ri,
-                                            S(stream)));
+                                            dnoise, S(stream)));
         } else {
             if ((rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, lv[l].t, rays->origins,
                                        rays->directions, rays->radii, lv[l].enc, MIPNERF_PREC_BF16, stream))) return rc;
-            if ((rc = mipnerf_mlp_forward_train(c, (int64_t)M, N, lv[l].enc, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act,
-                                                lv[l].masks, stream))) return rc;
+            if ((rc = mlp_forward_train_noise(c, (int64_t)M, N, lv[l].enc, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act,
+                                              lv[l].masks, dnoise, stream))) return rc;
         }
         if ((rc = mipnerf_volumetric_rendering(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].rgb, lv[l].dist,
                                                lv[l].acc, lv[l].w, stream))) return rc;
@@ -1099,12 +1109,8 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
     int rc;
     // pos_enc(viewdirs) is level-independent: computed once (the reference recomputes it, mip_nerf.py:220-226)
     if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, precision, stream))) return rc;
-    struct NoiseScope {
-        mipnerf_ctx* c;
-        ~NoiseScope() { c->dnoise = nullptr; }
-    } noise_scope{c};
     for (int lvl = 0; lvl < cfg.num_levels; ++lvl) {
-        c->dnoise = density_randn ? density_randn + (size_t)lvl * M : nullptr;
+        const float* dnoise = density_randn ? density_randn + (size_t)lvl * M : nullptr;    // this level's draws (mip_nerf.py:232-233)
         const mipnerf_level_out& o = out[lvl];
         if (!o.comp_rgb || !o.distance || !o.acc || !o.weights || !o.t_samples)
             return fail(MIPNERF_E_INVALID, "forward: output pointer of level %d is null", lvl);
@@ -1131,8 +1137,8 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
                 return fail(MIPNERF_E_UNSUPPORTED, "fused IPE is generated for max_deg-min_deg == 16");
             const mip::RayInputs ri = {o.t_samples, rays->origins, rays->directions, rays->radii, cfg.min_deg_point,
                                        cfg.disable_integration};
-            HIP_TRY(launch_bf16_variant(c, nullptr, viewenc, rgb_sigma, nullptr, (int64_t)M, N, true, &ri, S(stream)));
-        } else if ((rc = mipnerf_mlp_forward(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, stream))) {
+            HIP_TRY(launch_bf16_variant(c, nullptr, viewenc, rgb_sigma, nullptr, (int64_t)M, N, true, &ri, dnoise, S(stream)));
+        } else if ((rc = mlp_forward_noise(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, dnoise, stream))) {
             return rc;
         }
         if (c->time_mlp == 1) HIP_TRY(hipEventRecord(e1, S(stream)));
@@ -1185,6 +1191,26 @@ int mipnerf_selftest(void* stream) {
     g_err = msg;
     if (bad < 0) return MIPNERF_E_HIP;
     return bad == 0 ? MIPNERF_OK : (0x100 | bad);
+}
+
+int mipnerf_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_operands, double seconds, double* out3, void* stream) {
+    if (!out3 || waves_per_simd < 1 || waves_per_simd > 2 || lds_reads_per_mfma < 0 || lds_reads_per_mfma > 1 || !(seconds > 0) || seconds > 30)
+        return fail(MIPNERF_E_INVALID, "mfma_ceiling: waves_per_simd in {1,2}, lds_reads_per_mfma in {0,1}, 0 < seconds <= 30");
+    char msg[256];
+    const int rc = mip::run_mfma_ceiling(lds_reads_per_mfma, waves_per_simd, random_operands, seconds, out3, out3 + 1, out3 + 2, S(stream), msg, sizeof msg);
+    g_err = msg;
+    return rc == 0 ? MIPNERF_OK : MIPNERF_E_HIP;
+}
+
+int mipnerf_handoff_probe(int same_xcd, int store_flavour, int tiles, int ring, int tile_bytes, int mfma_per_wave, int reps, double* out6,
+                          void* stream) {
+    if (!out6 || tiles < 1 || tiles > (1 << 16) || ring < 1 || ring > 64 || tile_bytes < 65536 || tile_bytes > (1 << 22) || reps < 1 || reps > 16 ||
+        mfma_per_wave < 0 || mfma_per_wave > 4096 || (long long)ring * tile_bytes * 128 > (4ll << 30))
+        return fail(MIPNERF_E_INVALID, "handoff_probe: argument out of range");
+    char msg[256];
+    const int rc = mip::run_handoff_probe(same_xcd, store_flavour, tiles, ring, tile_bytes, mfma_per_wave, reps, out6, S(stream), msg, sizeof msg);
+    g_err = msg;
+    return rc == 0 ? MIPNERF_OK : (rc == -2 ? MIPNERF_E_INVALID : MIPNERF_E_HIP);
 }
 
 // Host-only debug export of the plan tables (flat parameter indices), used by the CPU tests to prove the

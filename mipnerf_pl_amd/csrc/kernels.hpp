@@ -61,8 +61,8 @@ hipError_t launch_loss_fused(int64_t B, int nlevels, const float* rgb0, const fl
                              const float* ray_loss0, const float* ray_loss1, float coarse_mult, float dist_mult, float* g_rgb0,
                              float* g_rgb1, float* out, hipStream_t st);
 
-hipError_t launch_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
-                            float eps, int step, hipStream_t st);
+hipError_t launch_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, double lr, double beta1, double beta2,
+                            double eps, int step, hipStream_t st);
 
 struct LrSchedule {          // MipLRDecay (utils/lr_schedule.py:5-59) + Adam constants, evaluated on the device
     double lr_init, lr_final, lr_delay_mult, constant_lr;   // constant_lr > 0: no schedule
@@ -195,5 +195,11 @@ hipError_t launch_eval_errors(int H, int W, const float* pred, const float* gt, 
 // returns 0 if the MFMA fragment layouts and the LDS-DMA path behave as the kernels assume;
 // otherwise a bit mask (1: bf16 32x32x16 layout, 2: f32 32x32x2 layout, 4: global_load_lds)
 int run_selftest(hipStream_t st, char* msg, int msg_cap);
+
+// ---- kernels_diag.hip (diagnostics bench.py reports next to the headline; they allocate and synchronise) ---------------
+int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_operands, double seconds, double* tflops,
+                     double* ms_per_launch, double* clock_ghz, hipStream_t st, char* msg, int msg_cap);
+int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_bytes, int mfma_per_wave, int reps, double* out,
+                      hipStream_t st, char* msg, int msg_cap);
 
 }  // namespace mip

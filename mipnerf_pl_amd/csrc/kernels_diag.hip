@@ -1,0 +1,393 @@
+// Diagnostics that ship inside the product library so that bench.py can report them from the SAME process as the
+// headline (VERDICT r02 #2a): what a register-resident / LDS-fed v_mfma_f32_32x32x16_bf16 stream sustains on THIS
+// chip, on operands shaped like the MLP's (weights ~ U(-0.1, 0.1), activations = relu(N(0,1))).
+// The loop is the one of scripts/micro/mfma_peak.hip (round 2); no memory access inside it except, for lds = 1, one
+// conflict-free ds_read_b128 A fragment per MFMA -- exactly the operand traffic of k_mlp_bf16.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace mip {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kIters = 256;    // outer iterations per launch
+constexpr int kUnroll = 64;    // MFMAs per iteration
+
+template <int LDS>
+__global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__ a_src, const bf16x8* __restrict__ b_src,
+                                                     float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    bf16x8 A[8], B[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A[i] = a_src[(size_t)i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) B[i] = b_src[(size_t)i * 64 + lane];
+    if (LDS) {
+        for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) reinterpret_cast<bf16x8*>(smem)[i] = a_src[i];
+        __syncthreads();
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const char* lane_base = smem + lane * 16;
+    for (int it = 0; it < iters; ++it) {
+        const char* base = lane_base + (it & 1) * 32768;
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j) {
+            bf16x8 a;
+            if (LDS == 1) a = *reinterpret_cast<const bf16x8*>(base + (j & 31) * 1024);
+            else a = A[j & 7];
+            acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B[(j * 5) & 15], acc[j & 3], 0, 0, 0);
+        }
+        if ((it & 15) == 15) {      // keep the accumulators bounded (the MLP re-initialises them every 16-22 MFMAs)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= 1e-3f;
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFF + ((u >> 16) & 1);
+    return (uint16_t)(u >> 16);
+}
+
+// xorshift: the operand values must be the same on every box
+struct Rng {
+    uint64_t s;
+    float uni() {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+        return (float)((s >> 11) & 0xFFFFFF) / 16777216.0f;
+    }
+};
+
+}  // namespace
+
+// Returns 0 on success.  tflops: algorithmic 2*32*32*16 flop per MFMA over the measured half of `seconds`;
+// clock_ghz: the shader clock implied by the MFMA issue rate if the pipe never idles (32 cycles per MFMA per SIMD).
+int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_operands, double seconds, double* tflops,
+                     double* ms_per_launch, double* clock_ghz, hipStream_t st, char* msg, int msg_cap) {
+#define DG(x)                                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) { snprintf(msg, msg_cap, "%s: %s", #x, hipGetErrorString(e_)); return -1; } \
+    } while (0)
+    int dev = 0, cus = 0;
+    DG(hipGetDevice(&dev));
+    DG(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const size_t nA = 64 * 64 * 8, nB = 16 * 64 * 8;
+    std::vector<uint16_t> ha(nA, 0), hb(nB, 0);
+    if (random_operands) {
+        Rng r{0x9E3779B97F4A7C15ull};
+        for (size_t i = 0; i < nA; ++i) ha[i] = f2bf((r.uni() - 0.5f) * 0.2f);
+        for (size_t i = 0; i < nB; ++i) {
+            float g = 0;     // Irwin-Hall normal, then ReLU
+            for (int k = 0; k < 12; ++k) g += r.uni();
+            g -= 6.0f;
+            hb[i] = f2bf(g > 0 ? g : 0.0f);
+        }
+    }
+    bf16x8 *dA = nullptr, *dB = nullptr;
+    float* dOut = nullptr;
+    DG(hipMalloc(&dA, nA * 2));
+    DG(hipMalloc(&dB, nB * 2));
+    DG(hipMalloc(&dOut, (size_t)cus * 512 * 4));
+    DG(hipMemcpyAsync(dA, ha.data(), nA * 2, hipMemcpyHostToDevice, st));
+    DG(hipMemcpyAsync(dB, hb.data(), nB * 2, hipMemcpyHostToDevice, st));
+    DG(hipStreamSynchronize(st));
+    hipEvent_t e0, e1;
+    DG(hipEventCreate(&e0));
+    DG(hipEventCreate(&e1));
+    const int threads = 256 * waves_per_simd;
+    DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    auto launch = [&]() {
+        if (lds_reads_per_mfma) hipLaunchKernelGGL(k_mfma_ceiling<1>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters);
+        else hipLaunchKernelGGL(k_mfma_ceiling<0>, dim3(cus), dim3(threads), 0, st, dA, dB, dOut, kIters);
+    };
+    const double flop = 2.0 * 32 * 32 * 16 * (double)kUnroll * kIters * (threads / 64) * cus;
+    launch();
+    DG(hipStreamSynchronize(st));
+    const int batch = 20;
+    float ms = 0;
+    double elapsed = 0;
+    while (elapsed < seconds * 0.5) {         // heat-up half: the package settles on its power budget
+        DG(hipEventRecord(e0, st));
+        for (int i = 0; i < batch; ++i) launch();
+        DG(hipEventRecord(e1, st));
+        DG(hipEventSynchronize(e1));
+        DG(hipEventElapsedTime(&ms, e0, e1));
+        elapsed += ms * 1e-3;
+    }
+    double tot_ms = 0;
+    long launches = 0;
+    while (tot_ms < seconds * 500.0) {        // measured half
+        DG(hipEventRecord(e0, st));
+        for (int i = 0; i < batch; ++i) launch();
+        DG(hipEventRecord(e1, st));
+        DG(hipEventSynchronize(e1));
+        DG(hipEventElapsedTime(&ms, e0, e1));
+        tot_ms += ms;
+        launches += batch;
+    }
+    const double per = tot_ms / launches;
+    *ms_per_launch = per;
+    *tflops = flop / (per * 1e-3) / 1e12;
+    *clock_ghz = (double)kUnroll * kIters * 32.0 * waves_per_simd / (per * 1e-3) / 1e9;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(dA);
+    hipFree(dB);
+    hipFree(dOut);
+    snprintf(msg, msg_cap, "ok");
+    return 0;
+#undef DG
+}
+
+
+// ======================================================================================================================
+// CU -> CU hand-off probe (milestone 1): can sample tiles stream from one workgroup to another through
+// L2 / Infinity Cache fast enough for a layer-pipelined training backward (each CU group owns ONE layer; delta tiles of
+// 512 B/sample go group -> group instead of through HBM)?  128 producer workgroups each hand `tiles` tiles of
+// `tile_bytes` to one consumer workgroup through a ring of `ring` slots in global memory:
+//   producer: wait slot free (consumed counter) -> 16-B stores of a checkable pattern -> publish (ready counter)
+//   consumer: poll ready (one lane, relaxed sc1 load + s_sleep) -> agent acquire -> barrier -> 16-B loads, every word
+//             verified -> consumed counter
+// Placement: block b runs on XCD b % 8 (observed, MI355X_MICROARCH.md); same_xcd = 1 pairs b with b + 8 (same XCD),
+// 0 pairs 2p with 2p + 1 (neighbouring XCDs).  store flavour 0: plain stores + __syncthreads + lane-0 agent release fence
+// + vmcnt(0) + relaxed agent flag; 1: write-through (sc1) 16-B stores, every wave drains vmcnt, barrier, sc1 flag.
+// `mfma_per_wave` register-only MFMAs per wave and tile on BOTH sides stand for the layer's arithmetic (a 256-sample tile of
+// one 256x256 layer's dgrad + wgrad = 256 MFMAs per wave).  Every poll loop is bounded: on a timeout the launch sets an
+// abort word, every loop leaves, and the probe reports it -- a missing co-resident partner cannot hang the GPU.
+namespace {
+
+constexpr int kProbeThreads = 512;
+constexpr unsigned kMaxSpins = 1u << 21;
+
+__device__ __forceinline__ uint4 probe_pattern(unsigned pair, unsigned tile, unsigned idx) {
+    unsigned h = pair * 0x9E3779B1u ^ tile * 0x85EBCA77u ^ idx * 0xC2B2AE3Du;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return make_uint4(h, h ^ 0xA5A5A5A5u, h + idx, h - tile);
+}
+
+__device__ __forceinline__ unsigned load_flag(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // global_load_dword sc1: L2-served
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_sc1_x4(uint4* p, uint4 v) {
+    const u32x4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+}
+
+// lane 0 waits until *flag >= need (or abort); result broadcast through LDS.  Returns false on abort.
+__device__ __forceinline__ bool wait_counter(const unsigned* flag, unsigned need, unsigned* abort_word, int* lds_ok,
+                                             unsigned long long& stall_ticks) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        unsigned spins = 0;
+        int ok = 1;
+        while (load_flag(flag) < need) {
+            if (++spins > kMaxSpins || load_flag(abort_word) != 0) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        stall_ticks += __builtin_amdgcn_s_memtime() - t0;
+        *lds_ok = ok;
+    }
+    __syncthreads();
+    const bool ok = *lds_ok != 0;
+    __syncthreads();
+    return ok;
+}
+
+template <int FLAVOUR>
+__global__ void __launch_bounds__(kProbeThreads) k_handoff_probe(uint4* __restrict__ ring_mem, unsigned* __restrict__ ready,
+                                                                unsigned* __restrict__ consumed, unsigned* __restrict__ abort_word,
+                                                                unsigned long long* __restrict__ stall, unsigned* __restrict__ errors,
+                                                                int same_xcd, int tiles, int ring, int tile_vec, int mfma_per_wave,
+                                                                const bf16x8* __restrict__ ab_src, float* __restrict__ sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // only to force one workgroup per CU
+    __shared__ int lds_ok;
+    const int b = blockIdx.x;
+    int pair, is_consumer;
+    if (same_xcd) {
+        const int row = b >> 3, x = b & 7;          // row 0..31 within the XCD
+        pair = (row >> 1) * 8 + x;
+        is_consumer = row & 1;
+    } else {
+        pair = b >> 1;
+        is_consumer = b & 1;
+    }
+    uint4* slots = ring_mem + (size_t)pair * ring * tile_vec;
+    unsigned long long stall_ticks = 0;
+    unsigned bad = 0;
+    const int lane = threadIdx.x & 63;
+    bf16x8 A0 = ab_src[lane], B0 = ab_src[64 + lane];
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    const int per_thread = tile_vec / kProbeThreads;     // 16-B vectors per thread and tile (multiple of 8)
+    for (int t = 0; t < tiles; ++t) {
+        uint4* slot = slots + (size_t)(t % ring) * tile_vec;
+        if (!is_consumer) {
+            if (t >= ring && !wait_counter(&consumed[pair], (unsigned)(t - ring + 1), abort_word, &lds_ok, stall_ticks)) break;
+            for (int i = 0; i < per_thread; ++i) {
+                const unsigned idx = (unsigned)(i * kProbeThreads + threadIdx.x);
+                const uint4 v = probe_pattern((unsigned)pair, (unsigned)t, idx);
+                if (FLAVOUR == 1) store_sc1_x4(slot + idx, v);
+                else slot[idx] = v;
+            }
+            for (int m = 0; m < mfma_per_wave; m += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc1, 0, 0, 0);
+            }
+            if (FLAVOUR == 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_store(&ready[pair], (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&ready[pair], (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        } else {
+            if (!wait_counter(&ready[pair], (unsigned)(t + 1), abort_word, &lds_ok, stall_ticks)) break;
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            for (int i0 = 0; i0 < per_thread; i0 += 8) {
+                uint4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = slot[(size_t)(i0 + i) * kProbeThreads + threadIdx.x];
+                if (i0 == 0)
+                    for (int m = 0; m < mfma_per_wave; m += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc1, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint4 w = probe_pattern((unsigned)pair, (unsigned)t, (unsigned)((i0 + i) * kProbeThreads + threadIdx.x));
+                    bad += (v[i].x != w.x) | (v[i].y != w.y) | (v[i].z != w.z) | (v[i].w != w.w);
+                }
+            }
+            __syncthreads();      // every lane's loads have returned (they were compared)
+            if (threadIdx.x == 0) __hip_atomic_store(&consumed[pair], (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    if (s == 12345.678f) sink[b] = s;      // keeps the filler MFMAs alive
+    if (bad) atomicAdd(errors, bad);
+    if (threadIdx.x == 0) stall[b] = stall_ticks;
+    (void)smem;
+}
+
+}  // namespace
+
+// out[0] = aggregate GB/s handed off (payload bytes / kernel time), out[1] = ms, out[2] = mean producer stall fraction,
+// out[3] = mean consumer stall fraction, out[4] = mismatching 16-B words, out[5] = 1 if a poll timed out.
+int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_bytes, int mfma_per_wave, int reps, double* out,
+                      hipStream_t st, char* msg, int msg_cap) {
+#define DG(x)                                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) { snprintf(msg, msg_cap, "%s: %s", #x, hipGetErrorString(e_)); return -1; } \
+    } while (0)
+    int dev = 0, cus = 0;
+    DG(hipGetDevice(&dev));
+    DG(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus != 256) { snprintf(msg, msg_cap, "probe assumes 256 CUs in 8 XCDs, device has %d", cus); return -2; }
+    if (tile_bytes % (16 * kProbeThreads * 8) || ring < 1 || tiles < 1 || reps < 1) { snprintf(msg, msg_cap, "bad probe arguments"); return -2; }
+    const int pairs = 128, tile_vec = tile_bytes / 16;
+    uint4* ring_mem = nullptr;
+    unsigned *ready = nullptr, *consumed = nullptr, *abort_word = nullptr, *errors = nullptr;
+    unsigned long long* stall = nullptr;
+    bf16x8* ab = nullptr;
+    float* sink = nullptr;
+    DG(hipMalloc(&ring_mem, (size_t)pairs * ring * tile_bytes));
+    DG(hipMalloc(&ready, pairs * 4));
+    DG(hipMalloc(&consumed, pairs * 4));
+    DG(hipMalloc(&abort_word, 4));
+    DG(hipMalloc(&errors, 4));
+    DG(hipMalloc(&stall, 256 * 8));
+    DG(hipMalloc(&ab, 128 * 16));
+    DG(hipMalloc(&sink, 256 * 4));
+    std::vector<uint16_t> hab(128 * 8);
+    Rng r{0x1234567ull};
+    for (auto& x : hab) x = f2bf(r.uni() - 0.3f);
+    DG(hipMemcpyAsync(ab, hab.data(), 128 * 16, hipMemcpyHostToDevice, st));
+    DG(hipMemsetAsync(errors, 0, 4, st));
+    DG(hipMemsetAsync(abort_word, 0, 4, st));
+    const size_t lds = 96 * 1024;                 // > half of the CU's 160 KiB: one workgroup per CU
+    DG(hipFuncSetAttribute((const void*)k_handoff_probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DG(hipFuncSetAttribute((const void*)k_handoff_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    DG(hipEventCreate(&e0));
+    DG(hipEventCreate(&e1));
+    double best_ms = 1e30;
+    for (int rep = 0; rep < reps + 1; ++rep) {    // first repetition = warm-up
+        DG(hipMemsetAsync(ready, 0, pairs * 4, st));
+        DG(hipMemsetAsync(consumed, 0, pairs * 4, st));
+        DG(hipEventRecord(e0, st));
+        if (flavour) hipLaunchKernelGGL(k_handoff_probe<1>, dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word,
+                                        stall, errors, same_xcd, tiles, ring, tile_vec, mfma_per_wave, ab, sink);
+        else hipLaunchKernelGGL(k_handoff_probe<0>, dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word, stall,
+                                errors, same_xcd, tiles, ring, tile_vec, mfma_per_wave, ab, sink);
+        DG(hipEventRecord(e1, st));
+        DG(hipEventSynchronize(e1));
+        float ms = 0;
+        DG(hipEventElapsedTime(&ms, e0, e1));
+        if (rep > 0 && ms < best_ms) best_ms = ms;
+    }
+    unsigned h_err = 0, h_abort = 0;
+    std::vector<unsigned long long> h_stall(256);
+    DG(hipMemcpy(&h_err, errors, 4, hipMemcpyDeviceToHost));
+    DG(hipMemcpy(&h_abort, abort_word, 4, hipMemcpyDeviceToHost));
+    DG(hipMemcpy(h_stall.data(), stall, 256 * 8, hipMemcpyDeviceToHost));
+    double sp = 0, sc = 0;
+    for (int b = 0; b < 256; ++b) {
+        const int cons = same_xcd ? ((b >> 3) & 1) : (b & 1);
+        (cons ? sc : sp) += (double)h_stall[b];
+    }
+    const double ticks_per_ms = 1e5;              // s_memtime counts at 100 MHz on gfx950
+    out[0] = (double)pairs * tiles * tile_bytes / (best_ms * 1e-3) / 1e9;
+    out[1] = best_ms;
+    out[2] = sp / 128 / (best_ms * ticks_per_ms);
+    out[3] = sc / 128 / (best_ms * ticks_per_ms);
+    out[4] = (double)h_err;
+    out[5] = (double)h_abort;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(ring_mem); hipFree(ready); hipFree(consumed); hipFree(abort_word); hipFree(errors); hipFree(stall); hipFree(ab); hipFree(sink);
+    snprintf(msg, msg_cap, "ok");
+    return 0;
+#undef DG
+}
+
+}  // namespace mip

@@ -431,14 +431,14 @@ hipError_t launch_adam_scheduled(int64_t n, float* p, const float* g, float* m, 
     return hipGetLastError();
 }
 
-hipError_t launch_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, float lr, float beta1, float beta2,
-                            float eps, int step, hipStream_t st) {
-    // the float arguments carry python doubles rounded once (0.9, 0.999, lr): widen them back the way they print
-    const double b1 = (double)(float)beta1 == 0.9f ? 0.9 : (double)beta1, b2 = (double)(float)beta2 == 0.999f ? 0.999 : (double)beta2;
-    const double bc1 = 1.0 - pow(b1, (double)step);
-    const double bc2 = 1.0 - pow(b2, (double)step);
-    hipLaunchKernelGGL(k_adam_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, (float)((double)lr / bc1),
-                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), eps, (float)sqrt(bc2));
+hipError_t launch_adam_flat(int64_t n, float* p, const float* g, float* m, float* v, double lr, double beta1, double beta2,
+                            double eps, int step, hipStream_t st) {
+    // the hyper-parameters arrive as the python doubles torch.optim.Adam holds; every derived scalar is formed in double and
+    // rounded once, like torch's scalar arguments (same as the scheduled path)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(k_adam_flat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, p, g, m, v, (float)(lr / bc1),
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)sqrt(bc2));
     return hipGetLastError();
 }
 }  // namespace mip

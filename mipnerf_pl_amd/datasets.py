@@ -345,8 +345,11 @@ class RayLoader:
     """What `DataLoader(dataset, shuffle, batch_size)` yields in nerf_system.py:78-93, without the host: a fresh device
     permutation of the pixel ids per epoch (train) or one image per item with the leading batch dimension of 1 (val / test).
     With world_size > 1 (default: the initialised torch.distributed group) every rank draws the SAME permutation (same seed,
-    same epoch) and keeps every world_size-th id starting at its rank -- what Lightning's DistributedSampler does for the
-    reference under train.py:56-60 -- so the global batch is batch_size x world_size disjoint rays."""
+    same epoch), PADS it to a multiple of world_size by wrapping around to its own start, and keeps every world_size-th id
+    starting at its rank -- what Lightning's DistributedSampler (drop_last=False) does for the reference under
+    train.py:56-60 -- so every rank sees the same number of rays and of batches per epoch (a rank with one batch more would
+    wait forever in the gradient all-reduce) and the global batch is batch_size x world_size rays, disjoint except for the
+    < world_size wrapped ids of the last batch."""
 
     def __init__(self, dataset, batch_size=1, shuffle=False, drop_last=False, seed=0, rank=None, world_size=None):
         self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
@@ -361,7 +364,7 @@ class RayLoader:
         n = len(self.dataset)
         if self.dataset.split != "train":
             return n
-        return (n - self.rank + self.world_size - 1) // self.world_size
+        return (n + self.world_size - 1) // self.world_size          # identical on every rank (padded permutation)
 
     def __len__(self):
         n = self._local_count()
@@ -387,6 +390,9 @@ class RayLoader:
         else:
             order = torch.arange(n, device=ds.device)
         self.epoch += 1
+        pad = self._local_count() * self.world_size - n
+        if pad:
+            order = torch.cat([order, order[:pad]])
         order = order[self.rank::self.world_size]
         for b in range(len(self)):
             yield ds.rays_at(order[b * self.batch_size:(b + 1) * self.batch_size])

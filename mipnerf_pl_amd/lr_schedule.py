@@ -36,26 +36,19 @@ def mip_lr(step: int, lr_init: float, lr_final: float, max_steps: int, lr_delay_
     return float(delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t))
 
 
-class DeviceMipLRDecay:
+class DeviceMipLRDecay(MipLRDecay):
     """Scheduler object returned by MipNeRFSystem.configure_optimizers when the optimiser evaluates MipLRDecay on the
-    device (FlatAdam(schedule=...)): `step()` only advances the host mirror of the epoch (no kernel, no write to
-    param_groups that the device would have to read back), `get_last_lr()` evaluates the same formula on the host."""
+    device (FlatAdam(schedule=...)).  It IS a torch LRScheduler (Lightning's `_validate_scheduler_api` accepts only those
+    unless `lr_scheduler_step` is overridden), i.e. MipLRDecay itself: `step()` advances the epoch and writes the host value
+    of the same formula into `param_groups[0]['lr']` -- informational (logging, checkpoints): the device-scheduled Adam
+    kernel never reads it, it derives the rate from its own device-side step counter."""
 
     def __init__(self, optimizer, lr_init: float, lr_final: float, max_steps: int, lr_delay_steps: int, lr_delay_mult: float):
-        self.optimizer = optimizer
         self.args = (lr_init, lr_final, max_steps, lr_delay_steps, lr_delay_mult)
-        self.last_epoch = 0
-        optimizer.param_groups[0]["lr"] = mip_lr(0, *self.args)
+        super().__init__(optimizer, lr_init, lr_final, max_steps, lr_delay_steps, lr_delay_mult)
 
-    def step(self):
-        self.last_epoch += 1
-        self.optimizer.param_groups[0]["lr"] = mip_lr(self.last_epoch, *self.args)      # informational (logging)
-
-    def get_last_lr(self):
-        return [mip_lr(self.last_epoch, *self.args)]
-
-    def state_dict(self):
-        return {"last_epoch": self.last_epoch}
-
-    def load_state_dict(self, sd):
-        self.last_epoch = int(sd["last_epoch"])
+    def step(self, epoch=None):
+        # the optimiser step may have been a graph replay (GraphedTrainStep) that never went through optimizer.step():
+        # torch's "lr_scheduler.step() before optimizer.step()" warning does not apply
+        self.optimizer._opt_called = True
+        return super().step() if epoch is None else super().step(epoch)

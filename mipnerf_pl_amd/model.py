@@ -323,6 +323,12 @@ class MipNerf(torch.nn.Module):
         mlp_view_dim = mlp_view_dim + 3 if append_identity else mlp_view_dim
         if not append_identity:
             raise NotImplementedError("append_identity=False: forward always appends (mip_nerf.py:224), as here")
+        if not stop_resample_grad and (precision or os.environ.get("MIPNERF_PRECISION", "bf16")) in ("bf16", "bfloat16"):
+            # inference is unaffected; training with the resampler in the graph needs dL/d(encoding), which only the fp32 path has
+            import warnings
+            warnings.warn("MipNerf(stop_resample_grad=False, precision='bf16'): forward / rendering work, but TRAINING with the "
+                          "resampler in the autograd graph needs precision='fp32' (the first backward-enabled forward raises "
+                          "NotImplementedError)", stacklevel=2)
         self.mlp = MLP(mlp_net_depth, mlp_net_width, mlp_net_depth_condition, mlp_net_width_condition,
                        mlp_skip_index, mlp_num_rgb_channels, mlp_num_density_channels, mlp_net_activation,
                        mlp_xyz_dim, mlp_view_dim)

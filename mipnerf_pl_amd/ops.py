@@ -112,7 +112,12 @@ def resample_along_rays(origins, directions, radii, t_samples, weights, randomiz
         if randomized and u_rand is None:
             u_rand = torch.rand(weights.shape[0], weights.shape[1] + 1, device=weights.device)
         t = _ResampleT.apply(t_samples, weights, resample_padding, u_rand if randomized else None)
-        return t, cast_rays(t.detach(), origins, directions, radii, ray_shape)
+        # the reference keeps means / covs differentiable w.r.t. t here (mip.py:265-280).  The native backward of that link is
+        # fused with the encoding (autograd._CastIPE, what MipNerf uses); the stand-alone Gaussians stay attached to the graph
+        # through a node whose backward RAISES, so composing this op with integrated_pos_enc can never silently drop the gradient
+        from .autograd import _CastRaysNoBackward
+        means, covs = _CastRaysNoBackward.apply(t, origins, directions, radii, ray_shape)
+        return t, (means, covs)
     t = resample_t(t_samples, weights, randomized, resample_padding, u_rand)
     return t, cast_rays(t, origins, directions, radii, ray_shape)
 

@@ -16,6 +16,7 @@ distloss_f, psnr_fine (valid until the next call).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -37,6 +38,14 @@ class GraphedTrainStep:
         self.B, self.N, self.dev = int(num_rays), model.num_samples, device
         self.use_graph = bool(use_graph)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # the collective form (graph A, all-reduce on the process group's communicator, graph B) is what every world > 1 run
+        # uses; MIPNERF_FORCE_COLLECTIVE_PATH=1 takes it at world 1 too when a process group exists (a 1-rank RCCL
+        # communicator is legal), so a single-GPU box exercises the two-graph + RCCL sequence end to end
+        self.collective = self.world > 1 or (os.environ.get("MIPNERF_FORCE_COLLECTIVE_PATH") == "1"
+                                             and dist.is_available() and dist.is_initialized())
+        self.capture_error = None
+        self.time_allreduce = False        # True: a HIP event pair around every all-reduce (allreduce_stats)
+        self._ar_events = []
         optimizer.grad_scale = 1.0 / self.world
         self.rays = Rays(*[torch.zeros(self.B, k, device=device) for k in (3, 3, 3, 1, 1, 1, 1)])
         self.rays.directions[:, 2] = 1.0
@@ -90,7 +99,7 @@ class GraphedTrainStep:
             import sys
             print(f"[mipnerf_pl_amd] hipGraph capture of the training step failed ({e}); running it eagerly", file=sys.stderr)
             torch.cuda.synchronize()
-            self.use_graph, self._graphs = False, None
+            self.use_graph, self._graphs, self.capture_error = False, None, f"{type(e).__name__}: {e}"
 
     def _capture_impl(self):
         s = torch.cuda.Stream()
@@ -102,7 +111,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._restore(snap)                 # the warm-up must not count as a training step
-        if self.world == 1:
+        if not self.collective:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._fwd_bwd()
@@ -131,6 +140,15 @@ class GraphedTrainStep:
             self.opt._dev_step.fill_(int(st["step"]))
         L.check(L.lib().mipnerf_set_params(self.ctx.handle, self._params, ops._stream()), "mipnerf_set_params")
 
+    def allreduce_stats(self):
+        """(mean ms, count) of the event pairs recorded around the gradient all-reduce since the last call (synchronises)."""
+        if not self._ar_events:
+            return None, 0
+        self._ar_events[-1][1].synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._ar_events]
+        self._ar_events = []
+        return sum(ms) / len(ms), len(ms)
+
     # ---- one optimisation step -----------------------------------------------------------------------------------------
     def __call__(self):
         mlp, st = self.model.mlp, self.opt.state[self.opt._key()]
@@ -138,7 +156,7 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: the parameters / gradients are no longer views of the flat buffers")
         if self.use_graph and self._graphs is None:
             self._capture()          # may fall back to eager (sets use_graph False)
-        if self.world == 1:
+        if not self.collective:
             if self.use_graph:
                 self._graphs[0].replay()
             else:
@@ -152,8 +170,16 @@ class GraphedTrainStep:
             # one SUM all-reduce of the 2.45 MB flat gradient; c10d runs it on its own stream, ordered after the backward
             # by an event, so the host goes on (next batch's ray generation) while it is in flight; wait() orders the Adam
             # kernels behind it.  The mean (1 / world) is applied inside the Adam kernel.
-            work = dist.all_reduce(mlp._flat_grad, op=dist.ReduceOp.SUM, async_op=True)
-            work.wait()
+            if self.time_allreduce and len(self._ar_events) < 4096:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                work = dist.all_reduce(mlp._flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+                work.wait()
+                ev[1].record()             # on the launch stream, behind the all-reduce it now waits for
+                self._ar_events.append(ev)
+            else:
+                work = dist.all_reduce(mlp._flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+                work.wait()
             if self.use_graph:
                 self._graphs[1].replay()
             else:

@@ -8,6 +8,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
 
     (no flag)                the 11 round-1 files: forward cases, stages, training gradients, ray generation, metrics (~1 min)
     --only-fullsize          round 2: BASELINE configs[1] 4096x128 and configs[3] 8192x256, every ray (~1 min on 8 threads)
+    --only-fullsize-train    round 3: loss + all 24 gradients of the reference's training step at 4096x128 (configs[1], configs[2] inputs; ~2 min)
     --only-trajectory        round 2: 300-step training trajectories (deterministic / randomized) of the reference's own loop,
                              each run twice (all threads / 1 thread) to record the reference's self-divergence (~20 min)
     --only-trajectory-long   round 2: converged 1500-step randomized trajectory, re-run at 4 and 2 threads (~60 min)
@@ -474,6 +475,73 @@ def fullsize_case(name, batch, num_samples, param_seed, gain, ray_seed, unbounde
           f"= {batch * num_samples * 2 / dt:.3e} ray-samples/s; acc range [{float(out['l1_acc'].min()):.3f}, {float(out['l1_acc'].max()):.3f}]")
 
 
+def fullsize_train_case(name, batch, num_samples, param_seed, gain, ray_seed, multiscale, torch_seed=None):
+    """Full-size TRAINING-step golden: the reference's forward + the loss of nerf_system.py:99-111 +
+    backward() at the size the metric is quoted on (configs[1] single-scale / configs[2] multi-scale lossmult + radii,
+    4096 rays x 128 samples).  Inputs regenerate from seeds (sha256 stored); `torch_seed` given = randomized=True with the
+    reference's two CPU draws (torch.rand at mip.py:159, Tensor.uniform_ at mip.py:201) taken from torch's CPU generator
+    under that seed -- the test regenerates the same draws from the same seed (hash stored).  Stored: loss, per-level mse /
+    distloss, per-ray rgb / acc of both levels, per parameter tensor (l2, sum, 64 strided samples) of the gradient and the
+    whole gradient vector."""
+    import hashlib
+    import time
+    rays = orc.synthetic_rays(batch, seed=ray_seed, multiscale=multiscale)
+    R = to_ref_rays(rays)
+    params = orc.make_params(seed=param_seed, density_gain=gain)
+    model = RefMipNerf(num_samples=num_samples)
+    load_params(model, params)
+    gt = np.random.default_rng(1).uniform(0, 1, size=(batch, 3)).astype(np.float32)
+    rgbs = torch.from_numpy(gt)
+    h = hashlib.sha256()
+    for a in rays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    h.update(gt.tobytes())
+    out = dict(num_samples=num_samples, batch=batch, param_seed=param_seed, density_gain=gain, ray_seed=ray_seed,
+               multiscale=int(multiscale), randomized=int(torch_seed is not None), input_sha256=h.hexdigest())
+    randomized = torch_seed is not None
+    if randomized:
+        torch.manual_seed(torch_seed)
+        t_rand = torch.rand(batch, num_samples + 1)
+        u_unit = torch.empty(batch, num_samples + 1).uniform_(0, 1)
+        out["torch_seed"] = torch_seed
+        out["draws_sha256"] = hashlib.sha256(t_rand.numpy().tobytes() + u_unit.numpy().tobytes()).hexdigest()
+        torch.manual_seed(torch_seed)
+    t0 = time.perf_counter()
+    ret = model(R, randomized, True)
+    mask = R.lossmult
+    losses, dls = [], []
+    for (rgb, _, _, w, t) in ret:
+        losses.append((mask * (rgb - rgbs[..., :3]) ** 2).sum() / mask.sum())
+        dls.append(refmip.distloss(w, t))
+    loss = 0.1 * (losses[0] + 0.01 * dls[0]) + losses[1] + 0.01 * dls[-1]
+    loss.backward()
+    dt = time.perf_counter() - t0
+    out.update(loss=np.float32(loss.item()), mse=np.array([l.item() for l in losses], np.float32),
+               distloss=np.array([d.item() for d in dls], np.float32))
+    for lvl, (rgb, dist, acc, w, t) in enumerate(ret):
+        out[f"l{lvl}_rgb"] = rgb.detach().numpy()
+        out[f"l{lvl}_acc"] = acc.detach().numpy()
+    for k, p in model.named_parameters():
+        g = p.grad.detach().numpy().ravel()
+        stride = max(1, g.size // 64)
+        key = k.replace("mlp.", "")
+        out["g_l2_" + key] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["g_sum_" + key] = np.float64(g.astype(np.float64).sum())
+        out["g_smp_" + key] = g[::stride][:64].copy()
+    # the whole gradient too (612,740 fp32, named_parameters order): the bf16 step's per-tensor cosine is taken against the
+    # reference's own gradient, not against our fp32 mode
+    out["g_full"] = np.concatenate([p.grad.detach().numpy().ravel() for _, p in model.named_parameters()]).astype(np.float32)
+    if randomized:
+        oret = orc.mipnerf_forward(params, rays, True, True, num_samples=num_samples, t_rand=t_rand.numpy(),
+                                   u_rand=u_unit.numpy().astype(np.float32))
+        check_oracle(name, ret, oret, 2e-4)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz loss={loss.item():.6f} mse={out['mse']} distloss={out['distloss']}  "
+          f"(reference fwd+bwd {dt:.1f} s on {torch.get_num_threads()} threads)")
+
+
 TRAJ = dict(batch=256, num_samples=32, steps=300, nbatches=300, lr_init=2e-3, lr_final=1e-4, max_steps=300,
             lr_delay_steps=30, lr_delay_mult=0.01, heldout=1024, param_seed=11, ray_seed=1000, rng_seed=4321)
 
@@ -673,6 +741,12 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-noise" in sys.argv:          # round 2: density_noise > 0
         noise_case("fwd_noise_48x64_trained", 48, 64, param_seed=9, gain=4.0, ray_seed=9, torch_seed=77, density_noise=1.0)
+        sys.exit(0)
+    if "--only-fullsize-train" in sys.argv:  # round 3: training step (loss + 24 gradients) at the size the metric is quoted on
+        fullsize_train_case("fulltrain_c2_4096x128", 4096, 128, param_seed=0, gain=40.0, ray_seed=100, multiscale=False)
+        fullsize_train_case("fulltrain_c3_4096x128_ms", 4096, 128, param_seed=0, gain=40.0, ray_seed=101, multiscale=True)
+        fullsize_train_case("fulltrain_c3_4096x128_ms_rand", 4096, 128, param_seed=0, gain=40.0, ray_seed=102, multiscale=True,
+                            torch_seed=2024)
         sys.exit(0)
     if "--only-fullsize" in sys.argv:       # round 2: the BASELINE configurations at full size (same inputs as bench.py)
         fullsize_case("full_c2_4096x128", 4096, 128, param_seed=0, gain=40.0, ray_seed=100)

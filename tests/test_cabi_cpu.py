@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_compiled_arch(lib):
-    assert lib.mipnerf_abi_version() == 3
+    assert lib.mipnerf_abi_version() == 4
     cfg = L.Config()
     assert lib.mipnerf_compiled_arch(C.byref(cfg)) == 0
     assert (cfg.net_depth, cfg.net_width, cfg.net_depth_condition, cfg.net_width_condition, cfg.skip_index) == (8, 256, 1, 128, 4)

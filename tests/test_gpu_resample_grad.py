@@ -258,3 +258,8 @@ def test_ops_resample_along_rays_stop_grad_false():
     assert rel(w.grad, w2.grad) <= 2e-3
     t_sg, _ = ops.resample_along_rays(o, d, r, bins, w, False, "cone", True, 0.01)      # the shipped mode: no graph
     assert not t_sg.requires_grad and torch.equal(t_sg, t_new.detach())
+    # the Gaussians of the stop_grad=False branch must not silently drop the gradient the reference keeps
+    # (mip.py:265-280): differentiating them outside MipNerf raises
+    assert means.requires_grad and covs.requires_grad
+    with pytest.raises(NotImplementedError, match="cast_ipe"):
+        (means.sum() + covs.sum()).backward()

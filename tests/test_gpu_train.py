@@ -379,6 +379,34 @@ def test_flat_adam_equals_torch_adam(G):
     assert l0[-1] != l0[0]                # the weights did move (re-pack after the raw-kernel update is effective)
 
 
+def test_adam_single_step_equals_torch_adam_any_betas(G):
+    """mipnerf_adam_step takes the python doubles torch.optim.Adam holds (no float round trip, no special-cased
+    0.9 / 0.999): ONE step on an identical gradient equals torch's single-tensor Adam to an fp32 ulp, also for other betas
+    and at a late step count (bias corrections formed in double)."""
+    from mipnerf_pl_amd import _lib as L
+    from mipnerf_pl_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    n = 100_003
+    for betas, lr, eps, steps_before in (((0.9, 0.999), 5e-4, 1e-8, 0), ((0.8, 0.95), 3e-4, 1e-6, 0), ((0.85, 0.9875), 1.7e-3, 1e-8, 37)):
+        p0 = torch.randn(n, device=DEV, generator=gen) * 0.1
+        ref = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.Adam([ref], lr=lr, betas=betas, eps=eps, foreach=False, fused=False)
+        mine, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for t in range(1, steps_before + 2):
+            g = torch.randn(n, device=DEV, generator=gen) * 1e-2
+            ref.grad = g.clone()
+            opt.step()
+            L.check(L.lib().mipnerf_adam_step(n, mine.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), lr, betas[0], betas[1], eps, t,
+                                              ops._stream()), "adam_step")
+        torch.cuda.synchronize()
+        d = (mine - ref.detach()).abs()
+        G.record(f"adam_single_step betas={betas} steps={steps_before + 1}", max_abs=float(d.max()))
+        # one fp32 ulp of the parameter per step at most (the division order inside addcdiv is torch's)
+        assert float(d.max()) <= (steps_before + 1) * 1.2e-7 * float(ref.detach().abs().max()) + 1e-9, float(d.max())
+        assert torch.allclose(m, opt.state[ref]["exp_avg"], rtol=3e-7, atol=1e-12)
+        assert torch.allclose(v, opt.state[ref]["exp_avg_sq"], rtol=3e-7, atol=1e-14)
+
+
 def test_end_to_end_training_bf16_tracks_fp32(G):
     """Stand-in for "PSNR within 0.1 dB of the reference" without Blender data (scripts/train_synthetic.py): a student
     trained on device-generated rays of a procedural scene, native bf16 kernels + FlatAdam vs the fp32 parity mode on

@@ -82,3 +82,62 @@ def test_shard_bounds_partition(n, world):
     assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
     sizes = [hi - lo for lo, hi in b]
     assert max(sizes) - min(sizes) <= 1
+
+
+def test_rayloader_equal_batches_per_rank_when_pixels_do_not_divide():
+    """n % world != 0 must not give one rank an extra ray / batch (that rank would block in the gradient
+    all-reduce): the permutation is padded by wrapping, like DistributedSampler(drop_last=False)."""
+    from mipnerf_pl_amd.datasets import RayLoader
+
+    class Stub:
+        split, device = "train", torch.device("cpu")
+
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+        def rays_at(self, ids):
+            return ids
+
+    for n, world, bs in ((10, 3, 2), (101, 4, 5), (64, 8, 8), (7, 8, 1), (1000, 7, 13)):
+        lens, seen = set(), torch.zeros(n, dtype=torch.int64)
+        counts = []
+        for r in range(world):
+            ld = RayLoader(Stub(n), batch_size=bs, shuffle=True, seed=5, rank=r, world_size=world)
+            batches = list(ld)
+            assert len(batches) == len(ld)
+            lens.add(len(ld))
+            counts.append(sum(b.numel() for b in batches))
+            for b in batches:
+                seen[b] += 1
+        assert len(lens) == 1, (n, world, lens)                      # same number of batches on every rank
+        assert len(set(counts)) == 1 and counts[0] == -(-n // world)   # same number of rays on every rank
+        assert int(seen.min()) >= 1 and int(seen.sum()) == world * (-(-n // world)) and int(seen.max()) <= 2 + (world > n)
+
+
+def test_device_lr_scheduler_is_a_torch_lrscheduler():
+    """what configure_optimizers returns with fused_adam must pass Lightning's scheduler validation."""
+    from mipnerf_pl_amd.lr_schedule import DeviceMipLRDecay, mip_lr
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.Adam([p], lr=1.0)
+    args = dict(lr_init=2e-3, lr_final=1e-4, max_steps=300, lr_delay_steps=30, lr_delay_mult=0.01)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        s = DeviceMipLRDecay(opt, **args)
+        assert isinstance(s, torch.optim.lr_scheduler.LRScheduler)
+        assert s.last_epoch == 0 and opt.param_groups[0]["lr"] == mip_lr(0, *s.args)
+        for _ in range(5):
+            s.step()                       # no optimizer.step() in between (graph replay): must not warn
+    assert s.last_epoch == 5 and abs(s.get_last_lr()[0] - mip_lr(5, *s.args)) < 1e-18
+    s2 = DeviceMipLRDecay(torch.optim.Adam([p], lr=1.0), **args)
+    s2.load_state_dict(s.state_dict())
+    assert s2.last_epoch == 5
+    try:
+        from pytorch_lightning.core.optimizer import _validate_scheduler_api
+        from pytorch_lightning.utilities.types import LRSchedulerConfig
+    except Exception:      # noqa: BLE001  (not installed in this image)
+        return
+    _validate_scheduler_api([LRSchedulerConfig(scheduler=s, interval="step")], torch.nn.Module())
