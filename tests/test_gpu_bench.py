@@ -42,9 +42,77 @@ def test_bench_self_launches_two_ranks():
 
 @pytest.mark.gpu
 def test_bench_single_gpu_line():
-    out = _run(["--steps", "3", "--warmup", "1", "--rays", "512", "--samples", "32", "--sustain-seconds", "0.2"], {})
+    out = _run(["--steps", "3", "--warmup", "1", "--rays", "512", "--samples", "32", "--sustain-seconds", "0.2", "--ceiling-seconds", "0.4"], {})
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["metric"] == "ray-samples/sec" and line["dtype"] == "bf16"
     assert line["cpu_baseline"]["kind"] in ("reference", "port") and line["cpu_baseline"]["value"] > 0
     assert line["sustained"]["value"] > 0 and "train" in line and "render" in line
+    assert line["train"]["config"]["hip_graph"] is True and line["train"]["config"]["hip_graph_capture_error"] is None
+    assert line["train"]["ranks"]["ms_per_step_min"] > 0
+    # round 3: the MFMA ceiling of THIS chip and the fp32 configs[3] forward travel in the same line
+    assert 0.3 < line["ceiling"]["lds_fed"] <= line["ceiling"]["register_fed"] * 1.05 < 1.1, line["ceiling"]
+    assert line["fp32"]["dtype"] == "fp32" and line["fp32"]["roofline"]["kernel"] == "k_mlp_f32" and line["fp32"]["roofline"]["frac"] > 0.3
+
+
+@pytest.mark.gpu
+def test_train_step_collective_path_on_a_one_rank_rccl_communicator():
+    """the data-parallel form of the training step (graph A = forward + backward, gradient all-reduce on the
+    process group's RCCL communicator, graph B = Adam + re-pack) had only ever run over gloo.  A 1-rank RCCL communicator is
+    legal: MIPNERF_FORCE_COLLECTIVE_PATH=1 drives exactly that sequence on the 1-GPU box, and the run must agree with the
+    single-graph form (the all-reduce of one rank is the identity, grad_scale = 1)."""
+    code = r'''
+import json, os, sys, torch
+sys.path.insert(0, os.getcwd())
+import torch.distributed as dist
+import synthetic_inputs as syn
+from mipnerf_pl_amd import Rays
+from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+from mipnerf_pl_amd.train_graph import GraphedTrainStep
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+forced = os.environ.get("MIPNERF_FORCE_COLLECTIVE_PATH") == "1"
+if forced:
+    dist.init_process_group("nccl", rank=0, world_size=1)
+B, N = 512, 64
+rays = syn.synthetic_rays(B, seed=3, multiscale=True)
+params = syn.make_params(seed=0, density_gain=40.0)
+hp = dict(DEFAULT_HPARAMS); hp.update({"nerf.num_samples": N, "train.randomized": False, "optimizer.lr_init": 1e-3,
+                                       "optimizer.lr_delay_steps": 0})
+system = MipNeRFSystem(hp, precision="bf16")
+system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+system = system.to(dev)
+system.fused_adam = True
+(opt,), (sch,) = system.configure_optimizers()
+g = GraphedTrainStep(system, opt, B, dev, use_graph=True)
+g.time_allreduce = True
+for dst, src in zip(g.rays, rays):
+    dst.copy_(torch.from_numpy(src))
+g.gt.copy_(torch.rand(B, 3, generator=torch.Generator().manual_seed(1)))
+losses = []
+for _ in range(6):
+    losses.append(float(g()[0]))
+    sch["scheduler"].step()
+torch.cuda.synchronize()
+ar = g.allreduce_stats()
+p = torch.cat([q.detach().reshape(-1) for q in system.mip_nerf.parameters()])
+print(json.dumps({"losses": losses, "collective": g.collective, "use_graph": g.use_graph, "graphs": len(g._graphs or ()),
+                  "allreduce_ms": ar[0], "allreduce_n": ar[1], "psum": float(p.double().sum()), "pabs": float(p.double().abs().sum()),
+                  "backend": dist.get_backend() if forced else None}))
+if forced:
+    dist.destroy_process_group()
+'''
+    res = {}
+    for forced in ("0", "1"):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        env.update({"MIPNERF_FORCE_COLLECTIVE_PATH": forced, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29653"})
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res[forced] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    a, b = res["0"], res["1"]
+    assert a["collective"] is False and a["graphs"] == 1 and a["use_graph"]
+    assert b["collective"] is True and b["graphs"] == 2 and b["use_graph"] and b["backend"] == "nccl"
+    assert b["allreduce_n"] == 6 and b["allreduce_ms"] is not None and 0 < b["allreduce_ms"] < 50
+    assert a["losses"] == b["losses"], (a["losses"], b["losses"])          # same kernels, identity all-reduce: bit-identical trajectories
+    assert a["psum"] == b["psum"] and a["pabs"] == b["pabs"]
+    assert a["losses"][-1] < a["losses"][0]
