@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -f gpurun_out/parity.jsonl
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > gpurun_out/r03a_pytest.txt
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -60 > gpurun_out/r03a_pytest.txt
 tail -5 gpurun_out/r03a_pytest.txt
 timeout 120 python scripts/handoff_probe.py --out gpurun_out/r03a_handoff_probe.jsonl > gpurun_out/r03a_handoff_probe.log 2>&1
 tail -3 gpurun_out/r03a_handoff_probe.log

@@ -9,6 +9,8 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     (no flag)                the 11 round-1 files: forward cases, stages, training gradients, ray generation, metrics (~1 min)
     --only-fullsize          round 2: BASELINE configs[1] 4096x128 and configs[3] 8192x256, every ray (~1 min on 8 threads)
     --only-fullsize-train    round 3: loss + all 24 gradients of the reference's training step at 4096x128 (configs[1], configs[2] inputs; ~2 min)
+    --only-quality-run TAG THREADS SEED / --only-quality-merge   round 3: reference training runs (600 steps x 1024 rays x 128 samples) on the
+                             procedural multi-scale scene, test PSNR at 4 scales (2-4 h of CPU per run)
     --only-trajectory        round 2: 300-step training trajectories (deterministic / randomized) of the reference's own loop,
                              each run twice (all threads / 1 thread) to record the reference's self-divergence (~20 min)
     --only-trajectory-long   round 2: converged 1500-step randomized trajectory, re-run at 4 and 2 threads (~60 min)
@@ -50,7 +52,7 @@ from synthetic_inputs import traj_target  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
-torch.set_num_threads(os.cpu_count())
+torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
 
 
 def to_ref_rays(rays):
@@ -542,6 +544,89 @@ def fullsize_train_case(name, batch, num_samples, param_seed, gain, ray_seed, mu
           f"(reference fwd+bwd {dt:.1f} s on {torch.get_num_threads()} threads)")
 
 
+def quality_run(tag, threads, draw_seed):
+    """Quality stand-in at realistic scale: the UNMODIFIED reference trained on the procedural multi-scale
+    Blender-format scene of tests/dataset_fixture.py (Multicam dataset class -> rays; MipNerf; loss of nerf_system.py:99-111 with
+    the lossmult mask; torch.optim.Adam + the reference's MipLRDecay), N = 128, 1024 rays per step, randomized, then the test
+    split rendered at all 4 scales (README.md:40-44 reports PSNR per scale).  The pixel ids of every step come from
+    dataset_fixture.quality_batch_ids, so the native loop sees the same batches.  One process per run (thread count fixed)."""
+    import time
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dataset_fixture as fx
+    from datasets.datasets import Multicam as RefMulticam
+    from utils.lr_schedule import MipLRDecay as RefLR
+    Q = fx.QUALITY
+    torch.set_num_threads(threads)
+    root = os.environ.get("QUALITY_SCENE_DIR", "/tmp/quality_scene_ms")
+    if not os.path.exists(os.path.join(root, "metadata.json")):
+        fx.write_multicam_scene(root)
+    train = RefMulticam(root, "train", True, "all_images")
+    test = RefMulticam(root, "test", True, "single_image")
+    n_pix = len(train)
+    ids = fx.quality_batch_ids(n_pix, Q["steps"], Q["batch"], Q["id_seed"])
+    torch.manual_seed(Q["param_seed"])
+    model = RefMipNerf(num_samples=Q["num_samples"])
+    opt = torch.optim.Adam(model.parameters(), lr=Q["lr_init"])
+    sch = RefLR(opt, Q["lr_init"], Q["lr_final"], Q["max_steps"], Q["lr_delay_steps"], Q["lr_delay_mult"])
+    torch.manual_seed(draw_seed)
+    losses, psnrs = [], []
+    t0 = time.perf_counter()
+    part = os.path.join(OUT, f"_quality_{tag}.npz")
+    for k in range(Q["steps"]):
+        b = ids[k]
+        # .astype(float32): under numpy >= 2 (NEP 50) the reference's `dx * 2 / np.sqrt(12)` (datasets.py:155) promotes the radii to
+        # float64; with the numpy the reference pins (requirements.txt) every field is float32, which is what the model needs
+        R = RefRays(*[torch.from_numpy(np.ascontiguousarray(getattr(train.rays, f)[b], dtype=np.float32)) for f in RefRays._fields])
+        rgbs = torch.from_numpy(np.ascontiguousarray(train.images[b], dtype=np.float32))
+        ret = model(R, True, True)
+        mask = R.lossmult
+        ls = [(mask * (rgb - rgbs[..., :3]) ** 2).sum() / mask.sum() for rgb, _, _, _, _ in ret]
+        dl = [refmip.distloss(w, t) for _, _, _, w, t in ret]
+        loss = 0.1 * (ls[0] + 0.01 * dl[0]) + ls[1] + 0.01 * dl[-1]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sch.step()
+        losses.append(loss.item())
+        psnrs.append(float(-10.0 * np.log10(np.mean((ret[1][0].detach().numpy() - train.images[b]) ** 2))))
+        if k % 25 == 0 or k == Q["steps"] - 1:
+            print(f"  [{tag}] step {k} loss {losses[-1]:.5f} train psnr {psnrs[-1]:.2f} dB  ({time.perf_counter() - t0:.0f} s)", flush=True)
+    # test-set PSNR per scale (4 views x 4 scales; image i has scale label i % 4)
+    model.eval()
+    per_image = []
+    with torch.no_grad():
+        for i in range(len(test.images)):
+            r = RefRays(*[torch.from_numpy(np.ascontiguousarray(getattr(test.rays, f)[i].reshape(-1, getattr(test.rays, f)[i].shape[-1]), dtype=np.float32))
+                          for f in RefRays._fields])
+            out = model(r, False, True)
+            gt = test.images[i].reshape(-1, 3)
+            per_image.append(float(-10.0 * np.log10(np.mean((out[1][0].numpy() - gt) ** 2))))
+    labels = np.asarray(test.meta["label"]).astype(int)
+    per_scale = [float(np.mean([p for p, l in zip(per_image, labels) if l == j])) for j in range(4)]
+    np.savez_compressed(part, losses=np.asarray(losses, np.float32), train_psnr=np.asarray(psnrs, np.float32),
+                        test_psnr_per_image=np.asarray(per_image, np.float32), test_psnr_per_scale=np.asarray(per_scale, np.float32),
+                        threads=threads, draw_seed=draw_seed, n_pixels=n_pix, seconds=time.perf_counter() - t0,
+                        first_ids=ids[0][:16], scale_labels=labels)
+    print(f"  [{tag}] done: test PSNR per scale {per_scale}, mean {np.mean(per_scale):.3f} dB, {time.perf_counter() - t0:.0f} s")
+
+
+def quality_merge(name):
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dataset_fixture as fx
+    parts = sorted(f for f in os.listdir(OUT) if f.startswith("_quality_") and f.endswith(".npz"))
+    assert parts, "no quality runs found (scripts/make_golden.py --only-quality-run TAG THREADS SEED)"
+    out = dict(runs=np.asarray([p[len("_quality_"):-4] for p in parts]))
+    for k, v in fx.QUALITY.items():
+        out["cfg_" + k] = v
+    for p in parts:
+        tag = p[len("_quality_"):-4]
+        d = np.load(os.path.join(OUT, p))
+        for k in d.files:
+            out[f"{tag}_{k}"] = d[k]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz from {parts}")
+
+
 TRAJ = dict(batch=256, num_samples=32, steps=300, nbatches=300, lr_init=2e-3, lr_final=1e-4, max_steps=300,
             lr_delay_steps=30, lr_delay_mult=0.01, heldout=1024, param_seed=11, ray_seed=1000, rng_seed=4321)
 
@@ -741,6 +826,13 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-noise" in sys.argv:          # round 2: density_noise > 0
         noise_case("fwd_noise_48x64_trained", 48, 64, param_seed=9, gain=4.0, ray_seed=9, torch_seed=77, density_noise=1.0)
+        sys.exit(0)
+    if "--only-quality-run" in sys.argv:     # round 3: one reference training run on the procedural multi-scale scene (hours of CPU)
+        i = sys.argv.index("--only-quality-run")
+        quality_run(sys.argv[i + 1], int(sys.argv[i + 2]), int(sys.argv[i + 3]))
+        sys.exit(0)
+    if "--only-quality-merge" in sys.argv:
+        quality_merge("quality_ms_1024x128")
         sys.exit(0)
     if "--only-fullsize-train" in sys.argv:  # round 3: training step (loss + 24 gradients) at the size the metric is quoted on
         fullsize_train_case("fulltrain_c2_4096x128", 4096, 128, param_seed=0, gain=40.0, ray_seed=100, multiscale=False)

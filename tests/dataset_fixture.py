@@ -92,3 +92,103 @@ def write_llff(root, seed=2, n=10, w=14, h=9, factor=4):
         f.write(struct.pack("<iiQQ", 1, 1, w * factor, h * factor))
         f.write(struct.pack("<dddd", 500.0, 510.0, 0.5 * w * factor - 0.7, 0.5 * h * factor + 0.4))
     return root
+
+
+# ---- a LEARNABLE procedural scene in the multi-scale Blender format (round 3: quality stand-in at realistic scale) ----------
+SCENE_BLOBS = (   # centre (xyz), radius (xyz), peak density, colour
+    ((0.00, 0.00, 0.05), (0.55, 0.40, 0.30), 38.0, (0.85, 0.25, 0.20)),
+    ((0.45, -0.35, 0.30), (0.25, 0.25, 0.35), 30.0, (0.15, 0.60, 0.85)),
+    ((-0.50, 0.30, -0.10), (0.30, 0.22, 0.22), 34.0, (0.20, 0.80, 0.30)),
+    ((0.10, 0.55, 0.45), (0.18, 0.30, 0.18), 26.0, (0.95, 0.85, 0.15)),
+    ((-0.25, -0.55, 0.50), (0.22, 0.18, 0.28), 28.0, (0.70, 0.30, 0.90)),
+)
+
+
+def _scene_density_colour(p):
+    """p [..., 3] float64 -> density [...], colour [..., 3]: anisotropic Gaussian blobs, colour = density-weighted mix + a smooth
+    position-dependent tint (so the network has view-independent but spatially varying colour to fit)."""
+    sig = np.zeros(p.shape[:-1])
+    col = np.zeros(p.shape)
+    for c, r, a, rgb in SCENE_BLOBS:
+        q = (p - np.asarray(c)) / np.asarray(r)
+        g = a * np.exp(-0.5 * np.sum(q * q, -1))
+        sig += g
+        col += g[..., None] * np.asarray(rgb)
+    col = col / np.maximum(sig[..., None], 1e-12)
+    tint = 0.12 * np.stack([np.sin(3.1 * p[..., 0]), np.sin(2.7 * p[..., 1] + 0.5), np.sin(3.7 * p[..., 2] + 1.0)], -1)
+    return sig, np.clip(col + tint, 0.0, 1.0)
+
+
+def _render_scene(origins, directions, near, far, steps=192):
+    """Quadrature of the volume-rendering integral along un-normalised rays o + t d, t in [near, far] (float64):
+    returns straight colour [...,3] and alpha [...]."""
+    o = np.asarray(origins, np.float64)[..., None, :]
+    d = np.asarray(directions, np.float64)[..., None, :]
+    t = np.linspace(near, far, steps + 1)
+    tm = 0.5 * (t[1:] + t[:-1])
+    dt = (t[1:] - t[:-1]) * np.linalg.norm(d, axis=-1)            # [..., steps]
+    sig, col = _scene_density_colour(o + tm[:, None] * d)
+    tau = sig * dt
+    trans = np.exp(-(np.cumsum(tau, -1) - tau))
+    w = (1.0 - np.exp(-tau)) * trans
+    alpha = w.sum(-1)
+    rgb = (w[..., None] * col).sum(-2) / np.maximum(alpha[..., None], 1e-9)
+    return np.clip(rgb, 0.0, 1.0), np.clip(alpha, 0.0, 1.0)
+
+
+def write_multicam_scene(root, seed=7, counts=(("train", 24), ("val", 2), ("test", 4)), base=64, scales=4):
+    """Multi-scale Blender-format dataset (metadata.json as convert_blender_data.py:84-117 writes it) of the analytic scene above:
+    every view rendered at base x base through the SAME pixel -> ray rule as Multicam._generate_rays (datasets.py:116-131), then
+    box-averaged to base/2, base/4, ... like the converter's area down-sampling; RGBA PNGs (straight colour + alpha)."""
+    from oracle import mipnerf_oracle as orc      # test infrastructure on both sides
+    rng = np.random.RandomState(seed)
+    meta = {}
+    for split, n in counts:
+        m = {k: [] for k in ("file_path", "cam2world", "width", "height", "focal", "label", "near", "far", "lossmult", "pix2cam")}
+        for i in range(n):
+            c2w = _look_at_pose(rng)
+            focal0 = 0.5 * base / np.tan(0.5 * 0.69)
+            p2c0 = [[1.0 / focal0, 0.0, -0.5 * base / focal0], [0.0, -1.0 / focal0, 0.5 * base / focal0], [0.0, 0.0, -1.0]]
+            r = orc.generate_rays_multicam(c2w[:3], np.asarray(p2c0), base, base, 2.0, 6.0, 1.0)
+            rgb, alpha = _render_scene(r.origins, r.directions, 2.0, 6.0)
+            img = np.concatenate([rgb * alpha[..., None], alpha[..., None]], -1)      # premultiplied for the box filter
+            for j in range(scales):
+                wj, fj = base // 2 ** j, focal0 / 2 ** j
+                if j:
+                    img = 0.25 * (img[0::2, 0::2] + img[1::2, 0::2] + img[0::2, 1::2] + img[1::2, 1::2])
+                a = img[..., 3:]
+                straight = np.where(a > 1e-6, img[..., :3] / np.maximum(a, 1e-6), 1.0)
+                rel = f"{split}/r_{i}_d{j}.png"
+                _png(os.path.join(root, rel), np.round(255.0 * np.clip(np.concatenate([straight, a], -1), 0, 1)).astype(np.uint8))
+                m["file_path"].append(rel)
+                m["cam2world"].append(c2w.tolist())
+                m["width"].append(wj)
+                m["height"].append(wj)
+                m["focal"].append(fj)
+                m["label"].append(j)
+                m["near"].append(2.0)
+                m["far"].append(6.0)
+                m["lossmult"].append(4.0 ** j)
+                m["pix2cam"].append([[1.0 / fj, 0.0, -0.5 * wj / fj], [0.0, -1.0 / fj, 0.5 * wj / fj], [0.0, 0.0, -1.0]])
+        meta[split] = m
+    os.makedirs(root, exist_ok=True)
+    with open(os.path.join(root, "metadata.json"), "w") as f:
+        json.dump(meta, f)
+    return root
+
+
+QUALITY = dict(batch=1024, num_samples=128, steps=500, lr_init=2e-3, lr_final=2e-5, max_steps=500, lr_delay_steps=50,
+               lr_delay_mult=0.01, id_seed=20240, param_seed=3)
+
+
+def quality_batch_ids(n_pixels, steps, batch, seed):
+    """The SAME pixel ids for the reference's loop and the native loop: step k draws `batch` ids without replacement inside an
+    epoch-wise permutation (what a shuffled DataLoader over the flattened rays does), from numpy's seeded generator."""
+    rng = np.random.default_rng(seed)
+    ids, perm, pos = [], rng.permutation(n_pixels), 0
+    for _ in range(steps):
+        if pos + batch > n_pixels:
+            perm, pos = rng.permutation(n_pixels), 0
+        ids.append(perm[pos:pos + batch].copy())
+        pos += batch
+    return np.stack(ids)

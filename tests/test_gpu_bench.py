@@ -90,9 +90,12 @@ for dst, src in zip(g.rays, rays):
     dst.copy_(torch.from_numpy(src))
 g.gt.copy_(torch.rand(B, 3, generator=torch.Generator().manual_seed(1)))
 losses = []
-for _ in range(6):
+for it in range(7):
     losses.append(float(g()[0]))
     sch["scheduler"].step()
+    if it == 0:
+        torch.cuda.synchronize()
+        g.allreduce_stats()          # the first all-reduce creates the RCCL communicator (hundreds of ms): not a step cost
 torch.cuda.synchronize()
 ar = g.allreduce_stats()
 p = torch.cat([q.detach().reshape(-1) for q in system.mip_nerf.parameters()])
@@ -112,7 +115,7 @@ if forced:
     a, b = res["0"], res["1"]
     assert a["collective"] is False and a["graphs"] == 1 and a["use_graph"]
     assert b["collective"] is True and b["graphs"] == 2 and b["use_graph"] and b["backend"] == "nccl"
-    assert b["allreduce_n"] == 6 and b["allreduce_ms"] is not None and 0 < b["allreduce_ms"] < 50
+    assert b["allreduce_n"] == 6 and b["allreduce_ms"] is not None and 0 < b["allreduce_ms"] < 50, b
     assert a["losses"] == b["losses"], (a["losses"], b["losses"])          # same kernels, identity all-reduce: bit-identical trajectories
     assert a["psum"] == b["psum"] and a["pabs"] == b["pabs"]
     assert a["losses"][-1] < a["losses"][0]

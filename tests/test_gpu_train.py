@@ -403,8 +403,9 @@ def test_adam_single_step_equals_torch_adam_any_betas(G):
         G.record(f"adam_single_step betas={betas} steps={steps_before + 1}", max_abs=float(d.max()))
         # one fp32 ulp of the parameter per step at most (the division order inside addcdiv is torch's)
         assert float(d.max()) <= (steps_before + 1) * 1.2e-7 * float(ref.detach().abs().max()) + 1e-9, float(d.max())
-        assert torch.allclose(m, opt.state[ref]["exp_avg"], rtol=3e-7, atol=1e-12)
-        assert torch.allclose(v, opt.state[ref]["exp_avg_sq"], rtol=3e-7, atol=1e-14)
+        # moments: one rounding of (g - m) * w apart (torch's lerp kernel may contract into an fma): an ulp of the LARGER operand
+        assert torch.allclose(m, opt.state[ref]["exp_avg"], rtol=3e-7, atol=4e-9), float((m - opt.state[ref]["exp_avg"]).abs().max())
+        assert torch.allclose(v, opt.state[ref]["exp_avg_sq"], rtol=3e-7, atol=1e-11), float((v - opt.state[ref]["exp_avg_sq"]).abs().max())
 
 
 def test_end_to_end_training_bf16_tracks_fp32(G):
