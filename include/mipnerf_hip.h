@@ -76,6 +76,9 @@ typedef struct mipnerf_config {
     float rgb_padding;           /* 0.001                                                   */
     float density_noise;         /* 0 ; std-dev of the noise added to raw density when a    */
                                  /* density_randn tensor is given (mip_nerf.py:232-233)     */
+    int32_t unbounded;           /* 0 ; 1 => the unbounded-scene (mip-NeRF 360) path: fence posts uniform in inverse depth,  */
+                                 /* contracted full-covariance Gaussians, off-axis IPE with 42 features per degree (what     */
+                                 /* models/mip.py:106-124, 292-319, 424-447 aim at); fp32 precision only (ABI 4)             */
 } mipnerf_config;
 
 #define MIPNERF_MAX_SAMPLES 512

@@ -23,7 +23,7 @@ class Config(C.Structure):
         "disparity", "disable_integration", "net_depth", "net_width", "net_depth_condition",
         "net_width_condition", "skip_index", "num_rgb_channels", "num_density_channels")] + [
         ("resample_padding", C.c_float), ("density_bias", C.c_float), ("rgb_padding", C.c_float),
-        ("density_noise", C.c_float)]
+        ("density_noise", C.c_float), ("unbounded", C.c_int32)]
 
 
 class RaysPtrs(C.Structure):

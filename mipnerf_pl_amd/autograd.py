@@ -299,9 +299,20 @@ def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_ra
         raise NotImplementedError("stop_resample_grad=False needs the gradient w.r.t. the MLP's input encoding, which the bf16 "
                                   "dgrad kernel does not produce; use precision='fp32' for this option")
     ret = []
-    t_samples, weights = None, None
+    t_samples, weights, t_inv = None, None, None
+    unbounded = getattr(model, "unbounded", False)
     for lvl in range(model.num_levels):
-        if through and lvl > 0:
+        if unbounded:
+            # same sequence as the unbounded branch of mipnerf_forward (capi.hip), no gradient through the sampler
+            with torch.no_grad():
+                if lvl == 0:
+                    t_inv, t_samples = ops.sample_t_360(N, rays.near, rays.far, randomized, t_rand)
+                else:
+                    t_inv = ops.resample_t(t_inv, weights.detach(), randomized, model.resample_padding, u_rand)
+                    t_samples = 1.0 / t_inv
+                enc = ops.cast_ipe_360(t_samples, rays.origins, rays.directions, rays.radii, model.min_deg_point, model.max_deg_point,
+                                       contracted=True, precision=model.precision)
+        elif through and lvl > 0:
             B = rays.origins.shape[0]
             u = None
             if randomized:

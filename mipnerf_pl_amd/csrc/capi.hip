@@ -239,12 +239,15 @@ hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* view
                                bool dma, const mip::RayInputs* rays, const float* dnoise, hipStream_t st) {
     // dnoise: density-noise draws of the level being evaluated, an ARGUMENT (not context state): two host threads / streams
     // driving the same context cannot see each other's pointer
-    return mip::kLaunchBf16[c->P->variant](c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
-                                c->grid_limit, dma, rays, dnoise, c->cfg.density_noise, st);
+    const mip::LaunchBf16Fn fn = mip::kLaunchBf16[c->P->variant];
+    if (!fn) return hipErrorInvalidValue;          // fp32-only architecture variant (callers check has_bf16 first)
+    return fn(c->d_stream_bf16, c->d_bias, enc, viewenc, rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding,
+              c->grid_limit, dma, rays, dnoise, c->cfg.density_noise, st);
 }
 
 // ... and its training kernels (variants whose row of the generated kLaunchTrainFwd table is not null)
 static inline bool has_bf16_train(const PlanDesc* P) { return mip::kLaunchTrainFwd[P->variant] != nullptr; }
+static inline bool has_bf16(const PlanDesc* P) { return mip::kLaunchBf16[P->variant] != nullptr; }
 hipError_t launch_trainfwd_variant(mipnerf_ctx* c, const void* enc, const void* viewenc, float* rgb_sigma, float* raw, void* act,
                                    void* masks, int64_t M, int N, const mip::RayInputs* rays, const float* dnoise, hipStream_t st) {
     const mip::LaunchTrainFwdFn fn = mip::kLaunchTrainFwd[c->P->variant];
@@ -298,7 +301,8 @@ int mipnerf_abi_version(void) { return MIPNERF_ABI_VERSION; }
 
 static void variant_to_cfg(const PlanDesc& P, mipnerf_config* cfg) {
     memset(cfg, 0, sizeof *cfg);
-    cfg->num_samples = 128; cfg->num_levels = 2; cfg->min_deg_point = 0; cfg->max_deg_point = P.xyz_dim / 6;
+    cfg->num_samples = 128; cfg->num_levels = 2; cfg->min_deg_point = 0; cfg->max_deg_point = P.xyz_dim / P.feat_per_deg;
+    cfg->unbounded = P.feat_per_deg == 42;
     cfg->deg_view = (P.view_dim - 3) / 6; cfg->use_viewdirs = P.use_viewdirs; cfg->net_depth = P.net_depth; cfg->net_width = P.net_width;
     cfg->net_depth_condition = P.net_depth_cond; cfg->net_width_condition = P.net_width_cond; cfg->skip_index = P.skip_index;
     cfg->num_rgb_channels = P.num_rgb; cfg->num_density_channels = P.num_density;
@@ -335,7 +339,8 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         const PlanDesc& q = kPlans[v];
         if (cfg->net_depth == q.net_depth && cfg->net_width == q.net_width && cfg->net_depth_condition == q.net_depth_cond &&
             cfg->net_width_condition == q.net_width_cond && cfg->skip_index == q.skip_index && cfg->num_rgb_channels == q.num_rgb &&
-            cfg->num_density_channels == q.num_density && 6 * (cfg->max_deg_point - cfg->min_deg_point) == q.xyz_dim &&
+            cfg->num_density_channels == q.num_density && (cfg->unbounded ? 42 : 6) == q.feat_per_deg &&
+            q.feat_per_deg * (cfg->max_deg_point - cfg->min_deg_point) == q.xyz_dim &&
             3 + 6 * cfg->deg_view == q.view_dim && (cfg->use_viewdirs != 0) == (q.use_viewdirs != 0))
             P = &q;
     }
@@ -343,9 +348,9 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         std::string have;
         for (int v = 0; v < kNumVariants; ++v) {
             char b[160];
-            snprintf(b, sizeof b, "%s[depth %d width %d cond %dx%d skip %d xyz %d view %d viewdirs %d]", v ? ", " : "", kPlans[v].net_depth,
+            snprintf(b, sizeof b, "%s[depth %d width %d cond %dx%d skip %d xyz %d (%d per degree) view %d viewdirs %d%s]", v ? ", " : "", kPlans[v].net_depth,
                      kPlans[v].net_width, kPlans[v].net_depth_cond, kPlans[v].net_width_cond, kPlans[v].skip_index, kPlans[v].xyz_dim,
-                     kPlans[v].view_dim, kPlans[v].use_viewdirs);
+                     kPlans[v].feat_per_deg, kPlans[v].view_dim, kPlans[v].use_viewdirs, mip::kLaunchBf16[v] ? "" : ", fp32 only");
             have += b;
         }
         return fail(MIPNERF_E_UNSUPPORTED, "no kernels / tables were generated for this MLP shape; generated: %s.  Add the shape to "
@@ -515,6 +520,7 @@ static int mlp_forward_noise(mipnerf_ctx* c, int64_t M, int32_t N, const void* e
     if (!c || M < 1 || N < 1 || !enc || !viewenc || !rgb_sigma) return fail(MIPNERF_E_INVALID, "mlp_forward: bad argument");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward: mipnerf_set_params has not been called");
     if (precision == MIPNERF_PREC_BF16) {
+        if (!has_bf16(c->P)) return fail(MIPNERF_E_UNSUPPORTED, "this architecture variant (xyz_dim %d) has fp32 kernels only", c->P->xyz_dim);
         HIP_TRY(launch_bf16_variant(c, enc, viewenc, rgb_sigma, raw, M, N, c->mlp_dma != 0, nullptr, dnoise, S(stream)));
     } else if (precision == MIPNERF_PREC_FP32) {
         HIP_TRY(mip::launch_mlp_f32(f32net_with_heads(c), c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
@@ -1082,7 +1088,8 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
 size_t mipnerf_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
     if (!c || B < 1) return 0;
     const size_t M = (size_t)B * (size_t)c->cfg.num_samples;
-    return align256(M * c->P->xyz_dim * 4) + align256((size_t)B * 32 * 4) + align256(M * 16) + 256;
+    return align256(M * c->P->xyz_dim * 4) + align256((size_t)B * 32 * 4) + align256(M * 16) + 256 +
+           (c->cfg.unbounded ? 2 * align256((size_t)B * (c->cfg.num_samples + 1) * 4) : 0);       // inverse-depth fence posts of two levels
 }
 
 int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* t_rand, const float* u_rand,
@@ -1104,6 +1111,14 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
     void* enc = ws;
     void* viewenc = ws + align256(M * c->P->xyz_dim * 4);
     float* rgb_sigma = reinterpret_cast<float*>(ws + align256(M * c->P->xyz_dim * 4) + align256((size_t)B * 32 * 4));
+    float* t_inv[2] = {nullptr, nullptr};
+    if (cfg.unbounded) {
+        if (precision != MIPNERF_PREC_FP32)
+            return fail(MIPNERF_E_UNSUPPORTED, "the unbounded-scene path runs in fp32 precision (its 42-features-per-degree encoding has no bf16 kernels)");
+        char* q = reinterpret_cast<char*>(rgb_sigma) + align256(M * 16);
+        t_inv[0] = reinterpret_cast<float*>(q);
+        t_inv[1] = reinterpret_cast<float*>(q + align256((size_t)B * (N + 1) * 4));
+    }
     const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
     const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
     int rc;
@@ -1114,14 +1129,28 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
         const mipnerf_level_out& o = out[lvl];
         if (!o.comp_rgb || !o.distance || !o.acc || !o.weights || !o.t_samples)
             return fail(MIPNERF_E_INVALID, "forward: output pointer of level %d is null", lvl);
-        if (lvl == 0) {
+        const bool fused = !cfg.unbounded && precision == MIPNERF_PREC_BF16 && c->fused_ipe && c->mlp_dma;
+        if (cfg.unbounded) {
+            // SURVEY 8(f)-4 (what mip.py:106-124, 292-319, 424-447 aim at): fence posts uniform in inverse depth; the fine level
+            // inverts the coarse weights' piecewise-constant PDF over the INVERSE-DEPTH fence posts (the same blur pool + padding
+            // as mip.py:252-257; the inversion only interpolates between bins, so it is the s-space resampling of the paper up
+            // to the affine map s <-> 1/t), then t = 1 / t_inv; contracted full-covariance Gaussians -> off-axis IPE
+            if (lvl == 0) {
+                HIP_TRY(mip::launch_sample_along_rays_360(B, N, rays->near, rays->far, t_rand, t_inv[0], o.t_samples, S(stream)));
+            } else {
+                if ((rc = mipnerf_resample_along_rays(B, N, t_inv[lvl - 1], out[lvl - 1].weights, u_rand, cfg.resample_padding,
+                                                      t_inv[lvl], stream))) return rc;
+                HIP_TRY(mip::launch_reciprocal((int64_t)B * (N + 1), t_inv[lvl], o.t_samples, S(stream)));
+            }
+            HIP_TRY(mip::launch_cast_ipe_360(B, N, cfg.min_deg_point, cfg.max_deg_point, 1, o.t_samples, rays->origins, rays->directions,
+                                             rays->radii, enc, false, nullptr, nullptr, S(stream)));
+        } else if (lvl == 0) {
             if ((rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, o.t_samples, stream))) return rc;
         } else {
             if ((rc = mipnerf_resample_along_rays(B, N, out[lvl - 1].t_samples, out[lvl - 1].weights, u_rand,
                                                   cfg.resample_padding, o.t_samples, stream))) return rc;
         }
-        const bool fused = precision == MIPNERF_PREC_BF16 && c->fused_ipe && c->mlp_dma;
-        if (!fused &&
+        if (!fused && !cfg.unbounded &&
             (rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, o.t_samples,
                                    rays->origins, rays->directions, rays->radii, enc, precision, stream))) return rc;
         hipEvent_t e0 = nullptr, e1 = nullptr;

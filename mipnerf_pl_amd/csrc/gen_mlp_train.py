@@ -675,6 +675,8 @@ def train_variants():
     out = []
     for vi, arch in enumerate(VARIANTS):
         try:
+            if not arch.bf16_kernels:
+                raise NotImplementedError("fp32-only architecture variant")
             tp = TrainPlan.build(arch)
             out.append((vi, tp, gen_trainfwd(tp, vi), gen_dgrad(tp, vi)))
         except (NotImplementedError, AssertionError) as ex:

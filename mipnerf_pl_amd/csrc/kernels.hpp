@@ -38,6 +38,7 @@ hipError_t launch_generate_rays(int64_t n, const float* cams, const int32_t* cam
                                 float* nearp, float* farp, hipStream_t st);
 
 // ---- kernels_360.hip (unbounded scenes: s-space sampling, contraction, off-axis IPE; raymath360.hpp) ----
+hipError_t launch_reciprocal(int64_t n, const float* x, float* y, hipStream_t st);
 hipError_t launch_sample_along_rays_360(int64_t B, int N, const float* nearp, const float* farp, const float* t_rand,
                                         float* t_inv, float* t, hipStream_t st);
 hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int contracted, const float* t, const float* origins,
@@ -158,6 +159,7 @@ struct F32Net {
     const float* col_b;
     F32Layer layers[kF32MaxLayers];
 };
+int mlp_f32_tile_samples(int ldx);      // 64, 32, or 0 (the LDS row does not fit)
 hipError_t launch_mlp_f32(const F32Net& net, const float* stream_w, const float* bias_tab, const float* enc,
                           const float* viewenc, float* rgb_sigma, float* raw_out, int64_t M, int num_samples,
                           float density_bias, float rgb_padding, float* save, unsigned long long* save_bits, const float* dnoise,

@@ -101,6 +101,16 @@ k_gauss_360(int64_t M, int min_deg, int L, int contracted, const float* __restri
     }
 }
 
+// t = 1 / t_inv for the resampled inverse-depth fence posts of the fine level
+__global__ void __launch_bounds__(256) k_reciprocal(int64_t n, const float* __restrict__ x, float* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = 1.0f / x[i];
+}
+hipError_t launch_reciprocal(int64_t n, const float* x, float* y, hipStream_t st) {
+    hipLaunchKernelGGL(k_reciprocal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, x, y);
+    return hipGetLastError();
+}
+
 hipError_t launch_gauss_360(int64_t M, int min_deg, int max_deg, int contracted, const float* means, const float* covs, void* enc,
                             bool bf16, float* means_out, float* covs_out, hipStream_t st) {
     const int64_t n = M * kBasis360N;

@@ -30,10 +30,13 @@ namespace mip {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int kF32TileSamples = 64;
 constexpr int kF32Waves = 8;
 constexpr int kF32Rounds = 1;   // hidden tiles per wave: widths up to 256 (8 tiles); the thin heads run on the VALU
 
+// TS = samples per workgroup tile: 64 (two 32-sample MFMA halves per weight chunk; every shape whose LDS rows fit: 64 x ldx x 4 B
+// <= 160 KiB) or 32 (one half; wide encodings such as the 672 off-axis features of the unbounded-scene model: half the reuse of
+// every weight chunk, same arithmetic and summation order per sample)
+template <int TS>
 __global__ void __launch_bounds__(kF32Waves * 64)
 k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __restrict__ bias_tab,
           const float* __restrict__ enc, const float* __restrict__ viewenc, float4* __restrict__ rgb_sigma,
@@ -71,6 +74,8 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
         }
     };
 
+    constexpr int kF32TileSamples = TS;
+    constexpr int NT = TS / 32;                // 32-sample MFMA halves per tile
     for (int tile = blockIdx.x; tile < ntiles_total; tile += gridDim.x) {
         const int64_t s0 = (int64_t)tile * kF32TileSamples;
         __syncthreads();     // the previous tile's last reads of X are done
@@ -114,7 +119,7 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                         const float4 n0 = *reinterpret_cast<const float4*>(wp + (size_t)kn * 512);
                         const float4 n1 = *reinterpret_cast<const float4*>(wp + (size_t)kn * 512 + 4);
                         const float* x0 = (kb < ly.kb0 ? xa : xb) + kb * 16;
-                        const float* x1 = x0 + 32 * ldx;
+                        const float* x1 = NT > 1 ? x0 + 32 * ldx : x0;
                         const float4 b00 = *reinterpret_cast<const float4*>(x0);
                         const float4 b01 = *reinterpret_cast<const float4*>(x0 + 4);
                         const float4 b10 = *reinterpret_cast<const float4*>(x1);
@@ -125,7 +130,7 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             acc[rd][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[j], acc[rd][0], 0, 0, 0);
-                            acc[rd][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc[rd][1], 0, 0, 0);
+                            if (NT > 1) acc[rd][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc[rd][1], 0, 0, 0);
                         }
                         a0 = n0;
                         a1 = n1;
@@ -133,7 +138,7 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                     }
                     // ---- this tile's results: the OTHER activation buffer (nobody reads it during this layer)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
+                    for (int nt = 0; nt < NT; ++nt) {
                         float* xo = X + (nt * 32 + n) * ldx + ly.x_out + t * 32 + hi * 4;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -154,7 +159,8 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                 const int K = ly.kb0 * 16;                          // in_features of the head (net_width / net_width_cond)
                 const int ks = K / kF32Waves;                       // k-slice of this wave (K is a multiple of 32)
                 const float* wrow = (ly.kind == 1 ? net.dens_w : net.col_w) + wave * ks;
-                const float* xr = X + lane * ldx + ly.x_in0 + wave * ks;
+                const int hl = lane < TS ? lane : TS - 1;             // TS = 32: the upper lane half shadows sample 31 (no stores)
+                const float* xr = X + hl * ldx + ly.x_in0 + wave * ks;
                 float part[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int k = 0; k < ks; k += 4) {
                     const float4 xv = *reinterpret_cast<const float4*>(xr + k);
@@ -170,8 +176,8 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                 }
                 // partials: spare encoding columns [ecol + 32, ecol + 32 + 8 * 4) of the sample's row (the view encoding uses
                 // [ecol, ecol + 32); the integrated encoding's last reader is behind a barrier); density keeps slot 4*w + 3
-                float* pr = X + lane * ldx + ecol + 32 + wave * 4;
-                if (ly.kind == 1) pr[3] = part[0];
+                float* pr = X + hl * ldx + ecol + 32 + wave * 4;
+                if (lane >= TS) {} else if (ly.kind == 1) pr[3] = part[0];
                 else { pr[0] = part[0]; pr[1] = part[1]; pr[2] = part[2]; }
             }
             if (ly.stage_view) {
@@ -191,7 +197,7 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
             if (ly.kind == 2 && wave == 0) {
                 // finalise: sum the 8 k-slice partials in wave order, add the biases, activations (mip_nerf.py:232-238)
                 const int64_t s = s0 + lane;
-                if (s < M) {
+                if (s < M && lane < TS) {
                     const float* pr = X + lane * ldx + ecol + 32;
                     float r[3] = {0.f, 0.f, 0.f}, dn = 0.f;
 #pragma unroll
@@ -222,6 +228,14 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
     }
 }
 
+// samples per workgroup tile for an LDS row of ldx floats: 64 when it fits the CU's 160 KiB, else 32, else 0
+int mlp_f32_tile_samples(int ldx) {
+    const int cap = 160 * 1024;
+    if (64 * ldx * (int)sizeof(float) <= cap) return 64;
+    if (32 * ldx * (int)sizeof(float) <= cap) return 32;
+    return 0;
+}
+
 hipError_t launch_mlp_f32(const F32Net& net_in, const float* stream_w, const float* bias_tab, const float* enc,
                           const float* viewenc, float* rgb_sigma, float* raw_out, int64_t M, int num_samples,
                           float density_bias, float rgb_padding, float* save, unsigned long long* save_bits, const float* dnoise,
@@ -230,18 +244,25 @@ hipError_t launch_mlp_f32(const F32Net& net_in, const float* stream_w, const flo
     if (!net.dens_w || !net.dens_b || !net.col_w || !net.col_b || net.num_rgb > 3 || net.width > 32 * kF32Waves * kF32Rounds ||
         net.ldx - net.enc_col - 4 < 64)      // VALU-head partials live in encoding columns [32, 64)
         return hipErrorInvalidValue;
-    const int ntiles = (int)((M + kF32TileSamples - 1) / kF32TileSamples);
-    const int lds = kF32TileSamples * net.ldx * (int)sizeof(float);
-    static int attr_lds = 0;
-    if (attr_lds < lds) {
-        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_f32, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int ts = mlp_f32_tile_samples(net.ldx);
+    if (ts == 0) return hipErrorInvalidValue;      // not even a 32-sample tile fits the CU's LDS
+    const int ntiles = (int)((M + ts - 1) / ts);
+    const int lds = ts * net.ldx * (int)sizeof(float);
+    static int attr_lds[2] = {0, 0};
+    if (attr_lds[ts == 64] < lds) {
+        hipError_t er = ts == 64 ? hipFuncSetAttribute((const void*)k_mlp_f32<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                                 : hipFuncSetAttribute((const void*)k_mlp_f32<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (er != hipSuccess) return er;
-        attr_lds = lds;
+        attr_lds[ts == 64] = lds;
     }
     int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(k_mlp_f32, dim3(grid), dim3(kF32Waves * 64), lds, st, net, stream_w, bias_tab, enc, viewenc,
-                       (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save, save_bits, dnoise, dnoise_scale);
+    if (ts == 64)
+        hipLaunchKernelGGL(k_mlp_f32<64>, dim3(grid), dim3(kF32Waves * 64), lds, st, net, stream_w, bias_tab, enc, viewenc,
+                           (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save, save_bits, dnoise, dnoise_scale);
+    else
+        hipLaunchKernelGGL(k_mlp_f32<32>, dim3(grid), dim3(kF32Waves * 64), lds, st, net, stream_w, bias_tab, enc, viewenc,
+                           (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save, save_bits, dnoise, dnoise_scale);
     return hipGetLastError();
 }
 

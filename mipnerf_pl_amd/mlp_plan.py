@@ -93,6 +93,9 @@ class Arch:
     xyz_dim: int = 96
     view_dim: int = 27
     use_viewdirs: bool = True      # False: MLP.forward(x, None) -- colour head on the trunk output (mip_nerf.py:99-110)
+    feat_per_deg: int = 6          # encoding features per frequency: 6 = axis-aligned IPE (sin, cos) x 3; 42 = off-axis IPE on 21 directions
+    bf16_kernels: bool = True      # False: plan tables + fp32 kernels only (an encoding too wide for the bf16 kernels' wave-private
+                                   # LDS area: the 672 off-axis features of the unbounded-scene model); not part of key()
 
     def key(self):
         return (self.net_depth, self.net_width, self.net_depth_condition, self.net_width_condition, self.skip_index,

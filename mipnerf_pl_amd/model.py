@@ -230,7 +230,7 @@ class MLP(torch.nn.Module):
     def native(self, device: torch.device) -> NativeContext:
         if self._ctx is None or self._ctx.device != device:
             a = self.arch
-            deg_point = a["xyz_dim"] // 6
+            deg_point = a["xyz_dim"] // (42 if self._cfg_extra.get("unbounded", 0) else 6)
             deg_view = (a["view_dim"] - 3) // 6
             e = self._cfg_extra
             cfg = L.Config(
@@ -242,7 +242,7 @@ class MLP(torch.nn.Module):
                 net_width_condition=a["net_width_condition"], skip_index=a["skip_index"],
                 num_rgb_channels=a["num_rgb_channels"], num_density_channels=a["num_density_channels"],
                 resample_padding=e.get("resample_padding", 0.01), density_bias=e.get("density_bias", -1.0),
-                rgb_padding=e.get("rgb_padding", 0.001), density_noise=e.get("density_noise", 0.0))
+                rgb_padding=e.get("rgb_padding", 0.001), density_noise=e.get("density_noise", 0.0), unbounded=e.get("unbounded", 0))
             self._ctx = NativeContext(cfg, device)
         self._ctx.sync_params(self.ordered_params())
         return self._ctx
@@ -283,8 +283,14 @@ class MLP(torch.nn.Module):
 class MipNerf(torch.nn.Module):
     """Nerf NN Model with both coarse and fine MLPs (reference: models/mip_nerf.py:114-248).
 
-    Extra keyword (not in the reference): `precision` = 'bf16' (default; bf16 MFMA with fp32
-    accumulation, BASELINE configs[1]) or 'fp32' (exact-fp32 MFMA, parity mode / configs[3])."""
+    Extra keywords (not in the reference): `precision` = 'bf16' (default; bf16 MFMA with fp32
+    accumulation, BASELINE configs[1]) or 'fp32' (exact-fp32 MFMA, parity mode / configs[3]);
+    `unbounded=True` = the unbounded-scene (mip-NeRF 360) path the reference's dead code aims at
+    (mip.py:106-124 sample_along_rays_360, :292-319 integrated_pos_enc_360, :424-447 contract / parameterization): fence posts
+    uniform in inverse depth, fine-level resampling over the inverse-depth fence posts, conical frustums lifted to
+    FULL-covariance Gaussians, contracted into the radius-2 ball, encoded with the off-axis IPE on 21 directions -- 42 features
+    per degree, so the MLP's first layer / skip concat are 42 * (max_deg_point - min_deg_point) wide (672 for 16 degrees).  fp32
+    precision only (forward, rendering and training through autograd); `disparity` / `disable_integration` do not apply."""
 
     def __init__(self, num_samples: int = 128, num_levels: int = 2, resample_padding: float = 0.01,
                  stop_resample_grad: bool = True, use_viewdirs: bool = True, disparity: bool = False,
@@ -294,8 +300,9 @@ class MipNerf(torch.nn.Module):
                  append_identity: bool = True, mlp_net_depth: int = 8, mlp_net_width: int = 256,
                  mlp_net_depth_condition: int = 1, mlp_net_width_condition: int = 128, mlp_skip_index: int = 4,
                  mlp_num_rgb_channels: int = 3, mlp_num_density_channels: int = 1, mlp_net_activation: str = 'relu',
-                 precision: Optional[str] = None):
+                 precision: Optional[str] = None, unbounded: bool = False):
         super().__init__()
+        self.unbounded = bool(unbounded)
         self.num_levels = num_levels
         self.num_samples = num_samples
         self.disparity = disparity
@@ -318,7 +325,15 @@ class MipNerf(torch.nn.Module):
             # MLP.forward(x, None) feeds the trunk output to color_layer (mip_nerf.py:99-110): a shape error in the reference
             raise NotImplementedError("use_viewdirs=False needs mlp_net_width_condition == mlp_net_width "
                                       "(color_layer reads the trunk output; the reference fails on other shapes too)")
-        mlp_xyz_dim = (max_deg_point - min_deg_point) * 3 * 2
+        mlp_xyz_dim = (max_deg_point - min_deg_point) * (42 if unbounded else 3 * 2)
+        if unbounded:
+            if disparity or disable_integration:
+                raise NotImplementedError("unbounded=True samples in inverse depth and always integrates (disparity / disable_integration do not apply)")
+            if not stop_resample_grad:
+                raise NotImplementedError("unbounded=True implements the shipped stop-gradient resampler")
+            if (precision or os.environ.get("MIPNERF_PRECISION", "fp32")) not in ("fp32", "float32"):
+                raise NotImplementedError("unbounded=True runs in precision='fp32' (the 42-features-per-degree encoding has no bf16 kernels)")
+            precision = "fp32"
         mlp_view_dim = deg_view * 3 * 2
         mlp_view_dim = mlp_view_dim + 3 if append_identity else mlp_view_dim
         if not append_identity:
@@ -341,7 +356,7 @@ class MipNerf(torch.nn.Module):
                                    max_deg_point=max_deg_point, deg_view=deg_view, use_viewdirs=int(use_viewdirs),
                                    disparity=int(disparity), disable_integration=int(disable_integration),
                                    resample_padding=resample_padding, density_bias=density_bias,
-                                   rgb_padding=rgb_padding, density_noise=float(density_noise))
+                                   rgb_padding=rgb_padding, density_noise=float(density_noise), unbounded=int(self.unbounded))
 
     def _density_randn(self, randomized, B, dev, density_randn):
         """mip_nerf.py:232-233: standard-normal draws [num_levels, B, N] when randomized and density_noise > 0 (the

@@ -82,6 +82,7 @@ DEFAULT_HPARAMS = {   # configs/lego.yaml, flattened like configs/config.py:62-9
     'nerf.mlp.net_activation': 'relu', 'optimizer.lr_init': 5e-4, 'optimizer.lr_final': 5e-6,
     'optimizer.lr_delay_steps': 2500, 'optimizer.lr_delay_mult': 0.01, 'optimizer.max_steps': 1000000,
     'loss.disable_multiscale_loss': False, 'loss.coarse_loss_mult': 0.1,
+    'nerf.unbounded': False,      # not a reference key: the unbounded-scene (mip-NeRF 360) path, MipNerf(unbounded=True)
 }
 
 
@@ -109,7 +110,7 @@ class MipNeRFSystem(_Base):
             mlp_net_width_condition=hp['nerf.mlp.net_width_condition'], mlp_skip_index=hp['nerf.mlp.skip_index'],
             mlp_num_rgb_channels=hp['nerf.mlp.num_rgb_channels'],
             mlp_num_density_channels=hp['nerf.mlp.num_density_channels'],
-            mlp_net_activation=hp['nerf.mlp.net_activation'], precision=precision)
+            mlp_net_activation=hp['nerf.mlp.net_activation'], precision=precision, unbounded=bool(hp.get('nerf.unbounded', False)))
 
     def forward(self, batch_rays, randomized: bool, white_bkgd: bool):
         return self.mip_nerf(batch_rays, randomized, white_bkgd)     # nerf_system.py:50-54

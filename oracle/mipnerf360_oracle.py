@@ -146,3 +146,42 @@ def integrated_pos_enc_360(means_covs, min_deg, max_deg, contracted=False):
     yl = (y[..., None, :] * scales[:, None]).reshape(y.shape[:-1] + (-1,))
     vl = (y_var[..., None, :] * scales[:, None] ** 2).reshape(y.shape[:-1] + (-1,))
     return expected_sin_mean(np.concatenate([yl, yl + F32(0.5 * np.pi)], -1), np.concatenate([vl, vl], -1))
+
+
+def mipnerf360_forward(params, rays, randomized, white_bkgd, num_samples=128, num_levels=2, resample_padding=0.01,
+                       min_deg_point=0, max_deg_point=16, deg_view=4, density_bias=-1., rgb_padding=0.001, skip_index=4,
+                       net_depth=8, net_depth_condition=1, t_rand=None, u_rand=None, return_stages=False):
+    """The level loop of MipNerf.forward (models/mip_nerf.py:172-248) with the unbounded-scene stages in place of the bounded
+    ones -- what `MipNerf(unbounded=True)` of mipnerf_pl_amd computes:
+      level 0   fence posts uniform in inverse depth (sample_along_rays_360 above)
+      level > 0 the coarse weights' piecewise-constant PDF (blur pool + padding of mip.py:252-257) inverted over the
+                INVERSE-DEPTH fence posts of the previous level with the reference's own sampler
+                (sorted_piecewise_constant_pdf, mip.py:168-229, restated in mipnerf_oracle), then t = 1 / t_inv
+      both      contracted full-covariance Gaussians -> off-axis IPE (42 features per degree) -> the reference MLP
+                (mip_nerf.py:75-111 restated in mipnerf_oracle.mlp_forward; first layer / skip 42 L wide) -> activations ->
+                volumetric_rendering over the metric t (mip.py:366-401)
+    Returns the list of per-level (comp_rgb, distance, acc, weights, t_samples)."""
+    from oracle import mipnerf_oracle as orc
+    ret, stages = [], []
+    t_inv, weights = None, None
+    viewdirs_enc = orc.pos_enc(rays.viewdirs, 0, deg_view, True)
+    for lvl in range(num_levels):
+        if lvl == 0:
+            t_inv, t_samples, mc = sample_along_rays_360(rays.origins, rays.directions, rays.radii, num_samples, rays.near, rays.far,
+                                                         randomized, t_rand=t_rand, contracted=True)
+        else:
+            w = _f32(weights)
+            wp = np.concatenate([w[:, :1], w, w[:, -1:]], axis=-1)                   # mip.py:252-254
+            wmax = np.maximum(wp[:, :-1], wp[:, 1:])
+            wblur = (F32(0.5) * (wmax[:, :-1] + wmax[:, 1:])).astype(F32) + F32(resample_padding)
+            t_inv = orc.sorted_piecewise_constant_pdf(t_inv, wblur, t_inv.shape[-1], randomized, u_rand=u_rand)
+            t_samples = (F32(1) / t_inv).astype(F32)
+            mc = cast_rays_360(t_samples, rays.origins, rays.directions, rays.radii, True)
+        enc = integrated_pos_enc_360(mc, min_deg_point, max_deg_point, contracted=False)     # the Gaussians are contracted already
+        raw_rgb, raw_density = orc.mlp_forward(params, enc, viewdirs_enc, skip_index, net_depth, net_depth_condition)
+        rgb = (orc.sigmoid(raw_rgb) * F32(1 + 2 * rgb_padding) - F32(rgb_padding)).astype(F32)
+        density = orc.softplus(raw_density + F32(density_bias))
+        comp_rgb, distance, acc, weights = orc.volumetric_rendering(rgb, density, t_samples, rays.directions, white_bkgd)
+        ret.append((comp_rgb, distance, acc, weights, t_samples))
+        stages.append(dict(t_inv=t_inv, t_samples=t_samples, enc=enc, raw_rgb=raw_rgb, raw_density=raw_density))
+    return (ret, stages) if return_stages else ret

@@ -11,6 +11,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-fullsize-train    round 3: loss + all 24 gradients of the reference's training step at 4096x128 (configs[1], configs[2] inputs; ~2 min)
     --only-quality-run TAG THREADS SEED / --only-quality-merge   round 3: reference training runs (600 steps x 1024 rays x 128 samples) on the
                              procedural multi-scale scene, test PSNR at 4 scales (2-4 h of CPU per run)
+    --only-360               round 3: contract() and sample_along_rays_360 fence posts / means of the reference (the parts of its dead 360 code that are right)
     --only-trajectory        round 2: 300-step training trajectories (deterministic / randomized) of the reference's own loop,
                              each run twice (all threads / 1 thread) to record the reference's self-divergence (~20 min)
     --only-trajectory-long   round 2: converged 1500-step randomized trajectory, re-run at 4 and 2 threads (~60 min)
@@ -627,6 +628,31 @@ def quality_merge(name):
     print(f"wrote {name}.npz from {parts}")
 
 
+def pin360_case(name):
+    """What of the reference's unbounded-scene code is CORRECT and can pin the oracle's building blocks:
+    `contract` (mip.py:424-428; valid for |x| > 1, the reference masks the rest in `parameterization`) and the inverse-depth
+    fence posts + Gaussian MEANS of `sample_along_rays_360` (mip.py:106-124; deterministic, and randomized with its torch.rand
+    draw replayed).  Its full covariances (mip.py:38-47 uses t_var for the perpendicular term), `parameterization` (needs names
+    that are not imported, replaces the covariance by the Jacobian) and `integrated_pos_enc_360` (no frequency scales) are wrong
+    upstream and pin nothing."""
+    rng = np.random.default_rng(36)
+    x = rng.normal(size=(256, 3)).astype(np.float32) * rng.uniform(0.2, 40.0, size=(256, 1)).astype(np.float32)
+    out = dict(contract_x=x, contract_y=refmip.contract(torch.from_numpy(x)).numpy())
+    B, N = 24, 64
+    rays = orc.synthetic_rays(B, seed=36, unbounded=True)
+    R = to_ref_rays(rays)
+    out.update(rays_dict(rays), num_samples=N)
+    t_inv, (means, _) = refmip.sample_along_rays_360(R.origins, R.directions, R.radii, N, R.near, R.far, False, False, "cone")
+    out.update(det_t_inv=t_inv.numpy(), det_means=means.numpy())
+    torch.manual_seed(360)
+    t_rand = torch.rand(B, N + 1)
+    torch.manual_seed(360)
+    t_inv, (means, _) = refmip.sample_along_rays_360(R.origins, R.directions, R.radii, N, R.near, R.far, True, False, "cone")
+    out.update(t_rand=t_rand.numpy(), rand_t_inv=t_inv.numpy(), rand_means=means.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz")
+
+
 TRAJ = dict(batch=256, num_samples=32, steps=300, nbatches=300, lr_init=2e-3, lr_final=1e-4, max_steps=300,
             lr_delay_steps=30, lr_delay_mult=0.01, heldout=1024, param_seed=11, ray_seed=1000, rng_seed=4321)
 
@@ -833,6 +859,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-quality-merge" in sys.argv:
         quality_merge("quality_ms_1024x128")
+        sys.exit(0)
+    if "--only-360" in sys.argv:             # round 3: the correct parts of the reference's unbounded-scene code
+        pin360_case("pin360_24x64")
         sys.exit(0)
     if "--only-fullsize-train" in sys.argv:  # round 3: training step (loss + 24 gradients) at the size the metric is quoted on
         fullsize_train_case("fulltrain_c2_4096x128", 4096, 128, param_seed=0, gain=40.0, ray_seed=100, multiscale=False)

@@ -122,14 +122,15 @@ def test_architecture_variants_exported(lib):
     """Every MLP shape of gen_mlp_bf16.VARIANTS is carried by the library (mipnerf_variant_arch) and the C++ table
     expansion of each equals mlp_plan.py (bf16 stream incl. its zero padding, bias table, fp32 stream)."""
     variants = _variants()
-    assert lib.mipnerf_num_variants() == len(variants) == 4
+    assert lib.mipnerf_num_variants() == len(variants) == 5
     for v, arch in enumerate(variants):
         cfg, has_train = L.Config(), C.c_int(-1)
         assert lib.mipnerf_variant_arch(v, C.byref(cfg), C.byref(has_train)) == 0
         assert (cfg.net_depth, cfg.net_width, cfg.net_depth_condition, cfg.net_width_condition, cfg.skip_index,
                 bool(cfg.use_viewdirs)) == (arch.net_depth, arch.net_width, arch.net_depth_condition, arch.net_width_condition,
                                             arch.skip_index, arch.use_viewdirs)
-        assert has_train.value == 1                            # bf16 training kernels are generated for every variant
+        assert has_train.value == int(arch.bf16_kernels)       # bf16 training kernels for every variant that has bf16 kernels at all
+        assert bool(cfg.unbounded) == (arch.feat_per_deg == 42) and (cfg.max_deg_point - cfg.min_deg_point) * arch.feat_per_deg == arch.xyz_dim
         plan = Plan.build(arch)
         for which, ref in ((0, "pack_table"), (1, "bias_table"), (2, "pack_table_f32")):
             want = getattr(plan, ref)().astype(np.int32).ravel()
@@ -148,12 +149,12 @@ def test_variant_dataflow_emulation_matches_oracle():
     for arch in _variants()[1:]:
         plan = Plan.build(arch)
         params = orc.make_params(seed=21, density_gain=10.0, net_width=arch.net_width, net_width_condition=arch.net_width_condition,
-                                 net_depth=arch.net_depth, skip_index=arch.skip_index)
+                                 net_depth=arch.net_depth, skip_index=arch.skip_index, xyz_dim=arch.xyz_dim)
         names = [n for n, _ in arch.param_shapes()]
         assert names == list(params.keys())
         flat = np.concatenate([params[n].ravel() for n in names])
         rng = np.random.default_rng(1)
-        enc = rng.uniform(-1, 1, (32, 96)).astype(np.float32)
+        enc = rng.uniform(-1, 1, (32, arch.xyz_dim)).astype(np.float32)
         v27 = rng.uniform(-1, 1, (32, 27)).astype(np.float32)
         view = np.zeros((32, 32), np.float32)
         view[:, :27] = v27

@@ -225,3 +225,24 @@ def test_oracle_constructor_variants(golden_dir, name, kw, tol1):
         for nm, val in zip(("rgb", "distance", "acc", "weights", "t_samples"), ret[lvl]):
             d = float(np.max(np.abs(val - g[f"wb1_l{lvl}_{nm}"])))
             assert d <= (2e-4 if lvl == 0 else tol1), (name, lvl, nm, d)
+
+
+def test_360_oracle_blocks_pinned_by_the_reference_where_it_is_right():
+    """`contract` (mip.py:424-428, |x| > 1) and the inverse-depth fence posts + Gaussian means of
+    `sample_along_rays_360` (mip.py:106-124) of the reference ARE correct and pin the corresponding oracle blocks
+    (scripts/make_golden.py --only-360); full covariances / parameterization / integrated_pos_enc_360 are wrong upstream and
+    cannot (the oracle follows the paper there: "parity unpinned")."""
+    from oracle import mipnerf360_oracle as o360
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pin360_24x64.npz"))
+    x = g["contract_x"]
+    outside = np.linalg.norm(x, axis=-1) > 1
+    assert outside.sum() > 200 and (~outside).sum() > 0
+    assert np.abs(o360.contract(x)[outside] - g["contract_y"][outside]).max() <= 5e-7
+    assert np.array_equal(o360.contract(x)[~outside], x[~outside])
+    rays = orc.Rays(*[g["rays_" + k] for k in orc.Rays._fields])
+    N = int(g["num_samples"])
+    for tag, randomized, tr in (("det", False, None), ("rand", True, g["t_rand"])):
+        t_inv, t, (m, c) = o360.sample_along_rays_360(rays.origins, rays.directions, rays.radii, N, rays.near, rays.far, randomized, t_rand=tr)
+        assert np.array_equal(t_inv, g[f"{tag}_t_inv"])                              # bit-exact fence posts
+        assert np.abs(m - g[f"{tag}_means"]).max() <= 2e-7 * np.abs(g[f"{tag}_means"]).max()
+        assert np.array_equal(t, (np.float32(1) / t_inv).astype(np.float32))
