@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--torch-adam", action="store_true", help="train: torch.optim.Adam on per-tensor gradients "
                     "(what the reference configures) instead of the fused flat Adam kernel")
     ap.add_argument("--no-graph", action="store_true", help="render / train: eager launches instead of the captured hipGraph")
+    ap.add_argument("--preheat-seconds", type=float, default=1.0, help="untimed steps for this long BEFORE the W warm-up steps of every "
+                    "timed region: the package reaches its steady clock / power state (the first tens of steps after an idle period "
+                    "run 3-6 %% slower than the sustained rate); reported in config.preheat_seconds, 0 = off")
     ap.add_argument("--ceiling-seconds", type=float, default=1.2, help="all / inference at N=1: seconds per variant of the in-process MFMA "
                     "ceiling measurement (0 = skip)")
     ap.add_argument("--no-fp32", action="store_true", help="all: skip the fp32 configs[3] sub-record")
@@ -111,6 +114,21 @@ def setup(args):
             s_.close()
         dist.init_process_group(os.environ.get("MIPNERF_BENCH_BACKEND", "nccl"), rank=0, world_size=1)
     return e
+
+
+PREHEAT = {"seconds": 0.0}
+
+
+def preheat(step):
+    """Untimed steps for --preheat-seconds (steady clock / power state of the package); every rank does the same."""
+    import torch
+    if PREHEAT["seconds"] <= 0:
+        return
+    t_end = time.perf_counter() + PREHEAT["seconds"]
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
 
 
 def timed(e, step, warmup, steps, return_local=False):
@@ -180,6 +198,7 @@ def run_inference(args, e):
             return model(R, False, True)
     step()
     ctx = model.mlp.native(e.dev)
+    preheat(step)
     for _ in range(args.warmup):
         step()
     ctx.set_option(2, 1)      # HIP events around every MLP launch of the timed region (on the launch stream)
@@ -229,7 +248,7 @@ def run_inference(args, e):
            "scaling": "weak", "roofline": roofline, "sustained": sustained,
            "config": {"workload": (f"BASELINE.json configs[1]: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) "
                                    f"samples per GPU, 8x256 MLP, random-init trained-like weights"),
-                      "mode": "inference", "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
+                      "mode": "inference", "preheat_seconds": PREHEAT["seconds"], "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
                       "inputs": "pinned host memory, copied every step (PCIe-inclusive)" if args.host_rays else "resident in HBM",
                       "parallelism": f"ray-split x{e.world} (no data-path collective)"}}
     return rec, (rays_np, params)
@@ -286,6 +305,7 @@ def run_train(args, e):
             sch["scheduler"].step()
             return [(loss.detach().reshape(1),)]
     step()
+    preheat(step)
     if graphed:
         gstep.allreduce_stats()                              # drop the events of the first (capturing) step
     dt, out, dt_local = timed(e, step, args.warmup, args.steps, return_local=True)
@@ -325,7 +345,7 @@ def run_train(args, e):
            "roofline": roofline, "ranks": per_rank,
            "config": {"workload": (f"training step (randomized forward + loss incl. distloss + backward + one flat gradient all-reduce + "
                                    f"Adam + MipLRDecay), {B} rays x ({N}+{N}) samples per GPU"),
-                      "mode": "train", "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
+                      "mode": "train", "preheat_seconds": PREHEAT["seconds"], "rays_per_gpu": B, "samples_per_level": N, "levels": model.num_levels,
                       "native_step": native, "fused_adam": bool(system.fused_adam),
                       "hip_graph": bool(graphed and gstep.use_graph),          # what actually ran (a failed capture falls back)
                       "hip_graph_requested": bool(graphed and not args.no_graph),
@@ -367,7 +387,7 @@ def run_render(args, e):
     frames = args.steps if args.mode == "render" else max(2, args.steps // 10)
     warm = args.warmup if args.mode == "render" else 1
     step()
-    dt, out = timed(e, step, warm, frames)
+    dt, out = timed(e, step, warm, frames)           # (a frame is 140 ms of back-to-back launches: no pre-heat needed)
     assert bool(torch.isfinite(out[-1][0]).all())
     samples_per_frame = Himg * Wimg * N * system.mip_nerf.num_levels
     ms = dt / frames * 1e3
@@ -423,7 +443,7 @@ def run_fp32_c4(args, e):
             return model(R, False, True)
     step()
     ctx = model.mlp.native(e.dev)
-    steps, warm = max(3, args.steps // 10), 1
+    steps, warm = max(3, args.steps // 10), 1            # (42 ms per step: no pre-heat needed)
     for _ in range(warm):
         step()
     ctx.set_option(2, 1)
@@ -557,6 +577,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     e = setup(args)
+    PREHEAT["seconds"] = max(0.0, args.preheat_seconds)
     import torch.distributed as dist
     recs, inputs = {}, None
     if args.mode in ("all", "inference"):

@@ -226,6 +226,7 @@ struct mipnerf_ctx {
     bool params_set = false;
     int mlp_dma = 1;                 // 1: global_load_lds ring, 0: register-staged ring (debug)
     int fused_ipe = 1;               // bf16 mipnerf_forward: IPE computed inside the MLP kernel (0: k_cast_ipe + enc buffer)
+    int fuse_small = 1;              // mipnerf_forward: k_ray_prologue / k_composite_resample instead of one launch per stage (option 4)
     int grid_limit = 256;            // persistent workgroups of the bf16 MLP kernel (= CUs)
     // optional instrumentation: HIP events around every MLP launch made by mipnerf_forward
     int time_mlp = 0;
@@ -439,6 +440,7 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
         case 1: if (value < 1) return fail(MIPNERF_E_INVALID, "grid_limit < 1"); c->grid_limit = value; return MIPNERF_OK;
         case 2: c->time_mlp = value < 0 ? 0 : (value > 2 ? 2 : value); c->ev_used = 0; return MIPNERF_OK;
         case 3: c->fused_ipe = value ? 1 : 0; return MIPNERF_OK;
+        case 4: c->fuse_small = value ? 1 : 0; return MIPNERF_OK;
         default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
     }
 }
@@ -1122,8 +1124,18 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
     const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
     const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
     int rc;
-    // pos_enc(viewdirs) is level-independent: computed once (the reference recomputes it, mip_nerf.py:220-226)
-    if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, precision, stream))) return rc;
+    // pos_enc(viewdirs) is level-independent: computed once (the reference recomputes it, mip_nerf.py:220-226) -- in the same launch
+    // as the coarse level's fence posts (option 4 = 0: one launch per stage, the per-stage kernels; both routes give the same bits)
+    bool have_t0 = false;
+    if (c->fuse_small && !cfg.unbounded) {
+        if (!out[0].t_samples) return fail(MIPNERF_E_INVALID, "forward: output pointer of level 0 is null");
+        HIP_TRY(mip::launch_ray_prologue(B, cfg.deg_view, rays->viewdirs, viewenc, 32, precision == MIPNERF_PREC_BF16, N, rays->near, rays->far,
+                                         t_rand, disparity, out[0].t_samples, S(stream)));
+        have_t0 = true;
+    } else if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, precision, stream))) {
+        return rc;
+    }
+    bool have_resampled = false;      // the previous level's launch already drew this level's fence posts (k_composite_resample)
     for (int lvl = 0; lvl < cfg.num_levels; ++lvl) {
         const float* dnoise = density_randn ? density_randn + (size_t)lvl * M : nullptr;    // this level's draws (mip_nerf.py:232-233)
         const mipnerf_level_out& o = out[lvl];
@@ -1138,18 +1150,20 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
             if (lvl == 0) {
                 HIP_TRY(mip::launch_sample_along_rays_360(B, N, rays->near, rays->far, t_rand, t_inv[0], o.t_samples, S(stream)));
             } else {
-                if ((rc = mipnerf_resample_along_rays(B, N, t_inv[lvl - 1], out[lvl - 1].weights, u_rand, cfg.resample_padding,
+                if (!have_resampled &&
+                    (rc = mipnerf_resample_along_rays(B, N, t_inv[lvl - 1], out[lvl - 1].weights, u_rand, cfg.resample_padding,
                                                       t_inv[lvl], stream))) return rc;
                 HIP_TRY(mip::launch_reciprocal((int64_t)B * (N + 1), t_inv[lvl], o.t_samples, S(stream)));
             }
             HIP_TRY(mip::launch_cast_ipe_360(B, N, cfg.min_deg_point, cfg.max_deg_point, 1, o.t_samples, rays->origins, rays->directions,
                                              rays->radii, enc, false, nullptr, nullptr, S(stream)));
         } else if (lvl == 0) {
-            if ((rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, o.t_samples, stream))) return rc;
-        } else {
+            if (!have_t0 && (rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, o.t_samples, stream))) return rc;
+        } else if (!have_resampled) {
             if ((rc = mipnerf_resample_along_rays(B, N, out[lvl - 1].t_samples, out[lvl - 1].weights, u_rand,
                                                   cfg.resample_padding, o.t_samples, stream))) return rc;
         }
+        have_resampled = false;
         if (!fused && !cfg.unbounded &&
             (rc = mipnerf_cast_ipe(B, N, cfg.min_deg_point, cfg.max_deg_point, cfg.disable_integration, o.t_samples,
                                    rays->origins, rays->directions, rays->radii, enc, precision, stream))) return rc;
@@ -1171,6 +1185,16 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
             return rc;
         }
         if (c->time_mlp == 1) HIP_TRY(hipEventRecord(e1, S(stream)));
+        if (c->fuse_small && lvl + 1 < cfg.num_levels && N <= 128) {
+            // compositing of this level + the next level's fence posts in one launch (weights go registers -> LDS, not through HBM)
+            const mipnerf_level_out& nx = out[lvl + 1];
+            if (!nx.t_samples) return fail(MIPNERF_E_INVALID, "forward: output pointer of level %d is null", lvl + 1);
+            HIP_TRY(mip::launch_composite_resample(B, N, rgb_sigma, o.t_samples, rays->directions, white, o.comp_rgb, o.distance, o.acc,
+                                                   o.weights, cfg.unbounded ? t_inv[lvl] : o.t_samples, u_rand, cfg.resample_padding,
+                                                   cfg.unbounded ? t_inv[lvl + 1] : nx.t_samples, S(stream)));
+            have_resampled = true;
+            continue;
+        }
         if ((rc = mipnerf_volumetric_rendering(B, N, rgb_sigma, o.t_samples, rays->directions, white, o.comp_rgb,
                                                o.distance, o.acc, o.weights, stream))) return rc;
     }

@@ -26,6 +26,11 @@ hipError_t launch_cast_ipe(int64_t B, int N, int min_deg, int max_deg, int disab
 hipError_t launch_integrated_pos_enc(int64_t M, int min_deg, int max_deg, const float* means, const float* covs,
                                      void* enc, bool bf16, hipStream_t st);
 hipError_t launch_pos_enc(int64_t B, int deg, const float* viewdirs, void* out, int ld, bool bf16, hipStream_t st);
+hipError_t launch_composite_resample(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs, int white_bkgd,
+                                     float* comp_rgb, float* distance, float* acc, float* weights, const float* bins,
+                                     const float* u_rand, float padding, float* t_new, hipStream_t st);   // hipErrorNotSupported: N > 128
+hipError_t launch_ray_prologue(int64_t B, int deg, const float* viewdirs, void* venc, int ld, bool venc_bf16, int N, const float* nearp,
+                               const float* farp, const float* t_rand, int disparity, float* t_out, hipStream_t st);
 hipError_t launch_volumetric_rendering(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs,
                                        int white_bkgd, float* comp_rgb, float* distance, float* acc,
                                        float* weights, hipStream_t st);

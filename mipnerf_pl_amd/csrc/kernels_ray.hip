@@ -222,21 +222,13 @@ k_pos_enc(int64_t B, int deg, const float* __restrict__ viewdirs, OutT* __restri
 // Lane l owns the K = ceil(N/64) consecutive samples [l*K, l*K+K): a local running sum plus
 // one wave-wide exclusive scan gives the exclusive cumsum of sigma*delta.
 // ------------------------------------------------------------------------------------------
+// The per-ray bodies are device functions shared by the stand-alone kernels and by the fused k_composite_resample (one launch
+// for "composite level 0, then draw the fine level's fence posts from its weights": same arithmetic, same order, same bits).
 template <int K>
-__global__ void __launch_bounds__(256)
-k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
-                       const float* __restrict__ t, const float* __restrict__ dirs, int white_bkgd,
-                       float* __restrict__ comp_rgb, float* __restrict__ distance,
-                       float* __restrict__ acc_out, float* __restrict__ weights) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= B) return;   // whole wave exits together (b is wave-uniform)
-    const float dx = dirs[b * 3], dy = dirs[b * 3 + 1], dz = dirs[b * 3 + 2];
-    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);   // torch.linalg.norm
-    const float* tb = t + b * (int64_t)(N + 1);
-    const float4* cb = rgb_sigma + b * (int64_t)N;
+__device__ __forceinline__ void composite_ray(bool active, int lane, int N, const float4* __restrict__ cb, const float* __restrict__ tb,
+                                              float dn, int white_bkgd, float* __restrict__ comp_rgb_b, float* __restrict__ distance_b,
+                                              float* __restrict__ acc_b, float* __restrict__ weights_b, float (&w_out)[K]) {
     const int i0 = lane * K;
-
     float tv[K + 1];
 #pragma unroll
     for (int k = 0; k <= K; ++k) tv[k] = (i0 + k <= N) ? tb[i0 + k] : 0.0f;
@@ -262,7 +254,8 @@ k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
         const float alpha = 1.0f - expf(-dd[k]);
         const float trans = expf(-(float)(off + pre[k]));   // exclusive cumsum rounded to fp32 like torch
         const float w = ok ? alpha * trans : 0.0f;
-        if (ok) weights[b * (int64_t)N + i0 + k] = w;
+        w_out[k] = w;
+        if (ok && active && weights_b) weights_b[i0 + k] = w;
         sr += w * c[k].x;
         sg += w * c[k].y;
         sb += w * c[k].z;
@@ -270,7 +263,7 @@ k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
         sd += w * (0.5f * (tv[k] + tv[k + 1]));
     }
     sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sa = wave_sum(sa); sd = wave_sum(sd);
-    if (lane == 0) {
+    if (lane == 0 && active) {
         const float tnear = tb[0], tfar = tb[N];
         float dist = nan_to_num(sd);
         dist = fminf(fmaxf(dist, tnear), tfar);   // torch.clamp(x, min, max) = min(max(x,min),max)
@@ -278,10 +271,26 @@ k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
             const float bg = 1.0f - sa;
             sr += bg; sg += bg; sb += bg;
         }
-        comp_rgb[b * 3] = sr; comp_rgb[b * 3 + 1] = sg; comp_rgb[b * 3 + 2] = sb;
-        distance[b] = dist;
-        acc_out[b] = sa;
+        comp_rgb_b[0] = sr; comp_rgb_b[1] = sg; comp_rgb_b[2] = sb;
+        *distance_b = dist;
+        *acc_b = sa;
     }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
+                       const float* __restrict__ t, const float* __restrict__ dirs, int white_bkgd,
+                       float* __restrict__ comp_rgb, float* __restrict__ distance,
+                       float* __restrict__ acc_out, float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;   // whole wave exits together (b is wave-uniform)
+    const float dx = dirs[b * 3], dy = dirs[b * 3 + 1], dz = dirs[b * 3 + 2];
+    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);   // torch.linalg.norm
+    float w[K];
+    composite_ray<K>(true, lane, N, rgb_sigma + b * (int64_t)N, t + b * (int64_t)(N + 1), dn, white_bkgd, comp_rgb + b * 3, distance + b,
+                     acc_out + b, weights + b * (int64_t)N, w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -294,30 +303,13 @@ k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
 constexpr int kPdfMaxBins = 512;      // N <= 512
 constexpr int kRaysPerBlock = 4;
 
+// s_w / s_bins hold the ray's weights [N] and bins [N+1] (staged by the caller, block barrier done); every wave of the block
+// must call this (it contains block barriers); out_row = nullptr: no stores (a wave shadowing the last ray)
 template <int K, bool BLUR>
-__global__ void __launch_bounds__(64 * kRaysPerBlock)
-k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const float* __restrict__ weights,
-                         int n_draws, const float* __restrict__ u_rand, float padding,
-                         float u_step, float u_jitter, float* __restrict__ out) {
-    __shared__ float s_w[kRaysPerBlock][kPdfMaxBins + 2];
-    __shared__ float s_cdf[kRaysPerBlock][kPdfMaxBins + 2];
-    __shared__ float s_bins[kRaysPerBlock][kPdfMaxBins + 2];
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int64_t b = (int64_t)blockIdx.x * kRaysPerBlock + wv;
-    const bool active = b < B;
-    const int64_t bb = active ? b : B - 1;    // inactive waves shadow the last ray (no stores)
-    const float* wb = weights + bb * (int64_t)N;
-    const float* binb = bins + bb * (int64_t)(N + 1);
+__device__ __forceinline__ void pdf_ray(int lane, int N, const float* __restrict__ s_w, float* __restrict__ s_cdf,
+                                        const float* __restrict__ s_bins, int n_draws, const float* __restrict__ u_row,
+                                        float padding, float u_step, float u_jitter, float* __restrict__ out_row) {
     const int i0 = lane * K;
-
-    // stage weights and bins
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-        if (i0 + k < N) s_w[wv][i0 + k] = wb[i0 + k];
-    for (int j = lane; j <= N; j += 64) s_bins[wv][j] = binb[j];
-    __syncthreads();
-
     float w[K];
     double run = 0.0;
 #pragma unroll
@@ -327,12 +319,12 @@ k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const
         if (i < N) {
             if (BLUR) {
                 // weights_pad = [w0, w, w_{N-1}]; max of neighbours; mean of neighbours (mip.py:252-254)
-                const float wc = s_w[wv][i];
-                const float wl = s_w[wv][i > 0 ? i - 1 : 0];
-                const float wr = s_w[wv][i < N - 1 ? i + 1 : N - 1];
+                const float wc = s_w[i];
+                const float wl = s_w[i > 0 ? i - 1 : 0];
+                const float wr = s_w[i < N - 1 ? i + 1 : N - 1];
                 v = 0.5f * (fmaxf(wl, wc) + fmaxf(wc, wr)) + padding;
             } else {
-                v = s_w[wv][i];
+                v = s_w[i];
             }
         }
         w[k] = v;
@@ -357,18 +349,18 @@ k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int i = i0 + k;
-        if (i < N) s_cdf[wv][i] = (i == 0) ? 0.0f : fminf(1.0f, (float)(off + pre[k]));
+        if (i < N) s_cdf[i] = (i == 0) ? 0.0f : fminf(1.0f, (float)(off + pre[k]));
     }
-    if (lane == 0) s_cdf[wv][N] = 1.0f;
+    if (lane == 0) s_cdf[N] = 1.0f;
     __syncthreads();
 
     const float eps32 = 1.1920928955078125e-07f;
     const float umax = 1.0f - eps32;
     for (int j = lane; j < n_draws; j += 64) {
         float u;
-        if (u_rand != nullptr) {
+        if (u_row != nullptr) {
             // u = arange*s + U[0, s-eps), clipped to 1-eps (mip.py:198-204)
-            u = (float)j * u_step + u_rand[bb * (int64_t)n_draws + j] * u_jitter;
+            u = (float)j * u_step + u_row[j] * u_jitter;
             u = fminf(u, umax);
         } else {
             u = torch_linspace_at(0.0f, umax, n_draws, j);   // mip.py:207
@@ -377,17 +369,78 @@ k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const
         int lo = 0, hi = N + 1;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (s_cdf[wv][mid] <= u) lo = mid + 1; else hi = mid;
+            if (s_cdf[mid] <= u) lo = mid + 1; else hi = mid;
         }
         const int below = max(0, lo - 1);
         const int above = min(N, lo);
-        const float c0 = s_cdf[wv][below], c1 = s_cdf[wv][above];
-        const float b0 = s_bins[wv][below], b1 = s_bins[wv][above];
+        const float c0 = s_cdf[below], c1 = s_cdf[above];
+        const float b0 = s_bins[below], b1 = s_bins[above];
         float denom = c1 - c0;
         denom = (denom < 1e-5f) ? 1.0f : denom;
         const float tt = (u - c0) / denom;
-        if (active) out[b * (int64_t)n_draws + j] = b0 + tt * (b1 - b0);
+        if (out_row) out_row[j] = b0 + tt * (b1 - b0);
     }
+}
+
+template <int K, bool BLUR>
+__global__ void __launch_bounds__(64 * kRaysPerBlock)
+k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const float* __restrict__ weights,
+                         int n_draws, const float* __restrict__ u_rand, float padding,
+                         float u_step, float u_jitter, float* __restrict__ out) {
+    __shared__ float s_w[kRaysPerBlock][kPdfMaxBins + 2];
+    __shared__ float s_cdf[kRaysPerBlock][kPdfMaxBins + 2];
+    __shared__ float s_bins[kRaysPerBlock][kPdfMaxBins + 2];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    const bool active = b < B;
+    const int64_t bb = active ? b : B - 1;    // inactive waves shadow the last ray (no stores)
+    const float* wb = weights + bb * (int64_t)N;
+    const float* binb = bins + bb * (int64_t)(N + 1);
+    const int i0 = lane * K;
+    // stage weights and bins
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (i0 + k < N) s_w[wv][i0 + k] = wb[i0 + k];
+    for (int j = lane; j <= N; j += 64) s_bins[wv][j] = binb[j];
+    __syncthreads();
+    pdf_ray<K, BLUR>(lane, N, s_w[wv], s_cdf[wv], s_bins[wv], n_draws, u_rand ? u_rand + bb * (int64_t)n_draws : nullptr, padding, u_step,
+                     u_jitter, active ? out + b * (int64_t)n_draws : nullptr);
+}
+
+// volumetric_rendering of one level FOLLOWED BY resample_along_rays' t part for the next level in ONE launch (the coarse level of
+// every forward): the ray's weights go from the compositing registers straight into the sampler's LDS row -- one launch, one
+// kernel boundary and one [B, N] read less per forward than k_volumetric_rendering + k_piecewise_constant_pdf<., true>.
+template <int K>
+__global__ void __launch_bounds__(64 * kRaysPerBlock)
+k_composite_resample(int64_t B, int N, const float4* __restrict__ rgb_sigma, const float* __restrict__ t,
+                     const float* __restrict__ dirs, int white_bkgd, float* __restrict__ comp_rgb, float* __restrict__ distance,
+                     float* __restrict__ acc_out, float* __restrict__ weights, const float* __restrict__ bins,
+                     const float* __restrict__ u_rand, float padding, float u_step, float u_jitter, float* __restrict__ t_new) {
+    __shared__ float s_w[kRaysPerBlock][kPdfMaxBins + 2];
+    __shared__ float s_cdf[kRaysPerBlock][kPdfMaxBins + 2];
+    __shared__ float s_bins[kRaysPerBlock][kPdfMaxBins + 2];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    const bool active = b < B;
+    const int64_t bb = active ? b : B - 1;
+    const float dx = dirs[bb * 3], dy = dirs[bb * 3 + 1], dz = dirs[bb * 3 + 2];
+    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+    float w[K];
+    composite_ray<K>(active, lane, N, rgb_sigma + bb * (int64_t)N, t + bb * (int64_t)(N + 1), dn, white_bkgd, comp_rgb + bb * 3,
+                     distance + bb, acc_out + bb, weights + bb * (int64_t)N, w);
+    const int i0 = lane * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (i0 + k < N) s_w[wv][i0 + k] = w[k];
+    // the sampler's bins: this level's fence posts, or (unbounded scenes) their inverse depths
+    const float* binb = bins + bb * (int64_t)(N + 1);
+    for (int j = lane; j <= N; j += 64) s_bins[wv][j] = binb[j];
+    __syncthreads();
+    const int n_draws = N + 1;
+    pdf_ray<K, true>(lane, N, s_w[wv], s_cdf[wv], s_bins[wv], n_draws, u_rand ? u_rand + bb * (int64_t)n_draws : nullptr, padding, u_step,
+                     u_jitter, active ? t_new + b * (int64_t)n_draws : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -496,6 +549,68 @@ hipError_t launch_piecewise_constant_pdf(int64_t B, int N, const float* bins, co
         default: return hipErrorInvalidValue;
     }
 #undef MIP_PDF
+    return hipGetLastError();
+}
+
+hipError_t launch_composite_resample(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs, int white_bkgd,
+                                     float* comp_rgb, float* distance, float* acc, float* weights, const float* bins,
+                                     const float* u_rand, float padding, float* t_new, hipStream_t st) {
+    if (N > kPdfMaxBins || N < 1) return hipErrorInvalidValue;
+    const dim3 grid(grid_for(B, kRaysPerBlock)), block(64 * kRaysPerBlock);
+    const float4* c = reinterpret_cast<const float4*>(rgb_sigma);
+    const int n_draws = N + 1;
+    const double s = 1.0 / (double)n_draws;           // as launch_piecewise_constant_pdf
+    const float u_step = (float)s;
+    const float u_jitter = (float)(s - (double)1.1920928955078125e-07f);
+    const int K = (N + 63) / 64;
+#define MIP_CR(KK)                                                                                                       \
+    hipLaunchKernelGGL((k_composite_resample<KK>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd, comp_rgb, distance, acc, \
+                       weights, bins, u_rand, padding, u_step, u_jitter, t_new)
+    switch (K) {      // the same K buckets as the stand-alone kernels use, so both routes give the same bits
+        case 1: MIP_CR(1); break;
+        case 2: MIP_CR(2); break;
+        default: return hipErrorNotSupported;       // other sizes: the caller launches the two kernels
+    }
+#undef MIP_CR
+    return hipGetLastError();
+}
+
+// pos_enc(viewdirs) and the coarse level's fence posts (sample_along_rays, t part) in ONE launch: both only read per-ray inputs
+__global__ void __launch_bounds__(256)
+k_ray_prologue(int64_t B, int deg, const float* __restrict__ viewdirs, void* __restrict__ venc, int ld, int venc_bf16, int N,
+               const float* __restrict__ nearp, const float* __restrict__ farp, const float* __restrict__ t_rand, int disparity,
+               float* __restrict__ t_out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < B * (int64_t)ld) {                   // k_pos_enc
+        const int64_t b = gid / ld;
+        const int c = (int)(gid - b * ld);
+        const float v[3] = {viewdirs[b * 3], viewdirs[b * 3 + 1], viewdirs[b * 3 + 2]};
+        const float f = (c < 3 + 6 * deg) ? view_feature(v, c, deg) : 0.0f;
+        if (venc_bf16) reinterpret_cast<__bf16*>(venc)[gid] = (__bf16)f;
+        else reinterpret_cast<float*>(venc)[gid] = f;
+    }
+    const int64_t total = B * (int64_t)(N + 1);
+    if (gid < total) {                             // k_sample_along_rays
+        const int64_t b = gid / (N + 1);
+        const int i = (int)(gid - b * (N + 1));
+        const float nv = nearp[b], fv = farp[b];
+        float t = level0_t(nv, fv, N, i, disparity);
+        if (t_rand != nullptr) {
+            const float tm = (i > 0) ? level0_t(nv, fv, N, i - 1, disparity) : t;
+            const float tp = (i < N) ? level0_t(nv, fv, N, i + 1, disparity) : t;
+            const float lower = (i > 0) ? 0.5f * (t + tm) : t;
+            const float upper = (i < N) ? 0.5f * (tp + t) : t;
+            t = lower + (upper - lower) * t_rand[gid];
+        }
+        t_out[gid] = t;
+    }
+}
+
+hipError_t launch_ray_prologue(int64_t B, int deg, const float* viewdirs, void* venc, int ld, bool venc_bf16, int N, const float* nearp,
+                               const float* farp, const float* t_rand, int disparity, float* t_out, hipStream_t st) {
+    const int64_t n = B * (int64_t)(ld > N + 1 ? ld : N + 1);
+    hipLaunchKernelGGL(k_ray_prologue, dim3(grid_for(n, 256)), dim3(256), 0, st, B, deg, viewdirs, venc, ld, venc_bf16 ? 1 : 0, N, nearp,
+                       farp, t_rand, disparity, t_out);
     return hipGetLastError();
 }
 

@@ -27,7 +27,7 @@ def test_bench_refuses_world_size_mismatch():
 
 @pytest.mark.gpu
 def test_bench_self_launches_two_ranks():
-    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rays", "512", "--samples", "32", "--sustain-seconds", "0"],
+    out = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--rays", "512", "--samples", "32", "--sustain-seconds", "0", "--preheat-seconds", "0.1"],
                {"MIPNERF_BENCH_SHARE_GPU": "1", "MIPNERF_BENCH_BACKEND": "gloo"})
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -42,7 +42,7 @@ def test_bench_self_launches_two_ranks():
 
 @pytest.mark.gpu
 def test_bench_single_gpu_line():
-    out = _run(["--steps", "3", "--warmup", "1", "--rays", "512", "--samples", "32", "--sustain-seconds", "0.2", "--ceiling-seconds", "0.4"], {})
+    out = _run(["--steps", "3", "--warmup", "1", "--rays", "512", "--samples", "32", "--sustain-seconds", "0.2", "--ceiling-seconds", "0.4", "--preheat-seconds", "0.2"], {})
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["metric"] == "ray-samples/sec" and line["dtype"] == "bf16"

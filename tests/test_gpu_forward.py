@@ -366,3 +366,45 @@ def test_whole_frame_in_one_call_equals_chunks(G, N):
                 for a, b in zip(full[lvl], part[lvl]):
                     assert torch.equal(a[c0:c0 + b.shape[0]], b), (N, c0, lvl)
     assert bool(torch.isfinite(full[1][0]).all())
+
+
+@pytest.mark.parametrize("N", [32, 64, 100, 128, 256])
+@pytest.mark.parametrize("randomized", [False, True])
+def test_fused_small_kernels_equal_per_stage_kernels(G, N, randomized):
+    """Round 3: mipnerf_forward runs pos_enc + the coarse fence posts as one launch (k_ray_prologue) and the coarse level's
+    compositing + the fine level's resampling as one launch (k_composite_resample, N <= 128) -- the SAME device functions as the
+    per-stage kernels, so option 4 = 0 (one launch per stage) must give the same bits in both precisions, also on the
+    unbounded-scene path (which resamples over inverse depths)."""
+    rays_np = orc.synthetic_rays(37, seed=5, multiscale=True)
+    params = orc.make_params(seed=2, density_gain=30.0)
+    rng = np.random.default_rng(N)
+    B = 37
+    tr = torch.from_numpy(rng.uniform(0, 1, (B, N + 1)).astype(np.float32)).to(G.DEV) if randomized else None
+    ur = torch.from_numpy(rng.uniform(0, 1, (B, N + 1)).astype(np.float32)).to(G.DEV) if randomized else None
+    for precision in ("fp32", "bf16"):
+        model = G.make_model(params, N, precision)
+        R = G.to_dev(rays_np)
+        outs = []
+        for fuse in (1, 0):
+            model.mlp.native(torch.device(G.DEV)).set_option(4, fuse)
+            with torch.no_grad():
+                outs.append([tuple(x.clone() for x in lv) for lv in model(R, randomized, True, t_rand=tr, u_rand=ur)])
+        for lvl in range(2):
+            for a, b in zip(outs[0][lvl], outs[1][lvl]):
+                assert torch.equal(a, b), (precision, lvl)
+    if N <= 64:
+        import synthetic_inputs as syn
+        from mipnerf_pl_amd import MipNerf
+        p360 = syn.make_params(seed=3, density_gain=30.0, xyz_dim=672)
+        m = MipNerf(num_samples=N, unbounded=True)
+        m.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in p360.items()})
+        m = m.to(G.DEV)
+        R = G.to_dev(orc.synthetic_rays(B, seed=6, unbounded=True))
+        outs = []
+        for fuse in (1, 0):
+            m.mlp.native(torch.device(G.DEV)).set_option(4, fuse)
+            with torch.no_grad():
+                outs.append([tuple(x.clone() for x in lv) for lv in m(R, randomized, False, t_rand=tr, u_rand=ur)])
+        for lvl in range(2):
+            for a, b in zip(outs[0][lvl], outs[1][lvl]):
+                assert torch.equal(a, b), ("unbounded", lvl)
