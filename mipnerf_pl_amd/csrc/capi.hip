@@ -877,7 +877,6 @@ static int mlp_backward_f32_impl(mipnerf_ctx* c, int64_t M, int32_t N, const flo
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_backward_f32: mipnerf_set_params has not been called");
     if (M > 0x7fffffff) return fail(MIPNERF_E_INVALID, "mlp_backward_f32: too many samples");
     const PlanDesc& PL = *c->P;
-    if (PL.net_depth_cond != 1) return fail(MIPNERF_E_UNSUPPORTED, "mlp_backward_f32: one view layer (net_depth_condition = 1) only");
     const int W = PL.net_width, Wc = PL.net_width_cond, E = PL.xyz_dim, D = PL.net_depth, V = PL.view_dim, RGB = PL.num_rgb;
     const bool views = PL.use_viewdirs != 0;
     const int splits = kF32WgradSplits, Mi = (int)M;
@@ -893,8 +892,9 @@ static int mlp_backward_f32_impl(mipnerf_ctx* c, int64_t M, int32_t N, const flo
     auto slot_bits = [&](int L) { return bits0 + (size_t)L * mip::f32_bits_slot_words(M, W); };
     auto P = [&](int t) { return c->pp.p[t]; };                       // fp32 master parameter t (state_dict order)
     auto G = [&](int t) { return grad_flat + c->tab.tensor_off[t]; }; // its gradient
+    const int Dc = PL.net_depth_cond;        // view layers (mip_nerf.py:62-69): the first reads [bottleneck | view encoding], the others Wc -> Wc
     const int tDensW = 2 * D, tDensB = 2 * D + 1, tExW = 2 * D + 2, tExB = 2 * D + 3, tVW = 2 * D + 4, tVB = 2 * D + 5,
-              tCW = 2 * D + 6, tCB = 2 * D + 7;
+              tCW = 2 * D + 4 + 2 * Dc, tCB = 2 * D + 5 + 2 * Dc;
     const float* x8 = slot(D - 1);     // trunk output [M, W]
     // wgrad / bias helpers: dW[out, ldw] (cols [col0, col0+n)) (+)= dY[M, out]^T X[M, n];  db[out] (+)= dY^T 1.
     // Shapes with >= 64 rows / columns go to the 128 x 128-tile kernel (bias gradient fused into its A-tile staging, ReLU mask
@@ -926,12 +926,23 @@ static int mlp_backward_f32_impl(mipnerf_ctx* c, int64_t M, int32_t N, const flo
         return e;
     };
     if (views) {
-        const float* hv = slot(D + 1);     // view-layer output [M, Wc]
+        const float* hv = slot(D + Dc);    // output of the LAST view layer [M, Wc] (slot D + 1 + i = output of view layer i)
         const float* bott = slot(D);       // bottleneck [M, W]
         // colour layer (mip_nerf.py:110): d_rgb = d_raw[:, 0:3]
         HIP_TRY(wgrad(d_raw, 4, RGB, hv, Wc, 1, Wc, G(tCW), Wc, G(tCB)));
         // g_hv = (d_rgb Wc) * relu'   [M, Wc] in g0
-        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, Wc, g0, Wc, D + 1));
+        HIP_TRY(dgrad(d_raw, 4, RGB, P(tCW), Wc, Wc, g0, Wc, D + Dc));
+        // view layers Dc-1 .. 1 (Wc -> Wc, mip_nerf.py:62-69 with net_depth_condition > 1): delta ping-pongs g0 -> g1 -> g0;
+        // an odd number of them leaves it in g1: copy back so the first view layer below reads g0 as it always did
+        {
+            float *ga = g0, *gb = g1;
+            for (int i = Dc - 1; i >= 1; --i) {
+                HIP_TRY(wgrad(ga, Wc, Wc, slot(D + i), Wc, 1, Wc, G(tVW + 2 * i), Wc, G(tVB + 2 * i)));
+                HIP_TRY(dgrad(ga, Wc, Wc, P(tVW + 2 * i), Wc, Wc, gb, Wc, D + i));
+                float* t = ga; ga = gb; gb = t;
+            }
+            if (ga != g0) HIP_TRY(hipMemcpyAsync(g0, ga, (size_t)M * Wc * 4, hipMemcpyDeviceToDevice, st));
+        }
         // view layer (mip_nerf.py:106-109): input [bottleneck | view encoding of the sample's ray]
         HIP_TRY(wgrad(g0, Wc, Wc, bott, W, 1, W, G(tVW), W + V, G(tVB)));
         HIP_TRY(wgrad(g0, Wc, Wc, viewenc, 32, N, V, G(tVW) + W, W + V, nullptr));
@@ -1106,6 +1117,8 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
     if (workspace_bytes < mipnerf_workspace_bytes(c, B)) return fail(MIPNERF_E_WORKSPACE, "forward: workspace too small");
     if (precision != MIPNERF_PREC_BF16 && precision != MIPNERF_PREC_FP32)
         return fail(MIPNERF_E_INVALID, "unknown precision %d", precision);
+    if (precision == MIPNERF_PREC_BF16 && !has_bf16(c->P))
+        return fail(MIPNERF_E_UNSUPPORTED, "forward: this architecture variant has fp32 kernels only (csrc/gen_mlp_bf16.py VARIANTS)");
     const mipnerf_config& cfg = c->cfg;
     const int N = cfg.num_samples;
     const size_t M = (size_t)B * N;

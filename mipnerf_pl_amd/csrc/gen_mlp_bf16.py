@@ -57,6 +57,9 @@ VARIANTS = [
     # contracted Gaussians (kernels_360.hip) to the same 8 x 256 trunk (first layer 672 -> 256, skip concat 256 + 672).  fp32 only:
     # 42 k-steps per sample do not fit the bf16 kernels' 8-KiB wave-private encoding area.
     Arch(xyz_dim=672, feat_per_deg=42, bf16_kernels=False),
+    # two view layers (mlp_net_depth_condition = 2, mip_nerf.py:62-69): fp32 forward + GEMM backward (the bf16 stream would need
+    # one more ring group of zero padding than the inference generator's tile-to-tile phase allows; bf16 training is one view layer)
+    Arch(net_depth_condition=2, bf16_kernels=False),
 ]
 
 

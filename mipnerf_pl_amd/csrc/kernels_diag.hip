@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(kProbeThreads) k_handoff_probe(uint4* __restri
     }
     uint4* slots = ring_mem + (size_t)pair * ring * tile_vec;
     unsigned long long stall_ticks = 0;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     unsigned bad = 0;
     const int lane = threadIdx.x & 63;
     bf16x8 A0 = ab_src[lane], B0 = ab_src[64 + lane];
@@ -304,7 +305,10 @@ __global__ void __launch_bounds__(kProbeThreads) k_handoff_probe(uint4* __restri
     for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
     if (s == 12345.678f) sink[b] = s;      // keeps the filler MFMAs alive
     if (bad) atomicAdd(errors, bad);
-    if (threadIdx.x == 0) stall[b] = stall_ticks;
+    if (threadIdx.x == 0) {          // both in s_memtime ticks of the SAME run: their ratio needs no clock assumption
+        stall[b] = stall_ticks;
+        stall[256 + b] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
     (void)smem;
 }
 
@@ -335,7 +339,7 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
     DG(hipMalloc(&consumed, pairs * 4));
     DG(hipMalloc(&abort_word, 4));
     DG(hipMalloc(&errors, 4));
-    DG(hipMalloc(&stall, 256 * 8));
+    DG(hipMalloc(&stall, 512 * 8));
     DG(hipMalloc(&ab, 128 * 16));
     DG(hipMalloc(&sink, 256 * 4));
     std::vector<uint16_t> hab(128 * 8);
@@ -366,20 +370,20 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
         if (rep > 0 && ms < best_ms) best_ms = ms;
     }
     unsigned h_err = 0, h_abort = 0;
-    std::vector<unsigned long long> h_stall(256);
+    std::vector<unsigned long long> h_stall(512);
     DG(hipMemcpy(&h_err, errors, 4, hipMemcpyDeviceToHost));
     DG(hipMemcpy(&h_abort, abort_word, 4, hipMemcpyDeviceToHost));
-    DG(hipMemcpy(h_stall.data(), stall, 256 * 8, hipMemcpyDeviceToHost));
+    DG(hipMemcpy(h_stall.data(), stall, 512 * 8, hipMemcpyDeviceToHost));
     double sp = 0, sc = 0;
-    for (int b = 0; b < 256; ++b) {
+    for (int b = 0; b < 256; ++b) {      // fraction of the workgroup's own lifetime (s_memtime ticks) its lane 0 spent polling
         const int cons = same_xcd ? ((b >> 3) & 1) : (b & 1);
-        (cons ? sc : sp) += (double)h_stall[b];
+        const double f = h_stall[256 + b] ? (double)h_stall[b] / (double)h_stall[256 + b] : 0.0;
+        (cons ? sc : sp) += f;
     }
-    const double ticks_per_ms = 1e5;              // s_memtime counts at 100 MHz on gfx950
     out[0] = (double)pairs * tiles * tile_bytes / (best_ms * 1e-3) / 1e9;
     out[1] = best_ms;
-    out[2] = sp / 128 / (best_ms * ticks_per_ms);
-    out[3] = sc / 128 / (best_ms * ticks_per_ms);
+    out[2] = sp / 128;
+    out[3] = sc / 128;
     out[4] = (double)h_err;
     out[5] = (double)h_abort;
     hipEventDestroy(e0);

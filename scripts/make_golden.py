@@ -172,6 +172,9 @@ def variant_case(name, batch, num_samples, param_seed, gain, ray_seed, **ctor):
     as zeros."""
     arch = dict(net_width=ctor.get("mlp_net_width", 256), net_width_condition=ctor.get("mlp_net_width_condition", 128),
                 net_depth=ctor.get("mlp_net_depth", 8), skip_index=ctor.get("mlp_skip_index", 4))
+    dc = ctor.get("mlp_net_depth_condition", 1)
+    if dc != 1:
+        arch["net_depth_condition"] = dc
     rays = orc.synthetic_rays(batch, seed=ray_seed, multiscale=True)
     R = to_ref_rays(rays)
     params = orc.make_params(seed=param_seed, density_gain=gain, **arch)
@@ -190,6 +193,8 @@ def variant_case(name, batch, num_samples, param_seed, gain, ray_seed, **ctor):
     out = dict(rays_dict(rays), num_samples=num_samples, param_seed=param_seed, density_gain=gain, gt=gt,
                loss=np.float32(loss.item()), net_width=arch["net_width"], net_width_condition=arch["net_width_condition"],
                net_depth=arch["net_depth"], skip_index=arch["skip_index"], use_viewdirs=int(ctor.get("use_viewdirs", True)))
+    if dc != 1:
+        out["net_depth_condition"] = dc
     out.update(ret_dict(ret, prefix="wb1_"))
     for k, p in model.named_parameters():
         g = (p.grad if p.grad is not None else torch.zeros_like(p)).detach().numpy().ravel()
@@ -199,7 +204,7 @@ def variant_case(name, batch, num_samples, param_seed, gain, ray_seed, **ctor):
         out["g_sum_" + key] = np.float64(g.astype(np.float64).sum())
         out["g_smp_" + key] = g[::stride][:64].copy()
     oret = orc.mipnerf_forward(params, rays, False, True, num_samples=num_samples, use_viewdirs=ctor.get("use_viewdirs", True),
-                               net_depth=arch["net_depth"], skip_index=arch["skip_index"])
+                               net_depth=arch["net_depth"], skip_index=arch["skip_index"], net_depth_condition=dc)
     check_oracle(name, ret, oret, 2e-4)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"wrote {name}.npz loss={loss.item():.6f}")
@@ -833,6 +838,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-grad-options" in sys.argv:   # round 2: training step with the other boundary settings
         grad_options_case("train_options_40x64", 40, 64, 6, 40.0, 31, 77)
+        sys.exit(0)
+    if "--only-variant-cond" in sys.argv:   # round 3: two view layers (mlp_net_depth_condition = 2; 26 parameter tensors)
+        variant_case("var_dc2_48x64", 48, 64, 10, 40.0, 20, mlp_net_depth_condition=2)
         sys.exit(0)
     if "--only-variant-depth" in sys.argv:  # round 2: another depth / skip period (20 parameter tensors)
         variant_case("var_d6s3_48x64", 48, 64, 9, 40.0, 19, mlp_net_depth=6, mlp_skip_index=3)

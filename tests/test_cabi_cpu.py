@@ -122,7 +122,7 @@ def test_architecture_variants_exported(lib):
     """Every MLP shape of gen_mlp_bf16.VARIANTS is carried by the library (mipnerf_variant_arch) and the C++ table
     expansion of each equals mlp_plan.py (bf16 stream incl. its zero padding, bias table, fp32 stream)."""
     variants = _variants()
-    assert lib.mipnerf_num_variants() == len(variants) == 5
+    assert lib.mipnerf_num_variants() == len(variants) >= 6
     for v, arch in enumerate(variants):
         cfg, has_train = L.Config(), C.c_int(-1)
         assert lib.mipnerf_variant_arch(v, C.byref(cfg), C.byref(has_train)) == 0
@@ -149,7 +149,8 @@ def test_variant_dataflow_emulation_matches_oracle():
     for arch in _variants()[1:]:
         plan = Plan.build(arch)
         params = orc.make_params(seed=21, density_gain=10.0, net_width=arch.net_width, net_width_condition=arch.net_width_condition,
-                                 net_depth=arch.net_depth, skip_index=arch.skip_index, xyz_dim=arch.xyz_dim)
+                                 net_depth=arch.net_depth, skip_index=arch.skip_index, xyz_dim=arch.xyz_dim,
+                                 net_depth_condition=arch.net_depth_condition)
         names = [n for n, _ in arch.param_shapes()]
         assert names == list(params.keys())
         flat = np.concatenate([params[n].ravel() for n in names])
@@ -160,6 +161,6 @@ def test_variant_dataflow_emulation_matches_oracle():
         view[:, :27] = v27
         rgb, dens = emulate_wave(plan, flat, enc, view)
         rr, dd = orc.mlp_forward(params, enc[:, None, :], v27 if arch.use_viewdirs else None, skip_index=arch.skip_index,
-                                 net_depth=arch.net_depth)
+                                 net_depth=arch.net_depth, net_depth_condition=arch.net_depth_condition)
         np.testing.assert_allclose(rgb, rr[:, 0], atol=5e-6)
         np.testing.assert_allclose(dens, dd[:, 0, 0], atol=2e-5)
