@@ -341,6 +341,11 @@ def run_train(args, e):
                 "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": traffic,
                 "traffic_source": tsrc,
                 "flop_per_sample": FLOP_PER_SAMPLE_TRAIN, "samples_per_step": samples_per_step}
+    if traffic:
+        # what actually bounds the step: the saved activations / deltas, written once and read once
+        roofline["hbm_view"] = {"bytes_per_step": traffic, "achieved_TBps": round(traffic / (ms * 1e-3) / 1e12, 3), "peak_TBps": 8.0,
+                                "frac_of_peak": round(traffic / (ms * 1e-3) / 8e12, 4),
+                                "note": "store-everything backprop: 3.73 TFLOP / 20.9 GB = 178 FLOP/B, below the 312 FLOP/B ridge"}
     rec = {"value": round(value, 1), "ms_per_step": round(ms, 4), "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
            "roofline": roofline, "ranks": per_rank,
            "config": {"workload": (f"training step (randomized forward + loss incl. distloss + backward + one flat gradient all-reduce + "
