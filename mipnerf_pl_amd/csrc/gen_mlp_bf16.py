@@ -39,6 +39,10 @@ ABLATE_LDA = int(os.environ.get("MLP_ABLATE_LDA", "0"))              # N > 0: re
 # static priority 1 for the second-dispatched half of the workgroup (the arbitration loser on every segment): 0.4722-0.4756 vs
 # 0.4762-0.4773 ms per launch in three alternating A/B pairs (+0.4 %, profiles/r02k_setprio_ab.log); MLP_SETPRIO=0 turns it off
 SETPRIO = os.environ.get("MLP_SETPRIO", "1") == "1"
+# The integrated positional encoding of the NEXT tile computed piecewise in the shadow of this tile's MFMAs (after the last layer
+# that reads the encoding: its LDS area is free from there on) instead of in a VALU-only phase at the start of every tile.
+IPE_SHADOW = os.environ.get("MLP_IPE_SHADOW", "0") == "1"    # measured: -0.56 % cycles, +0.25 % time (profiles/r03f_ipe_shadow_ab.txt): off
+IPE_SHADOW_STRIDE = int(os.environ.get("MLP_IPE_SHADOW_STRIDE", "4"))    # one piece every STRIDE slots
 NE = 3                # rotating registers for LDS-resident B operands (E0..E2)
 ENC_WAVE_BYTES = 8192  # wave-private LDS: 6 KiB encoding + 2 KiB view encoding
 
@@ -355,6 +359,43 @@ __device__ __forceinline__ void ipe_to_lds(const RayIn& R, int64_t sc, int num_s
     }
 }
 
+// The same encoding in PIECES (gen_mlp_bf16.IPE_SHADOW): the generated tile body spreads them over the MFMA slots that follow the
+// last layer reading the encoding, computing the NEXT tile's fragments while this tile's layers 6.. run.  Expression for
+// expression the body of ipe_to_lds above, so both routes write the same bits.
+struct IpeNext { float mx, my, mz, cx, cy, cz; };
+__device__ __forceinline__ void ipe_next_gauss(const RayIn& R, int64_t sc, int num_samples, IpeNext& q) {
+    const int64_t b = sc / num_samples;
+    const int i = (int)(sc - b * num_samples);
+    const float d[3] = {R.dirs[b * 3], R.dirs[b * 3 + 1], R.dirs[b * 3 + 2]};
+    const float o[3] = {R.origins[b * 3], R.origins[b * 3 + 1], R.origins[b * 3 + 2]};
+    const float t0 = R.t[b * (num_samples + 1) + i], t1 = R.t[b * (num_samples + 1) + i + 1];
+    Gauss3 g = conical_frustum_to_gaussian(t0, t1, d, o, R.radii[b]);
+    if (R.disable_integration) g.cov[0] = g.cov[1] = g.cov[2] = 0.0f;
+    q.mx = g.mean[0]; q.my = g.mean[1]; q.mz = g.mean[2]; q.cx = g.cov[0]; q.cy = g.cov[1]; q.cz = g.cov[2];
+}
+template <int KS, int J>
+__device__ __forceinline__ void ipe_next_yd(const RayIn& R, const IpeNext& q, int hi, float& y, float& damp) {
+    auto pick = [](int a, float x, float yy, float z) { return a == 0 ? x : (a == 1 ? yy : z); };
+    constexpr int f0 = KS * 16 + J, f1 = f0 + 8;              // lane-half 0 / 1
+    const int l = hi ? f1 / 3 : f0 / 3;
+    const float m = hi ? pick(f1 % 3, q.mx, q.my, q.mz) : pick(f0 % 3, q.mx, q.my, q.mz);
+    const float cv = hi ? pick(f1 % 3, q.cx, q.cy, q.cz) : pick(f0 % 3, q.cx, q.cy, q.cz);
+    const float scale = (float)(1u << (l + R.min_deg));
+    y = m * scale;
+    const float yv = cv * (scale * scale);
+    damp = exp_fast(-0.5f * yv);
+}
+template <int J>
+__device__ __forceinline__ void ipe_next_sc(float y, float damp, bf16x8& fs, bf16x8& fc) {
+    fs[J] = (__bf16)(damp * sin_fast(y));
+    fc[J] = (__bf16)(damp * sin_fast(y + kHalfPiF));
+}
+template <int KS>
+__device__ __forceinline__ void ipe_next_store(const bf16x8& fs, const bf16x8& fc, char* enc_lane_w) {
+    *reinterpret_cast<bf16x8*>(enc_lane_w + KS * 1024) = fs;
+    *reinterpret_cast<bf16x8*>(enc_lane_w + (KS + 3) * 1024) = fc;
+}
+
 // Ring-group boundary, executed when the A-fragment LOAD cursor enters group g:
 // (1) this wave's share of group g has landed (vmcnt) and all its LDS reads of group g-1 have
 //     returned (lgkmcnt); (2) barrier: both now hold for every wave, so group g is readable and
@@ -367,6 +408,13 @@ __device__ __forceinline__ void ipe_to_lds(const RayIn& R, int64_t sc, int num_s
         else if (has_next) issue_group<DMA>(stream, smem, 0, (nslot), wave, lane16);              \
     } while (0)
 """
+
+
+def _shadow_fits(plan: Plan) -> bool:
+    """Three ops behind the last encoding reader with >= 2 x 18 MFMA slots each (gen_kernel places one encoding k-step per op)."""
+    last = max(i for i, op in enumerate(plan.ops) if any(sg.regset == "enc" for sg in op.segs))
+    tail = plan.ops[last + 1:last + 4]
+    return len(tail) == 3 and all(op.nk * len(op.tiles) // 2 >= 18 for op in tail)
 
 
 def gen_kernel(plan: Plan, variant: int = 0) -> str:
@@ -433,15 +481,28 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e("    __syncthreads();")
     if SETPRIO:
         e("    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // MI355X_MICROARCH.md, two waves per SIMD, item 4")
+    shadow = IPE_SHADOW and nenc == 6 and _shadow_fits(plan)
     e("    if ((int)blockIdx.x < ntiles) issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
+    if shadow:
+        e("    if (IPE && (int)blockIdx.x < ntiles) {      // the first tile's encoding; every later one is computed in the previous tile's shadow")
+        e("        const int64_t s_first = (int64_t)blockIdx.x * kTileSamples + wave * 32 + n;")
+        e(f"        ipe_to_lds<{nenc}>(rin, s_first < M ? s_first : M - 1, num_samples, hi, encw + lane16);")
+        e("    }")
     e("    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {")
     e("        const bool has_next = tile + (int)gridDim.x < ntiles;")
     e("        const int64_t s = (int64_t)tile * kTileSamples + wave * 32 + n;")
     e("        const int64_t sc = s < M ? s : M - 1;")
     e("        const int64_t ray = sc / num_samples;")
+    if shadow:
+        e("        const int64_t s_next = (int64_t)(tile + (int)gridDim.x) * kTileSamples + wave * 32 + n;")
+        e("        const int64_t scn = s_next < M ? s_next : M - 1;     // past the end: a valid sample, its encoding is never used")
+        e("        IpeNext ipn;")
+        e("        float ipe_y = 0.0f, ipe_d = 0.0f;")
+        e("        bf16x8 ipe_fs, ipe_fc;")
     e("        if (IPE) {")
     e(f"            issue_encodings<DMA, {nenc}, {nenc}>(nullptr, viewenc + ray * 32 + hi * 8, encw, lane16);")
-    e(f"            ipe_to_lds<{nenc}>(rin, sc, num_samples, hi, encw + lane16);")
+    if not shadow:
+        e(f"            ipe_to_lds<{nenc}>(rin, sc, num_samples, hi, encw + lane16);")
     e("        } else {")
     e(f"            issue_encodings<DMA, {nenc}, 0>(enc + sc * {a.xyz_dim} + hi * 8, viewenc + ray * 32 + hi * 8, encw, lane16);")
     e("        }")
@@ -511,6 +572,36 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
                     at = min(at, readers[0] - pn["first"] - 1)
             side[pn["first"] + at].append(stmt)       # at == -1: right behind the last MFMA of the producing panel
     _check_hazards(plan, panels, slots, b_expr, side)
+
+    # ---- the next tile's integrated positional encoding, in pieces, behind the last reader of this tile's encoding ----
+    # One k-step (8 feature pairs + its LDS store) per op, in the FIRST HALF of that op's slots: there most of the op's output
+    # registers are still dead, so the pieces' temporaries (y, damping, two fragments) fit the 256-VGPR budget without spills;
+    # only the six Gaussian moments stay live from the first piece to the last.
+    if shadow:
+        last_enc = max(c for c, sl in enumerate(slots) if sl["b"][0] == "lds" and sl["b"][1] < nenc * 1024)
+        tail_ops = []
+        for pn in panels:
+            op = pn["op"]
+            if pn["first"] > last_enc + 2 and (not tail_ops or tail_ops[-1][0] is not op):
+                tail_ops.append([op, pn["first"], 0])
+            if tail_ops and tail_ops[-1][0] is op:
+                tail_ops[-1][2] = pn["first"] + pn["n"] - tail_ops[-1][1]
+        per_k = []
+        for ks in range(3):
+            ps = []
+            for j in range(8):
+                ps.append(f"ipe_next_yd<{ks}, {j}>(rin, ipn, hi, ipe_y, ipe_d);")
+                ps.append(f"ipe_next_sc<{j}>(ipe_y, ipe_d, ipe_fs, ipe_fc);")
+            ps.append(f"ipe_next_store<{ks}>(ipe_fs, ipe_fc, encw + lane16);")
+            per_k.append(ps)
+        per_k[0].insert(0, "ipe_next_gauss(rin, scn, num_samples, ipn);")
+        regions = [(first, n // 2) for _, first, n in tail_ops[:3]]
+        assert len(regions) == 3 and all(r[1] >= len(per_k[0]) for r in regions), \
+            "IPE_SHADOW needs three ops behind the skip layer with >= 36 MFMA slots each (set MLP_IPE_SHADOW=0 for this shape)"
+        for (first, n), ps in zip(regions, per_k):
+            stride = max(1, min(IPE_SHADOW_STRIDE, n // len(ps)))
+            for pi_, stmt in enumerate(ps):
+                side[first + pi_ * stride].append("if (IPE) { " + stmt + " }")
 
     # ---- tile prologue --------------------------------------------------------------------------
     e("        GROUP_BEGIN(0, 1);")
