@@ -180,6 +180,7 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
 // abort word, every loop leaves, and the probe reports it -- a missing co-resident partner cannot hang the GPU.
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kProbeThreads = 512;
 constexpr unsigned kMaxSpins = 1u << 21;
 
@@ -193,10 +194,14 @@ __device__ __forceinline__ unsigned load_flag(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // global_load_dword sc1: L2-served
 }
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_sc1_x4(uint4* p, uint4 v) {
     const u32x4 w = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+}
+
+// 16-byte load that bypasses this CU's L1 (served by the XCD's L2): flavour 2 reads a same-XCD producer's plain stores with it
+__device__ __forceinline__ void load_sc1_x4_issue(const uint4* p, u32x4& dst) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(dst) : "v"(p) : "memory");
 }
 
 // lane 0 waits until *flag >= need (or abort); result broadcast through LDS.  Returns false on abort.
@@ -265,7 +270,8 @@ __global__ void __launch_bounds__(kProbeThreads) k_handoff_probe(uint4* __restri
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc1, 0, 0, 0);
             }
-            if (FLAVOUR == 1) {
+            if (FLAVOUR == 1 || FLAVOUR == 2) {
+                // 2: plain stores are write-through to the XCD's L2; a same-XCD consumer that bypasses ITS L1 needs no fence at all
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (threadIdx.x == 0) __hip_atomic_store(&ready[pair], (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -279,17 +285,30 @@ __global__ void __launch_bounds__(kProbeThreads) k_handoff_probe(uint4* __restri
             }
         } else {
             if (!wait_counter(&ready[pair], (unsigned)(t + 1), abort_word, &lds_ok, stall_ticks)) break;
-            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (FLAVOUR != 2 && threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __syncthreads();
             for (int i0 = 0; i0 < per_thread; i0 += 8) {
                 uint4 v[8];
+                u32x4 r[8];
+                if (FLAVOUR == 2) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = slot[(size_t)(i0 + i) * kProbeThreads + threadIdx.x];
+                    for (int i = 0; i < 8; ++i) load_sc1_x4_issue(slot + (size_t)(i0 + i) * kProbeThreads + threadIdx.x, r[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = slot[(size_t)(i0 + i) * kProbeThreads + threadIdx.x];
+                }
                 if (i0 == 0)
                     for (int m = 0; m < mfma_per_wave; m += 2) {
                         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc1, 0, 0, 0);
                     }
+                if (FLAVOUR == 2) {       // the asm loads are invisible to the compiler's waitcnt insertion: wait by hand, after the MFMAs
+                    // the registers are operands of the wait, so the compiler cannot read them before it
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                                 :: "memory");
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = make_uint4(r[i].x, r[i].y, r[i].z, r[i].w);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const uint4 w = probe_pattern((unsigned)pair, (unsigned)t, (unsigned)((i0 + i) * kProbeThreads + threadIdx.x));
@@ -351,6 +370,7 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
     const size_t lds = 96 * 1024;                 // > half of the CU's 160 KiB: one workgroup per CU
     DG(hipFuncSetAttribute((const void*)k_handoff_probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DG(hipFuncSetAttribute((const void*)k_handoff_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DG(hipFuncSetAttribute((const void*)k_handoff_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     DG(hipEventCreate(&e0));
     DG(hipEventCreate(&e1));
@@ -359,7 +379,9 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
         DG(hipMemsetAsync(ready, 0, pairs * 4, st));
         DG(hipMemsetAsync(consumed, 0, pairs * 4, st));
         DG(hipEventRecord(e0, st));
-        if (flavour) hipLaunchKernelGGL(k_handoff_probe<1>, dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word,
+        if (flavour == 2) hipLaunchKernelGGL(k_handoff_probe<2>, dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word,
+                                             stall, errors, same_xcd, tiles, ring, tile_vec, mfma_per_wave, ab, sink);
+        else if (flavour) hipLaunchKernelGGL(k_handoff_probe<1>, dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word,
                                         stall, errors, same_xcd, tiles, ring, tile_vec, mfma_per_wave, ab, sink);
         else hipLaunchKernelGGL(k_handoff_probe<0>, dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word, stall,
                                 errors, same_xcd, tiles, ring, tile_vec, mfma_per_wave, ab, sink);

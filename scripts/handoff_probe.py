@@ -30,7 +30,7 @@ def main():
     grid = []
     for tile_bytes in ((131072,) if args.quick else (131072, 65536, 262144)):
         for same in (1, 0):
-            for flavour in (0, 1):
+            for flavour in (0, 1, 2):
                 for ring in ((4,) if args.quick else (2, 4, 8)):
                     for mfma in (0, 256, 512):
                         if tile_bytes != 131072 and (ring != 4 or mfma == 512):
@@ -40,7 +40,7 @@ def main():
         for same, flavour, ring, tile_bytes, mfma in grid:
             out = (C.c_double * 6)()
             rc = L.lib().mipnerf_handoff_probe(same, flavour, args.tiles, ring, tile_bytes, mfma, 3, out, st)
-            row = {"same_xcd": same, "stores": "sc1 write-through" if flavour else "plain + agent release", "ring": ring,
+            row = {"same_xcd": same, "stores": ("plain + agent release", "sc1 write-through", "plain, no fence; consumer loads bypass L1 (sc1)")[flavour], "ring": ring,
                    "tile_bytes": tile_bytes, "tiles_per_pair": args.tiles, "mfma_per_wave_per_tile": mfma, "rc": rc,
                    "msg": L.last_error()}
             if rc == 0:
