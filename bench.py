@@ -119,16 +119,28 @@ def setup(args):
 PREHEAT = {"seconds": 0.0}
 
 
-def preheat(step):
-    """Untimed steps for --preheat-seconds (steady clock / power state of the package); every rank does the same."""
+def preheat(step, e=None):
+    """Untimed steps for about --preheat-seconds (steady clock / power state of the package).  The step COUNT is agreed between the
+    ranks (a step may contain a collective: every rank must run the same number): 8 probe steps, the slowest rank's time decides."""
     import torch
     if PREHEAT["seconds"] <= 0:
         return
-    t_end = time.perf_counter() + PREHEAT["seconds"]
-    while time.perf_counter() < t_end:
-        for _ in range(8):
-            step()
-        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    per = max((time.perf_counter() - t0) / 8, 1e-6)
+    if e is not None and e.world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([per], device=e.dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        per = float(tt.item())
+    n = int(min(max(PREHEAT["seconds"] / per - 8, 0), 20000))
+    for i in range(n):
+        step()
+        if i % 64 == 63:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
 
 
 def timed(e, step, warmup, steps, return_local=False):
@@ -198,7 +210,7 @@ def run_inference(args, e):
             return model(R, False, True)
     step()
     ctx = model.mlp.native(e.dev)
-    preheat(step)
+    preheat(step, e)
     for _ in range(args.warmup):
         step()
     ctx.set_option(2, 1)      # HIP events around every MLP launch of the timed region (on the launch stream)
@@ -305,7 +317,7 @@ def run_train(args, e):
             sch["scheduler"].step()
             return [(loss.detach().reshape(1),)]
     step()
-    preheat(step)
+    preheat(step, e)
     if graphed:
         gstep.allreduce_stats()                              # drop the events of the first (capturing) step
     dt, out, dt_local = timed(e, step, args.warmup, args.steps, return_local=True)
