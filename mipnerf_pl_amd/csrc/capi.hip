@@ -1198,7 +1198,7 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
             return rc;
         }
         if (c->time_mlp == 1) HIP_TRY(hipEventRecord(e1, S(stream)));
-        if (c->fuse_small && lvl + 1 < cfg.num_levels && N <= 128) {
+        if (c->fuse_small && lvl + 1 < cfg.num_levels && (N <= 128 || (N > 192 && N <= 256))) {
             // compositing of this level + the next level's fence posts in one launch (weights go registers -> LDS, not through HBM)
             const mipnerf_level_out& nx = out[lvl + 1];
             if (!nx.t_samples) return fail(MIPNERF_E_INVALID, "forward: output pointer of level %d is null", lvl + 1);

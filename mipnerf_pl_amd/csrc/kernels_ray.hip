@@ -569,7 +569,8 @@ hipError_t launch_composite_resample(int64_t B, int N, const float* rgb_sigma, c
     switch (K) {      // the same K buckets as the stand-alone kernels use, so both routes give the same bits
         case 1: MIP_CR(1); break;
         case 2: MIP_CR(2); break;
-        default: return hipErrorNotSupported;       // other sizes: the caller launches the two kernels
+        case 4: MIP_CR(4); break;                   // N in (192, 256]: both stand-alone kernels use K = 4 there too
+        default: return hipErrorNotSupported;       // K = 3, 5..8: the stand-alone kernels use different K buckets -> two launches
     }
 #undef MIP_CR
     return hipGetLastError();
