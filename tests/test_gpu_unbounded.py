@@ -172,3 +172,7 @@ def test_unbounded_model_trains_in_fp32(G):
     img_rays = type(rays)(*[x.reshape(1, 6, 8, -1) for x in rays])
     c_rgb, f_rgb, _ = system.render_image((img_rays, torch.zeros(1, 6, 8, 3, device=DEV)))
     assert f_rgb.shape == (1, 6, 8, 3) and bool(torch.isfinite(f_rgb).all())
+    # ... and replayed from one captured hipGraph (model.GraphedFrame) it gives the same frame
+    system.enable_hip_graph(True)
+    c2, f2, _ = system.render_image((img_rays, torch.zeros(1, 6, 8, 3, device=DEV)))
+    assert torch.equal(f2, f_rgb) and torch.equal(c2, c_rgb)
