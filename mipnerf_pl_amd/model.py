@@ -447,9 +447,10 @@ class MipNerf(torch.nn.Module):
                 off += p.numel()
         return scalars, ret
 
-    def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None, density_randn=None, out=None):
+    def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None, density_randn=None, out=None, ws=None):
         """`out` (optional): preallocated per-level tuples (comp_rgb, distance, acc, weights, t_samples) to write into
-        (contiguous fp32 HIP tensors of the right shapes) instead of fresh tensors."""
+        (contiguous fp32 HIP tensors of the right shapes) instead of fresh tensors.  `ws` (optional): a private workspace
+        (uint8, >= mipnerf_workspace_bytes) for a caller that keeps several forwards in flight on different streams."""
         dev = rays.origins.device
         B, N = rays.origins.shape[0], self.num_samples
         ctx = self.mlp.native(dev)
@@ -476,7 +477,8 @@ class MipNerf(torch.nn.Module):
             outs[lvl] = L.LevelOut(comp_rgb.data_ptr(), distance.data_ptr(), acc.data_ptr(), weights.data_ptr(),
                                    t_samples.data_ptr())
             ret.append((comp_rgb, distance, acc, weights, t_samples))
-        ws = ctx.workspace(B)
+        if ws is None:
+            ws = ctx.workspace(B)
         flags = L.FLAG_WHITE_BKGD if white_bkgd else 0
         dz = self._density_randn(randomized, B, dev, density_randn)     # mip_nerf.py:232-233
         L.check(L.lib().mipnerf_forward(ctx.handle, B, C.byref(rp), t_rand.data_ptr() if randomized else None,
@@ -490,10 +492,14 @@ class GraphedFrame:
     79 chunk forwards, ~20 kernels each): every chunk launch reads its slice of a static full-frame ray buffer and writes its
     slice of static full-frame outputs, so a frame is 7 ray copies + one graph launch -- no per-chunk copies, clones or
     Python.  `__call__(rays)` takes flattened [n, k] rays and returns (coarse_rgb [n,3], fine_rgb [n,3], distance [n])
-    views of the static outputs (valid until the next call)."""
+    views of the static outputs (valid until the next call).
+    `lanes` (default 2, env MIPNERF_FRAME_LANES): the chunks are independent, so the capture forks into that many streams that
+    take the chunks round-robin, each with its own workspace and per-sample scratch: the small kernels and the kernel boundaries
+    of one lane run while the other lane's MLP kernel owns the CUs."""
 
-    def __init__(self, model: "MipNerf", num_rays: int, chunk: int, white_bkgd: bool, device: torch.device):
+    def __init__(self, model: "MipNerf", num_rays: int, chunk: int, white_bkgd: bool, device: torch.device, lanes: Optional[int] = None):
         self.model, self.n, self.chunk, self.white_bkgd, self.dev = model, int(num_rays), int(chunk), bool(white_bkgd), device
+        self.lanes = max(1, int(lanes if lanes is not None else os.environ.get("MIPNERF_FRAME_LANES", "2")))
         self.static_in = Rays(*[torch.zeros(self.n, k, device=device) for k in (3, 3, 3, 1, 1, 1, 1)])
         for k in ("directions", "viewdirs"):
             getattr(self.static_in, k)[:, 2] = 1.0
@@ -508,16 +514,33 @@ class GraphedFrame:
 
     def _run_chunks(self):
         m, N = self.model, self.model.num_samples
-        scratch = {}
-        for lo in range(0, self.n, self.chunk):
-            hi = min(self.n, lo + self.chunk)
+        bounds = [(lo, min(self.n, lo + self.chunk)) for lo in range(0, self.n, self.chunk)]
+        lanes = min(self.lanes, len(bounds))
+        ctx = m.mlp.native(self.dev)
+        need = int(L.lib().mipnerf_workspace_bytes(ctx.handle, min(self.n, self.chunk)))
+        if getattr(self, "_lane_ws", None) is None or len(self._lane_ws) != lanes or self._lane_ws[0].numel() < need:
+            self._lane_ws = [torch.empty(need, dtype=torch.uint8, device=self.dev) for _ in range(lanes)]
+            self._lane_streams = [torch.cuda.Stream(device=self.dev) for _ in range(lanes)] if lanes > 1 else []
+            self._scratch = [dict() for _ in range(lanes)]
+        cur = torch.cuda.current_stream()
+        for s_ in self._lane_streams:            # fork (inside a capture the lanes join the captured graph)
+            s_.wait_stream(cur)
+        for ci, (lo, hi) in enumerate(bounds):
+            lane = ci % lanes
             b = hi - lo
-            if b not in scratch:      # per-sample outputs nobody reads after the chunk: shared by all chunks of that size
+            scratch = self._scratch[lane]
+            if b not in scratch:      # per-sample outputs nobody reads after the chunk: shared by all chunks of that size on this lane
                 scratch[b] = [(torch.empty(b, N, device=self.dev), torch.empty(b, N + 1, device=self.dev)) for _ in range(m.num_levels)]
             out = [(self.rgb[l][lo:hi], self.dist[l][lo:hi], self.acc[l][lo:hi], scratch[b][l][0], scratch[b][l][1])
                    for l in range(m.num_levels)]
-            m._forward_native(Rays(*[x[lo:hi] for x in self.static_in]), False, self.white_bkgd, out=out)
-        self._scratch = scratch
+            rays = Rays(*[x[lo:hi] for x in self.static_in])
+            if lanes > 1:
+                with torch.cuda.stream(self._lane_streams[lane]):
+                    m._forward_native(rays, False, self.white_bkgd, out=out, ws=self._lane_ws[lane])
+            else:
+                m._forward_native(rays, False, self.white_bkgd, out=out, ws=self._lane_ws[0])
+        for s_ in self._lane_streams:            # join
+            cur.wait_stream(s_)
 
     def _capture(self):
         s = torch.cuda.Stream()
