@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--torch-adam", action="store_true", help="train: torch.optim.Adam on per-tensor gradients "
                     "(what the reference configures) instead of the fused flat Adam kernel")
     ap.add_argument("--no-graph", action="store_true", help="render / train: eager launches instead of the captured hipGraph")
-    ap.add_argument("--preheat-seconds", type=float, default=1.0, help="untimed steps for this long BEFORE the W warm-up steps of every "
+    ap.add_argument("--preheat-seconds", type=float, default=3.0, help="untimed steps for this long BEFORE the W warm-up steps of every "
                     "timed region: the package reaches its steady clock / power state (the first tens of steps after an idle period "
                     "run 3-6 %% slower than the sustained rate); reported in config.preheat_seconds, 0 = off")
     ap.add_argument("--ceiling-seconds", type=float, default=1.2, help="all / inference at N=1: seconds per variant of the in-process MFMA "
