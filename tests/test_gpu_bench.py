@@ -108,7 +108,11 @@ if forced:
     res = {}
     for forced in ("0", "1"):
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-        env.update({"MIPNERF_FORCE_COLLECTIVE_PATH": forced, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29653"})
+        import socket
+        with socket.socket() as sk:          # a free port for the 1-rank rendezvous
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env.update({"MIPNERF_FORCE_COLLECTIVE_PATH": forced, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
         assert out.returncode == 0, out.stderr[-3000:]
         res[forced] = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
