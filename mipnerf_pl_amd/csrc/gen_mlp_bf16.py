@@ -64,6 +64,8 @@ VARIANTS = [
     # two view layers (mlp_net_depth_condition = 2, mip_nerf.py:62-69): fp32 forward + GEMM backward (the bf16 stream would need
     # one more ring group of zero padding than the inference generator's tile-to-tile phase allows; bf16 training is one view layer)
     Arch(net_depth_condition=2, bf16_kernels=False),
+    # a 512-wide trunk with a 256-wide view layer (fp32 only: the bf16 kernels hold a layer's activations in registers, <= 256 wide)
+    Arch(net_width=512, net_width_condition=256, bf16_kernels=False),
 ]
 
 
@@ -75,7 +77,7 @@ def _ops_table(plan: Plan, name: str):
         if len(op.segs) == 1:
             segs += ", {0, 0, 0, 0}"
         tiles = ", ".join(f"{{{t.wt}, {t.bt}, {t.row0}, {t.nrows}, {t.ld}}}" for t in op.tiles)
-        assert len(op.tiles) <= 9
+        assert len(op.tiles) <= 17
         kind = 1 if op.name == "head" else (2 if op.out == "rgb" else 0)
         L.append(f"  /* {op.name} */ {{{len(op.segs)}, {{{segs}}}, {len(op.tiles)}, {{{tiles}}}, {op.first_tile}, {fl['x_in']}, {int(op.relu)}, {kind}}},")
     L.append("};")
@@ -104,7 +106,7 @@ def gen_plan_header(plans) -> str:
     L.append("struct SegDesc { int kind, nk, col0, ncols; };            // kind 0 natural, 1 dlayout")
     L.append("struct TileDesc { int wt, bt, row0, nrows, ld; };")
     L.append("// kind 0 hidden, 1 head (last tile = density), 2 colour")
-    L.append("struct OpDesc { int nsegs; SegDesc segs[2]; int ntiles; TileDesc tiles[9]; int first_tile; int xcol_in; int relu; int kind; };")
+    L.append("struct OpDesc { int nsegs; SegDesc segs[2]; int ntiles; TileDesc tiles[17]; int first_tile; int xcol_in; int relu; int kind; };")
     L.append("// ---- every architecture the library was generated for (gen_mlp_bf16.VARIANTS) ----")
     L.append("struct PlanDesc {")
     L.append("    int net_depth, net_width, net_depth_cond, net_width_cond, skip_index, num_rgb, num_density, xyz_dim, view_dim, use_viewdirs;")

@@ -31,7 +31,7 @@ namespace mip {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kF32Waves = 8;
-constexpr int kF32Rounds = 1;   // hidden tiles per wave: widths up to 256 (8 tiles); the thin heads run on the VALU
+constexpr int kF32Rounds = 2;   // hidden tiles per wave: widths up to 512 (16 tiles; a 256-wide layer skips round 1); thin heads: VALU
 
 // TS = samples per workgroup tile: 64 (two 32-sample MFMA halves per weight chunk; every shape whose LDS rows fit: 64 x ldx x 4 B
 // <= 160 KiB) or 32 (one half; wide encodings such as the 672 off-axis features of the unbounded-scene model: half the reuse of

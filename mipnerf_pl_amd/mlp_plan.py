@@ -140,8 +140,9 @@ class Plan:
     @staticmethod
     def build(arch: Arch = None) -> "Plan":
         a = arch or Arch()
-        if a.net_width % TILE or a.net_width_condition % TILE or a.net_width > 256:
-            raise NotImplementedError("MFMA kernels need widths that are multiples of 32 and <= 256")
+        wmax = 256 if a.bf16_kernels else 512      # the bf16 kernels keep a whole layer in registers; the fp32 kernel in LDS
+        if a.net_width % TILE or a.net_width_condition % TILE or a.net_width > wmax or a.net_width_condition > wmax:
+            raise NotImplementedError("MFMA kernels need widths that are multiples of 32 and <= 256 (<= 512 for fp32-only variants)")
         if a.xyz_dim % KSTEP or a.view_dim > 32 or a.num_rgb > 4 or a.num_density != 1:
             raise NotImplementedError("unsupported encoding / head size for the MFMA kernels")
         if a.net_depth >= 2 and (a.net_depth - 1) % a.skip_index == 0 and a.net_depth - 1 > 0:

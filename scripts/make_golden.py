@@ -21,6 +21,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-resample-grad     round 2: stop_resample_grad=False -- loss and gradients with the cross-level path through the PDF sampler
     --only-init              round 2: checksums of the freshly initialised parameters under a fixed torch seed
     --only-grad-options      round 2: training step on a black background, disparity sampling, multiscale loss off, randomized draws replayed
+    --only-variant-cond / --only-variant-wide   round 3: two view layers; a 512-wide trunk (fp32-only architecture variants)
     --only-variant-depth     round 2: a 6-layer trunk with skip_index 3
     --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
     --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
@@ -838,6 +839,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-grad-options" in sys.argv:   # round 2: training step with the other boundary settings
         grad_options_case("train_options_40x64", 40, 64, 6, 40.0, 31, 77)
+        sys.exit(0)
+    if "--only-variant-wide" in sys.argv:   # round 3: a 512-wide trunk / 256-wide view layer (fp32-only architecture variant)
+        variant_case("var_w512_24x64", 24, 64, param_seed=25, gain=20.0, ray_seed=25, mlp_net_width=512, mlp_net_width_condition=256)
         sys.exit(0)
     if "--only-variant-cond" in sys.argv:   # round 3: two view layers (mlp_net_depth_condition = 2; 26 parameter tensors)
         variant_case("var_dc2_48x64", 48, 64, 10, 40.0, 20, mlp_net_depth_condition=2)

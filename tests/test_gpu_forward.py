@@ -452,3 +452,45 @@ def test_two_view_layers_variant_fp32(G):
     with pytest.raises(NotImplementedError):
         with torch.no_grad():
             bm(rays, False, True)
+
+
+def test_wide_trunk_variant_fp32(G):
+    """mlp_net_width = 512, mlp_net_width_condition = 256 (wider than the bf16 kernels' register-resident 256): an fp32-only
+    architecture variant -- `k_mlp_f32` with two tile rounds per wave and 32-sample tiles, fp32 GEMM backward; forward and the
+    training step's loss / gradients against the reference's golden."""
+    from mipnerf_pl_amd import MipNerf
+    from mipnerf_pl_amd.system import MipNeRFSystem, DEFAULT_HPARAMS
+    g = G.load_golden("var_w512_24x64")
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]), net_width=512, net_width_condition=256)
+    model = G.make_model(params, int(g["num_samples"]), "fp32", mlp_net_width=512, mlp_net_width_condition=256)
+    rays = G.to_dev(G.rays_of(g))
+    with torch.no_grad():
+        ret = model(rays, False, True)
+    errs = {}
+    for lvl in range(2):
+        for nm, val in zip(G.NAMES, ret[lvl]):
+            errs[f"l{lvl}_{nm}"] = G.maxdiff(val, g[f"wb1_l{lvl}_{nm}"])
+            assert errs[f"l{lvl}_{nm}"] <= G.TOL_FP32[nm], (lvl, nm, errs)
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({'nerf.num_samples': int(g["num_samples"]), 'train.randomized': False, 'nerf.mlp.net_width': 512,
+               'nerf.mlp.net_width_condition': 256})
+    system = MipNeRFSystem(hp, precision="fp32")
+    system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    system = system.to(G.DEV)
+    loss = system.training_step((rays, torch.from_numpy(g["gt"]).to(G.DEV)), 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-5 * max(1.0, float(g["loss"]))
+    worst = 0.0
+    for k, p in system.mip_nerf.mlp.named_parameters():
+        grad = p.grad.detach().cpu().numpy().ravel()
+        l2 = float(g["g_l2_" + k])
+        stride = max(1, grad.size // 64)
+        scale = max(float(np.abs(g["g_smp_" + k]).max()), l2 / np.sqrt(grad.size), 1e-12)
+        err = float(np.max(np.abs(grad[::stride][:64] - g["g_smp_" + k]))) / scale
+        worst = max(worst, err)
+        assert abs(float(np.sqrt((grad.astype(np.float64) ** 2).sum())) - l2) <= 2e-3 * max(l2, 1e-9), k
+        assert err <= 5e-3, (k, err)
+    G.record("variant var_w512_24x64 fp32", worst_grad_rel=worst, **errs)
+    with pytest.raises(NotImplementedError):
+        with torch.no_grad():
+            MipNerf(num_samples=int(g["num_samples"]), mlp_net_width=512, mlp_net_width_condition=256, precision="bf16").to(G.DEV)(rays, False, True)
