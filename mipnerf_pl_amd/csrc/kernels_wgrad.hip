@@ -24,6 +24,12 @@ constexpr int kStages = 4;
 constexpr int kStageBytes = 16 * 2048;       // [8 activation blocks | 8 delta blocks] x 2 KiB
 constexpr int kWgradLds = kStages * kStageBytes;
 
+// Every saved-activation / delta block is read exactly once per job: MLP_WGRAD_NT=1 (build knob) marks the stream non-temporal
+#if defined(MIP_WGRAD_NT) && MIP_WGRAD_NT
+#define MIP_WGRAD_LOAD_POLICY " nt"
+#else
+#define MIP_WGRAD_LOAD_POLICY ""
+#endif
 // two 1-KiB DMAs: global (uniform base + lane*16, +1024) -> LDS (uniform dst, +1024)
 __device__ __forceinline__ void dma_block(const char* gbase, char* lbase, unsigned lane16) {
     const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lbase;
@@ -32,8 +38,8 @@ __device__ __forceinline__ void dma_block(const char* gbase, char* lbase, unsign
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2" MIP_WGRAD_LOAD_POLICY "\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024" MIP_WGRAD_LOAD_POLICY "\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(lane16), "s"(gbase), "s"(lds_addr)

@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+A=$GRAFT_REPO_ROOT/mipnerf_pl_amd/csrc/libmipnerf_hip.so
+B=$GRAFT_REPO_ROOT/mipnerf_pl_amd/csrc/libmipnerf_hip_wnt.so
+for round in 1 2 3; do for so in $A $B; do
+  echo -n "$(basename $so): "; MIPNERF_LIB=$so timeout 200 python bench.py --mode train --steps 60 --warmup 5 --no-cpu-baseline --preheat-seconds 1.5 2>/dev/null | python -c "import sys,json; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(l['ms_per_step'])"
+done; done 2>&1 | tee gpurun_out/r03p_wgrad_nt_ab.log
+MIPNERF_LIB=$B timeout 300 python -m pytest tests/test_gpu_train.py -m gpu -q -k "native_mlp_backward or native_train_step" 2>&1 | tail -2
