@@ -16,6 +16,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--samples", type=int, default=128)
 ap.add_argument("--heat", type=float, default=0.0, help="seconds of untimed forwards first")
+ap.add_argument("--grid", type=int, default=0, help="persistent workgroups of the MLP kernel (option 1; default = CUs)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 params = syn.make_params(seed=0, density_gain=40.0)
@@ -23,6 +24,8 @@ m = MipNerf(num_samples=a.samples, precision="bf16")
 m.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
 m = m.to(dev)
 R = Rays(*[torch.from_numpy(x).to(dev) for x in syn.synthetic_rays(a.rays, seed=100)])
+if a.grid:
+    m.mlp.native(dev).set_option(1, a.grid)
 with torch.no_grad():
     m(R, False, True)
     t_end = time.perf_counter() + a.heat
@@ -44,4 +47,4 @@ tot, nl = C.c_double(), C.c_int64()
 L.check(L.lib().mipnerf_mlp_launch_stats(ctx.handle, C.byref(tot), C.byref(nl)))
 lm = tot.value / max(nl.value, 1)
 print(f"forward {a.rays}x{a.samples}: {dt * 1e3:.4f} ms/step, MLP launch {lm:.4f} ms = {1220608 * a.rays * a.samples / (lm * 1e-3) / 1e12:.1f} TFLOP/s "
-      f"({os.path.basename(os.environ.get('MIPNERF_LIB', 'libmipnerf_hip.so'))}) checksum {float(out[1][0].double().sum()):.9f}")
+      f"({os.path.basename(os.environ.get('MIPNERF_LIB', 'libmipnerf_hip.so'))}, grid {a.grid or 'CUs'}) checksum {float(out[1][0].double().sum()):.9f}")
