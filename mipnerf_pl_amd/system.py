@@ -152,6 +152,11 @@ class MipNeRFSystem(_Base):
         self._optimizer_for_log = optimizer
         return [optimizer], [{'scheduler': scheduler, 'interval': 'step'}]
 
+    def lr_scheduler_step(self, scheduler, *args):
+        """Lightning hook (signature differs between 1.x and 2.x: optimizer_idx / metric): the schedules returned above are step-wise
+        torch LRSchedulers, so stepping them is all there is to do -- stated explicitly so that no Lightning version has to guess."""
+        scheduler.step()
+
     def train_dataloader(self):   # nerf_system.py:78-83: shuffled batches of `train.batch_size` rays, drawn on the device
         from .datasets import RayLoader
         return RayLoader(self.train_dataset, batch_size=self.hparams['train.batch_size'], shuffle=True)
