@@ -214,6 +214,7 @@ struct mipnerf_ctx {
     // training (bf16): W^T stream of the dgrad kernel, wgrad job tables
     TrainTables tt;
     int32_t* d_pack_dgrad = nullptr;
+    int32_t* d_pack_extraT = nullptr;   // index table of W_extra^T (the transpose as a gather, so it joins the one pack launch)
     void* d_stream_dgrad = nullptr;
     mip::WgradJob* d_jobs = nullptr;
     int32_t* d_otab = nullptr;
@@ -404,7 +405,13 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         chk(hipMalloc(&c->d_jobslots, (size_t)tt.njobs * sizeof(int2)));
         chk(hipMalloc(&c->d_scratch, (size_t)(tt.n_scratch > 0 ? tt.n_scratch : 1) * 4));
         chk(hipMalloc(&c->d_extra_wT, (size_t)P->net_width * P->net_width * 4));
+        const int Wn = P->net_width, t_extra = 2 * P->net_depth + 2;
+        std::vector<int32_t> e_xt((size_t)Wn * Wn);
+        for (int i = 0; i < Wn; ++i)
+            for (int j = 0; j < Wn; ++j) e_xt[(size_t)i * Wn + j] = (int32_t)((t_extra << 20) | (j * Wn + i));     // out[i][j] = W[j][i]
+        chk(hipMalloc(&c->d_pack_extraT, e_xt.size() * 4));
         if (er == hipSuccess) {
+            chk(hipMemcpy(c->d_pack_extraT, e_xt.data(), e_xt.size() * 4, hipMemcpyHostToDevice));
             chk(hipMemcpy(c->d_pack_dgrad, e_dg.data(), e_dg.size() * 4, hipMemcpyHostToDevice));
             chk(hipMemcpy(c->d_jobs, tt.jobs, (size_t)tt.njobs * sizeof(mip::WgradJob), hipMemcpyHostToDevice));
             chk(hipMemcpy(c->d_otab, tt.otab, (size_t)tt.njobs * tt.job_floats * 4, hipMemcpyHostToDevice));
@@ -428,6 +435,7 @@ int mipnerf_destroy(mipnerf_ctx* c) {
     (void)hipFree(c->d_stream_bf16); (void)hipFree(c->d_stream_f32); (void)hipFree(c->d_bias);
     (void)hipFree(c->d_pack_dgrad); (void)hipFree(c->d_stream_dgrad); (void)hipFree(c->d_jobs); (void)hipFree(c->d_otab);
     (void)hipFree(c->d_wgtab); (void)hipFree(c->d_jobslots); (void)hipFree(c->d_scratch); (void)hipFree(c->d_extra_wT);
+    (void)hipFree(c->d_pack_extraT);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
     return MIPNERF_OK;
@@ -457,13 +465,23 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
         pp.p[i] = params_host[i];
     }
     const int64_t nst = (int64_t)P.num_chunks * 512;
-    HIP_TRY(mip::launch_pack(c->d_pack_bf16, nst, pp, c->d_stream_bf16, true, S(stream)));
-    HIP_TRY(mip::launch_pack(c->d_pack_f32, nst, pp, c->d_stream_f32, false, S(stream)));
-    HIP_TRY(mip::launch_pack(c->d_bias_idx, (int64_t)P.num_tiles * 32, pp, c->d_bias, false, S(stream)));
+    // every stream of the context in ONE launch: bf16 stream, fp32 stream, bias table, and for the trainable variants the
+    // transposed (dgrad) stream and W_extra^T (a gather through an index table like the others)
+    mip::PackSegments sg;
+    memset(&sg, 0, sizeof sg);
+    auto add = [&](const int32_t* table, int64_t n, void* out, bool bf16) {
+        sg.table[sg.n] = table; sg.out[sg.n] = out; sg.bf16[sg.n] = bf16 ? 1 : 0;
+        sg.start[sg.n + 1] = sg.start[sg.n] + n;
+        ++sg.n;
+    };
+    add(c->d_pack_bf16, nst, c->d_stream_bf16, true);
+    add(c->d_pack_f32, nst, c->d_stream_f32, false);
+    add(c->d_bias_idx, (int64_t)P.num_tiles * 32, c->d_bias, false);
     if (has_bf16_train(&P)) {
-        HIP_TRY(mip::launch_pack(c->d_pack_dgrad, (int64_t)c->tt.n_bchunks * 512, pp, c->d_stream_dgrad, true, S(stream)));
-        HIP_TRY(mip::launch_transpose_sq(P.net_width, pp.p[2 * P.net_depth + 2], c->d_extra_wT, S(stream)));
+        add(c->d_pack_dgrad, (int64_t)c->tt.n_bchunks * 512, c->d_stream_dgrad, true);
+        add(c->d_pack_extraT, (int64_t)P.net_width * P.net_width, c->d_extra_wT, false);
     }
+    HIP_TRY(mip::launch_pack_multi(sg, pp, S(stream)));
     c->pp = pp;
     c->params_set = true;
     return MIPNERF_OK;
@@ -1045,12 +1063,20 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
     const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
     // ---- forward (mip_nerf.py:182-246), activations saved for the backward -------------------------------------------
-    if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, MIPNERF_PREC_BF16, stream))) return rc;
+    // option 4 (fuse_small): pos_enc + coarse fence posts in one launch; per level compositing + distloss (+ the next level's
+    // fence posts) in one launch instead of three -- same per-ray device functions, same bits
+    const bool fuse_tail = c->fuse_small && (N <= 128 || (N > 192 && N <= 256));
+    if (c->fuse_small) {
+        HIP_TRY(mip::launch_ray_prologue(B, cfg.deg_view, rays->viewdirs, viewenc, 32, true, N, rays->near, rays->far, t_rand, disparity,
+                                         lv[0].t, S(stream)));
+    } else if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, MIPNERF_PREC_BF16, stream))) {
+        return rc;
+    }
     for (int l = 0; l < L; ++l) {
         const float* dnoise = density_randn ? density_randn + (size_t)l * M : nullptr;      // this level's draws (mip_nerf.py:232-233)
         if (l == 0) {
-            if ((rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, lv[0].t, stream))) return rc;
-        } else {
+            if (!c->fuse_small && (rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, lv[0].t, stream))) return rc;
+        } else if (!fuse_tail) {
             if ((rc = mipnerf_resample_along_rays(B, N, lv[l - 1].t, lv[l - 1].w, u_rand, cfg.resample_padding, lv[l].t, stream))) return rc;
         }
         if (c->fused_ipe && max_deg_span_is_16(cfg)) {      // encoding computed inside the forward-with-save kernel
@@ -1064,10 +1090,16 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
             if ((rc = mlp_forward_train_noise(c, (int64_t)M, N, lv[l].enc, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act,
                                               lv[l].masks, dnoise, stream))) return rc;
         }
-        if ((rc = mipnerf_volumetric_rendering(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].rgb, lv[l].dist,
-                                               lv[l].acc, lv[l].w, stream))) return rc;
         // distloss (mip.py:8-20) forward AND backward in one pass: d loss / d ray_loss is the constant k_l * dm / B
         const float k = (L > 1 && l == 0) ? coarse_loss_mult : 1.0f;
+        if (fuse_tail) {
+            HIP_TRY(mip::launch_composite_train(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].rgb, lv[l].dist, lv[l].acc,
+                                                lv[l].w, lv[l].ray_loss, k * distloss_mult / (float)B, lv[l].d_w, u_rand,
+                                                cfg.resample_padding, l + 1 < L ? lv[l + 1].t : nullptr, S(stream)));
+            continue;
+        }
+        if ((rc = mipnerf_volumetric_rendering(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].rgb, lv[l].dist,
+                                               lv[l].acc, lv[l].w, stream))) return rc;
         HIP_TRY(mip::launch_distloss(B, N, lv[l].w, lv[l].t, lv[l].ray_loss, nullptr, k * distloss_mult / (float)B, lv[l].d_w,
                                      S(stream)));
     }

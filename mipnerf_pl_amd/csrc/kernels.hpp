@@ -26,6 +26,9 @@ hipError_t launch_cast_ipe(int64_t B, int N, int min_deg, int max_deg, int disab
 hipError_t launch_integrated_pos_enc(int64_t M, int min_deg, int max_deg, const float* means, const float* covs,
                                      void* enc, bool bf16, hipStream_t st);
 hipError_t launch_pos_enc(int64_t B, int deg, const float* viewdirs, void* out, int ld, bool bf16, hipStream_t st);
+hipError_t launch_composite_train(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs, int white_bkgd,
+                                  float* comp_rgb, float* distance, float* acc, float* weights, float* ray_loss, float g_const,
+                                  float* d_w, const float* u_rand, float padding, float* t_new, hipStream_t st);   // hipErrorNotSupported: K not in {1,2,4}
 hipError_t launch_composite_resample(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs, int white_bkgd,
                                      float* comp_rgb, float* distance, float* acc, float* weights, const float* bins,
                                      const float* u_rand, float padding, float* t_new, hipStream_t st);   // hipErrorNotSupported: N > 128
@@ -193,6 +196,15 @@ struct ParamPtrs {
 };
 // table entry: -1 => 0, else (tensor << 20) | element offset
 hipError_t launch_pack(const int32_t* table, int64_t n, const ParamPtrs& ptrs, void* out, bool bf16, hipStream_t st);
+constexpr int kMaxPackSegments = 6;
+struct PackSegments {              // several (table -> stream) packs as one launch
+    int n;
+    int64_t start[kMaxPackSegments + 1];
+    const int32_t* table[kMaxPackSegments];
+    void* out[kMaxPackSegments];
+    int bf16[kMaxPackSegments];
+};
+hipError_t launch_pack_multi(const PackSegments& sg, const ParamPtrs& ptrs, hipStream_t st);
 
 // ---- kernels_eval.hip ---------------------------------------------------------------------------
 int64_t eval_errors_partial_floats(int H, int W);

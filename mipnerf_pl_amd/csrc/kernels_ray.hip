@@ -9,50 +9,9 @@
 
 #include "kernels.hpp"
 #include "raymath.hpp"
+#include "raywave.hpp"
 
 namespace mip {
-
-// ------------------------------------------------------------------------------------------
-// wave64 helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// exclusive prefix sum across the 64 lanes; *total = sum over all lanes
-__device__ __forceinline__ float wave_excl_scan(float v, int lane, float* total) {
-    float inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const float n = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += n;
-    }
-    *total = __shfl(inc, 63, 64);
-    const float ex = __shfl_up(inc, 1, 64);
-    return lane == 0 ? 0.0f : ex;
-}
-
-// double-precision variants: torch's CPU cumsum accumulates float32 in double
-// (at::acc_type<float,false>), and the inverse-CDF / transmittance are sensitive to the prefix sums
-// (a 1e-7 error of the CDF moves a resampled t by 1e-5 where the pdf is ~5e-4), so the scans run in
-// fp64 -- a few dozen DP adds per ray on a chip with full-rate fp64.
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_excl_scan_f64(double v, int lane) {
-    double inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double n = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += n;
-    }
-    const double ex = __shfl_up(inc, 1, 64);
-    return lane == 0 ? 0.0 : ex;
-}
 
 // ------------------------------------------------------------------------------------------
 // sample_along_rays, t part (models/mip.py:143-163)
@@ -222,61 +181,6 @@ k_pos_enc(int64_t B, int deg, const float* __restrict__ viewdirs, OutT* __restri
 // Lane l owns the K = ceil(N/64) consecutive samples [l*K, l*K+K): a local running sum plus
 // one wave-wide exclusive scan gives the exclusive cumsum of sigma*delta.
 // ------------------------------------------------------------------------------------------
-// The per-ray bodies are device functions shared by the stand-alone kernels and by the fused k_composite_resample (one launch
-// for "composite level 0, then draw the fine level's fence posts from its weights": same arithmetic, same order, same bits).
-template <int K>
-__device__ __forceinline__ void composite_ray(bool active, int lane, int N, const float4* __restrict__ cb, const float* __restrict__ tb,
-                                              float dn, int white_bkgd, float* __restrict__ comp_rgb_b, float* __restrict__ distance_b,
-                                              float* __restrict__ acc_b, float* __restrict__ weights_b, float (&w_out)[K]) {
-    const int i0 = lane * K;
-    float tv[K + 1];
-#pragma unroll
-    for (int k = 0; k <= K; ++k) tv[k] = (i0 + k <= N) ? tb[i0 + k] : 0.0f;
-    float4 c[K];
-    float dd[K];
-    double pre[K];
-    double run = 0.0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const bool ok = i0 + k < N;
-        c[k] = ok ? cb[i0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float delta = (tv[k + 1] - tv[k]) * dn;
-        dd[k] = ok ? c[k].w * delta : 0.0f;   // density_delta
-        pre[k] = run;
-        run += (double)dd[k];
-    }
-    const double off = wave_excl_scan_f64(run, lane);
-
-    float sr = 0.f, sg = 0.f, sb = 0.f, sa = 0.f, sd = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const bool ok = i0 + k < N;
-        const float alpha = 1.0f - expf(-dd[k]);
-        const float trans = expf(-(float)(off + pre[k]));   // exclusive cumsum rounded to fp32 like torch
-        const float w = ok ? alpha * trans : 0.0f;
-        w_out[k] = w;
-        if (ok && active && weights_b) weights_b[i0 + k] = w;
-        sr += w * c[k].x;
-        sg += w * c[k].y;
-        sb += w * c[k].z;
-        sa += w;
-        sd += w * (0.5f * (tv[k] + tv[k + 1]));
-    }
-    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sa = wave_sum(sa); sd = wave_sum(sd);
-    if (lane == 0 && active) {
-        const float tnear = tb[0], tfar = tb[N];
-        float dist = nan_to_num(sd);
-        dist = fminf(fmaxf(dist, tnear), tfar);   // torch.clamp(x, min, max) = min(max(x,min),max)
-        if (white_bkgd) {
-            const float bg = 1.0f - sa;
-            sr += bg; sg += bg; sb += bg;
-        }
-        comp_rgb_b[0] = sr; comp_rgb_b[1] = sg; comp_rgb_b[2] = sb;
-        *distance_b = dist;
-        *acc_b = sa;
-    }
-}
-
 template <int K>
 __global__ void __launch_bounds__(256)
 k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
@@ -293,95 +197,7 @@ k_volumetric_rendering(int64_t B, int N, const float4* __restrict__ rgb_sigma,
                      acc_out + b, weights + b * (int64_t)N, w);
 }
 
-// ------------------------------------------------------------------------------------------
-// resample_along_rays t part (models/mip.py:232-280) and sorted_piecewise_constant_pdf
-// (models/mip.py:168-229).  One wavefront per ray; the ray's CDF and bins live in LDS; each
-// lane inverts the CDF for its draws with a binary search (torch.searchsorted right=True).
-//   BLUR = true : weights are blur-pooled and `padding` added first (resample path)
-//   BLUR = false: weights used as given
-// ------------------------------------------------------------------------------------------
-constexpr int kPdfMaxBins = 512;      // N <= 512
-constexpr int kRaysPerBlock = 4;
-
-// s_w / s_bins hold the ray's weights [N] and bins [N+1] (staged by the caller, block barrier done); every wave of the block
-// must call this (it contains block barriers); out_row = nullptr: no stores (a wave shadowing the last ray)
-template <int K, bool BLUR>
-__device__ __forceinline__ void pdf_ray(int lane, int N, const float* __restrict__ s_w, float* __restrict__ s_cdf,
-                                        const float* __restrict__ s_bins, int n_draws, const float* __restrict__ u_row,
-                                        float padding, float u_step, float u_jitter, float* __restrict__ out_row) {
-    const int i0 = lane * K;
-    float w[K];
-    double run = 0.0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int i = i0 + k;
-        float v = 0.0f;
-        if (i < N) {
-            if (BLUR) {
-                // weights_pad = [w0, w, w_{N-1}]; max of neighbours; mean of neighbours (mip.py:252-254)
-                const float wc = s_w[i];
-                const float wl = s_w[i > 0 ? i - 1 : 0];
-                const float wr = s_w[i < N - 1 ? i + 1 : N - 1];
-                v = 0.5f * (fmaxf(wl, wc) + fmaxf(wc, wr)) + padding;
-            } else {
-                v = s_w[i];
-            }
-        }
-        w[k] = v;
-        run += (double)v;
-    }
-    // eps padding so the sum is >= 1e-5 (mip.py:181-185)
-    float wsum = (float)wave_sum_f64(run);
-    const float pad = fmaxf(0.0f, 1e-5f - wsum);
-    const float padn = pad / (float)N;
-    wsum += pad;
-    double pre[K];
-    run = 0.0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int i = i0 + k;
-        const float pdf = (i < N) ? (w[k] + padn) / wsum : 0.0f;
-        pre[k] = run;
-        run += (double)pdf;
-    }
-    const double off = wave_excl_scan_f64(run, lane);
-    // cdf = [0, min(1, cumsum(pdf[:-1])), 1]  (mip.py:190-195): cdf[i] = min(1, sum_{j<i} pdf_j)
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int i = i0 + k;
-        if (i < N) s_cdf[i] = (i == 0) ? 0.0f : fminf(1.0f, (float)(off + pre[k]));
-    }
-    if (lane == 0) s_cdf[N] = 1.0f;
-    __syncthreads();
-
-    const float eps32 = 1.1920928955078125e-07f;
-    const float umax = 1.0f - eps32;
-    for (int j = lane; j < n_draws; j += 64) {
-        float u;
-        if (u_row != nullptr) {
-            // u = arange*s + U[0, s-eps), clipped to 1-eps (mip.py:198-204)
-            u = (float)j * u_step + u_row[j] * u_jitter;
-            u = fminf(u, umax);
-        } else {
-            u = torch_linspace_at(0.0f, umax, n_draws, j);   // mip.py:207
-        }
-        // searchsorted(cdf, u, right=True): number of entries <= u, over cdf[0..N]
-        int lo = 0, hi = N + 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_cdf[mid] <= u) lo = mid + 1; else hi = mid;
-        }
-        const int below = max(0, lo - 1);
-        const int above = min(N, lo);
-        const float c0 = s_cdf[below], c1 = s_cdf[above];
-        const float b0 = s_bins[below], b1 = s_bins[above];
-        float denom = c1 - c0;
-        denom = (denom < 1e-5f) ? 1.0f : denom;
-        const float tt = (u - c0) / denom;
-        if (out_row) out_row[j] = b0 + tt * (b1 - b0);
-    }
-}
-
+// (the sampler's per-ray body pdf_ray and its constants live in raywave.hpp)
 template <int K, bool BLUR>
 __global__ void __launch_bounds__(64 * kRaysPerBlock)
 k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const float* __restrict__ weights,

@@ -7,6 +7,7 @@
 
 #include "kernels.hpp"
 #include "raymath.hpp"
+#include "raywave.hpp"
 
 namespace mip {
 
@@ -178,69 +179,83 @@ k_distloss(int64_t B, int N, const float* __restrict__ weights, const float* __r
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
-    const float* tb = t + b * (int64_t)(N + 1);
     const float* wb = weights + b * (int64_t)N;
     const int i0 = lane * K;
-    float w[K], m[K], iv[K];
-    double pP[K], pQ[K];
-    double rP = 0.0, rQ = 0.0, uni = 0.0;
+    float w[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const bool ok = i0 + k < N;
-        const float t0 = ok ? tb[i0 + k] : 0.f, t1 = ok ? tb[i0 + k + 1] : 0.f;
-        w[k] = ok ? wb[i0 + k] : 0.f;
-        m[k] = (t1 + t0) * 0.5f;
-        iv[k] = t1 - t0;
-        pP[k] = rP; pQ[k] = rQ;
-        rP += (double)w[k];
-        rQ += (double)w[k] * (double)m[k];
-        uni += (double)(iv[k] * w[k] * w[k]);
-    }
-    const double oP = wexcl_prefix64(rP, lane), oQ = wexcl_prefix64(rQ, lane);
-    const double totP = wsum64(rP), totQ = wsum64(rQ);
-    double bi = 0.0;
+    for (int k = 0; k < K; ++k) w[k] = i0 + k < N ? wb[i0 + k] : 0.f;
+    distloss_ray<K>(lane, N, w, t + b * (int64_t)(N + 1), ray_loss ? ray_loss + b : nullptr, g_ray ? g_ray[b] : g_const,
+                    d_w ? d_w + b * (int64_t)N : nullptr, d_t ? d_t + b * (int64_t)(N + 1) : nullptr);
+}
+
+// The ray-side tail of one level of the TRAINING forward in one launch: volumetric_rendering (weights stay in registers), the
+// distortion loss forward + backward on those weights (d loss / d ray_loss is a constant), and -- for every level but the last --
+// the next level's fence posts from the blurred weights (RESAMPLE).  Same per-ray device functions as k_volumetric_rendering,
+// k_distloss and k_piecewise_constant_pdf<K, true>: same bits.  mipnerf_train_step ran those as three launches per level.
+template <int K, bool RESAMPLE>
+__global__ void __launch_bounds__(64 * kRaysPerBlock)
+k_composite_train(int64_t B, int N, const float4* __restrict__ rgb_sigma, const float* __restrict__ t, const float* __restrict__ dirs,
+                  int white_bkgd, float* __restrict__ comp_rgb, float* __restrict__ distance, float* __restrict__ acc_out,
+                  float* __restrict__ weights, float* __restrict__ ray_loss, float g_const, float* __restrict__ d_w,
+                  const float* __restrict__ u_rand, float padding, float u_step, float u_jitter, float* __restrict__ t_new) {
+    __shared__ float s_w[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? kPdfMaxBins + 2 : 1];
+    __shared__ float s_cdf[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? kPdfMaxBins + 2 : 1];
+    __shared__ float s_bins[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? kPdfMaxBins + 2 : 1];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * kRaysPerBlock + wv;
+    const bool active = b < B;
+    if (!RESAMPLE && !active) return;          // no block barriers on this path
+    const int64_t bb = active ? b : B - 1;     // RESAMPLE: inactive waves shadow the last ray (no stores)
+    const float dx = dirs[bb * 3], dy = dirs[bb * 3 + 1], dz = dirs[bb * 3 + 2];
+    const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float* tb = t + bb * (int64_t)(N + 1);
+    float w[K];
+    composite_ray<K>(active, lane, N, rgb_sigma + bb * (int64_t)N, tb, dn, white_bkgd, comp_rgb + bb * 3, distance + bb, acc_out + bb,
+                     weights + bb * (int64_t)N, w);
+    distloss_ray<K>(lane, N, w, tb, active ? ray_loss + bb : nullptr, g_const, active ? d_w + bb * (int64_t)N : nullptr, nullptr);
+    if (RESAMPLE) {
+        const int i0 = lane * K;
 #pragma unroll
-    for (int k = 0; k < K; ++k) bi += (double)w[k] * ((double)m[k] * (oP + pP[k]) - (oQ + pQ[k]));
-    const double tot = wsum64(uni) / 3.0 + 2.0 * wsum64(bi);
-    if (lane == 0 && ray_loss) ray_loss[b] = (float)tot;
-    if (d_w) {
-        const float g = g_ray ? g_ray[b] : g_const;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (i0 + k < N) {
-                const double P = oP + pP[k], Q = oQ + pQ[k];
-                const double wi = w[k], mi = m[k];
-                // sum_j w_j |m_i - m_j| = m_i P - Q + (Qtot - Q - w_i m_i) - m_i (Ptot - P - w_i)
-                const double sj = mi * P - Q + (totQ - Q - wi * mi) - mi * (totP - P - wi);
-                d_w[b * (int64_t)N + i0 + k] = g * (float)((2.0 / 3.0) * iv[k] * wi + 2.0 * sj);
-            }
-        }
-    }
-    if (d_t) {
-        // interval_i = t_{i+1} - t_i, m_i = (t_i + t_{i+1}) / 2:  dL/dinterval_i = w_i^2 / 3,
-        // dL/dm_i = 2 w_i (sum_{j<i} w_j - sum_{j>i} w_j)  (t sorted)  ->  d_t[i] = (A_{i-1} - A_i) + (C_{i-1} + C_i) / 2
-        const float g = g_ray ? g_ray[b] : g_const;
-        float A[K], C[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const bool ok = i0 + k < N;
-            const double P = oP + pP[k], wi = w[k];
-            A[k] = ok ? g * (float)(wi * wi / 3.0) : 0.f;
-            C[k] = ok ? g * (float)(2.0 * wi * (2.0 * P + wi - totP)) : 0.f;
-        }
-        float pa = __shfl_up(A[K - 1], 1, 64), pc = __shfl_up(C[K - 1], 1, 64);
-        if (lane == 0) { pa = 0.f; pc = 0.f; }
-#pragma unroll
-        for (int k = 0; k <= K; ++k) {
-            const int i = i0 + k;
-            const float ak = k < K ? A[k < K ? k : 0] : 0.f, ck = k < K ? C[k < K ? k : 0] : 0.f;
-            if (i <= N && (k < K || i == N)) d_t[b * (int64_t)(N + 1) + i] = (pa - ak) + 0.5f * (pc + ck);
-            if (k < K) { pa = A[k]; pc = C[k]; }
-        }
+        for (int k = 0; k < K; ++k)
+            if (i0 + k < N) s_w[wv][i0 + k] = w[k];
+        for (int j = lane; j <= N; j += 64) s_bins[wv][j] = tb[j];
+        __syncthreads();
+        const int n_draws = N + 1;
+        pdf_ray<K, true>(lane, N, s_w[wv], s_cdf[wv], s_bins[wv], n_draws, u_rand ? u_rand + bb * (int64_t)n_draws : nullptr, padding, u_step,
+                         u_jitter, active ? t_new + b * (int64_t)n_draws : nullptr);
     }
 }
 
 static inline unsigned gridf(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+hipError_t launch_composite_train(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs, int white_bkgd,
+                                  float* comp_rgb, float* distance, float* acc, float* weights, float* ray_loss, float g_const,
+                                  float* d_w, const float* u_rand, float padding, float* t_new, hipStream_t st) {
+    if (N > kPdfMaxBins || N < 1) return hipErrorInvalidValue;
+    const dim3 grid(gridf(B, kRaysPerBlock)), block(64 * kRaysPerBlock);
+    const float4* c = reinterpret_cast<const float4*>(rgb_sigma);
+    const int n_draws = N + 1;
+    const double s = 1.0 / (double)n_draws;           // as launch_piecewise_constant_pdf
+    const float u_step = (float)s;
+    const float u_jitter = (float)(s - (double)1.1920928955078125e-07f);
+    const int K = (N + 63) / 64;
+#define MIP_CT(KK)                                                                                                                   \
+    do {                                                                                                                             \
+        if (t_new) hipLaunchKernelGGL((k_composite_train<KK, true>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd, comp_rgb, distance, \
+                                      acc, weights, ray_loss, g_const, d_w, u_rand, padding, u_step, u_jitter, t_new);                    \
+        else hipLaunchKernelGGL((k_composite_train<KK, false>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd, comp_rgb, distance, acc, \
+                                weights, ray_loss, g_const, d_w, u_rand, padding, u_step, u_jitter, t_new);                               \
+    } while (0)
+    switch (K) {      // the K buckets all three stand-alone kernels share (1, 2, 4), so the fused route gives the same bits
+        case 1: MIP_CT(1); break;
+        case 2: MIP_CT(2); break;
+        case 4: MIP_CT(4); break;
+        default: return hipErrorNotSupported;
+    }
+#undef MIP_CT
+    return hipGetLastError();
+}
 
 hipError_t launch_activate(int64_t M, const float* raw, float rgb_padding, float density_bias, const float* dnoise,
                            float dnoise_scale, float* out, hipStream_t st) {

@@ -75,8 +75,8 @@ class GraphedTrainStep:
         m, B, N = self.model, self.B, self.N
         t_rand = u_rand = dz = None
         if self.randomized:
-            t_rand = torch.rand(B, N + 1, device=self.dev)          # mip.py:159
-            u_rand = torch.rand(B, N + 1, device=self.dev)          # mip.py:201
+            draws = torch.rand(2, B, N + 1, device=self.dev)        # one launch for both draws
+            t_rand, u_rand = draws[0], draws[1]                     # mip.py:159 / mip.py:201
             if m.density_noise > 0:
                 dz = torch.randn(m.num_levels, B, N, device=self.dev)   # mip_nerf.py:232-233
         flags = L.FLAG_WHITE_BKGD if self.white else 0

@@ -714,3 +714,31 @@ def test_training_step_other_boundary_settings_vs_reference(G):
     for k, p in nsys.mip_nerf.mlp.named_parameters():
         assert G.maxdiff(p.grad, gb[k]) <= 2e-3 * max(1e-6, float(gb[k].abs().max())), k
     G.record("training_step_other_settings", worst_grad_rel_fp32=worst, loss_fp32=l32, loss_bf16=lb, worst_cos_bf16=cos_worst)
+
+
+@pytest.mark.parametrize("B,N,randomized", [(37, 32, True), (50, 64, False), (21, 100, True), (64, 128, True), (9, 256, False), (5, 300, True)])
+def test_native_train_step_fused_tail_equals_per_stage_kernels(G, B, N, randomized):
+    """Round 3: mipnerf_train_step runs pos_enc + the coarse fence posts as one launch and, per level, compositing + distloss
+    (+ the next level's fence posts) as one launch (k_composite_train) instead of three; option 4 = 0 restores one launch per
+    stage.  Same per-ray device functions: loss, every gradient and the returned outputs must be bit-identical."""
+    from mipnerf_pl_amd import MipNerf
+    rays_np = orc.synthetic_rays(B, seed=B + N, multiscale=True)
+    params = orc.make_params(seed=3, density_gain=30.0)
+    rays = G.to_dev(rays_np)
+    gt = torch.rand(B, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(N))
+    gen = torch.Generator(device=DEV).manual_seed(B)
+    t_rand = torch.rand(B, N + 1, device=DEV, generator=gen) if randomized else None
+    u_rand = torch.rand(B, N + 1, device=DEV, generator=gen) if randomized else None
+    res = []
+    for fuse in (1, 0):
+        model = G.make_model(params, N, "bf16")
+        model.mlp.native(torch.device(DEV)).set_option(4, fuse)
+        sc, outs = model.train_step_native(rays, gt, randomized, True, t_rand=t_rand, u_rand=u_rand, return_outputs=True)
+        grads = torch.cat([p.grad.reshape(-1) for p in model.mlp.parameters()]).clone()
+        res.append((sc.clone(), grads, [tuple(x.clone() for x in lv) for lv in outs]))
+    (s1, g1, o1), (s0, g0, o0) = res
+    assert torch.equal(s1, s0), (s1, s0)
+    assert torch.equal(g1, g0)
+    for lvl in range(2):
+        for a, b in zip(o1[lvl], o0[lvl]):
+            assert torch.equal(a, b), lvl
