@@ -122,7 +122,7 @@ class _MLPNative(torch.autograd.Function):
         d_raw = d_raw.contiguous().float()
         delta = nctx.scratch("delta", ctx.sizes[2])
         partials = nctx.scratch("partials", ctx.sizes[3])
-        total = sum(int(torch.Size(s).numel()) for s in ctx.shapes)
+        total = nctx.grad_numel(ctx.shapes)
         mlp = ctx.mlp
         hooked = any(getattr(p, "_backward_hooks", None) for p in mlp.ordered_params())     # somebody wants to SEE the gradients
         if mlp.grads_are_flat() and not hooked:
@@ -137,12 +137,7 @@ class _MLPNative(torch.autograd.Function):
         L.check(L.lib().mipnerf_mlp_backward(nctx.handle, ctx.M, d_raw.data_ptr(), act.data_ptr(), masks.data_ptr(),
                                              delta.data_ptr(), partials.data_ptr(), grad_flat.data_ptr(), 0, ops._stream()),
                 "mlp_backward")
-        grads, off = [], 0
-        for shp in ctx.shapes:
-            n = int(torch.Size(shp).numel())
-            grads.append(grad_flat[off:off + n].view(shp))
-            off += n
-        return (None, None, None, *grads)
+        return (None, None, None, *nctx.split_grads(grad_flat, ctx.shapes))
 
 
 class _MLPNativeF32(torch.autograd.Function):
@@ -177,8 +172,7 @@ class _MLPNativeF32(torch.autograd.Function):
         nctx = ctx.nctx
         d_raw = d_raw.contiguous().float()
         ws = nctx.scratch("f32_bwd", ctx.ws_bytes)
-        total = sum(int(torch.Size(s).numel()) for s in ctx.shapes)
-        grad_flat = torch.empty(total, device=save.device, dtype=torch.float32)
+        grad_flat = torch.empty(nctx.grad_numel(ctx.shapes), device=save.device, dtype=torch.float32)
         d_enc = None
         if ctx.needs_input_grad[1]:        # the encoding is in the graph (stop_resample_grad=False): input gradient too
             d_enc = torch.empty_like(enc)
@@ -189,12 +183,7 @@ class _MLPNativeF32(torch.autograd.Function):
             L.check(L.lib().mipnerf_mlp_backward_f32(nctx.handle, ctx.M, ctx.N, d_raw.data_ptr(), enc.data_ptr(), venc.data_ptr(),
                                                      save.data_ptr(), ws.data_ptr(), grad_flat.data_ptr(), 0, ops._stream()),
                     "mlp_backward_f32")
-        grads, off = [], 0
-        for shp in ctx.shapes:
-            n = int(torch.Size(shp).numel())
-            grads.append(grad_flat[off:off + n].view(shp))
-            off += n
-        return (None, d_enc, None, *grads)
+        return (None, d_enc, None, *nctx.split_grads(grad_flat, ctx.shapes))
 
 
 def mlp_native_f32(mlp, samples_enc, viewdirs_enc):

@@ -27,12 +27,112 @@ def _xavier_init(linear):
     torch.nn.init.xavier_uniform_(linear.weight.data)
 
 
+def param_layout(arch: dict, use_viewdirs: bool = True):
+    """[(name, (out, in) or (out,), column split)] of the reference MLP's parameters in state_dict order (mip_nerf.py:19-73).
+    `column split` = width of the FIRST part of a concatenated input ([trunk | encoding] of a skip layer, [bottleneck | view
+    encoding] of the first view layer), else None."""
+    w, wc, x, v = arch["net_width"], arch["net_width_condition"], arch["xyz_dim"], arch["view_dim"]
+    out = []
+    for i in range(arch["net_depth"]):
+        if i == 0:
+            din, split = x, None
+        elif (i - 1) % arch["skip_index"] == 0 and i > 1:
+            din, split = w + x, w
+        else:
+            din, split = w, None
+        out += [(f"layers.{i}.0.weight", (w, din), split), (f"layers.{i}.0.bias", (w,), None)]
+    out += [("density_layer.weight", (arch["num_density_channels"], w), None), ("density_layer.bias", (arch["num_density_channels"],), None),
+            ("extra_layer.weight", (w, w), None), ("extra_layer.bias", (w,), None)]
+    for i in range(arch["net_depth_condition"]):
+        din, split = (w + v, w) if i == 0 else (wc, None)
+        out += [(f"view_layers.{i}.0.weight", (wc, din), split), (f"view_layers.{i}.0.bias", (wc,), None)]
+    out += [("color_layer.weight", (arch["num_rgb_channels"], wc), None), ("color_layer.bias", (arch["num_rgb_channels"],), None)]
+    return out
+
+
+class WidthPadding:
+    """An MLP whose widths are not among the generated kernel shapes runs on the smallest generated shape that CONTAINS it
+    (same depth, skip period, view-layer count and encodings; net_width / net_width_condition rounded up): the true parameters
+    are scattered into zero-initialised tensors of the generated shape.  The padded network computes the same function -- a
+    padded unit has zero weights and bias, outputs relu(0) = 0 and feeds zero weights -- and its gradient w.r.t. every padded
+    entry is exactly zero (no upstream delta passes relu'(0) = 0, and the inputs it multiplies are 0), so the gradient of the
+    true parameters is a gather of the padded gradient.  `index` holds, for every element of the concatenated true parameters,
+    its position in the concatenated padded parameters."""
+
+    def __init__(self, arch: dict, padded_arch: dict, use_viewdirs: bool = True):
+        self.arch, self.padded_arch = dict(arch), dict(padded_arch)
+        true_l, pad_l = param_layout(arch, use_viewdirs), param_layout(padded_arch, use_viewdirs)
+        assert [t[0] for t in true_l] == [t[0] for t in pad_l]
+        idx, off = [], 0
+        self.padded_shapes, self.padded_offsets = [], []
+        for (name, ts, tsplit), (_, ps, psplit) in zip(true_l, pad_l):
+            if len(ts) == 1:
+                assert ts[0] <= ps[0], name
+                flat = torch.arange(ts[0])
+            else:
+                assert ts[0] <= ps[0] and ts[1] <= ps[1], name
+                col = torch.arange(ts[1])
+                if tsplit is not None:                      # [first part | rest]: the rest starts behind the PADDED first part
+                    col = torch.where(col < tsplit, col, col + (psplit - tsplit))
+                flat = (torch.arange(ts[0])[:, None] * ps[1] + col[None, :]).reshape(-1)
+            idx.append(flat + off)
+            self.padded_shapes.append(tuple(ps))
+            self.padded_offsets.append(off)
+            off += int(torch.Size(ps).numel())
+        self.index = torch.cat(idx)
+        self.true_numel, self.padded_numel = int(self.index.numel()), off
+
+    def scatter(self, params, out_flat: torch.Tensor) -> None:
+        """true parameters -> their places in the (zero elsewhere) flat padded buffer"""
+        out_flat[self.index] = torch.cat([p.detach().reshape(-1) for p in params])
+
+    def gather(self, padded_flat: torch.Tensor) -> torch.Tensor:
+        return padded_flat[self.index]
+
+    def padded_views(self, flat: torch.Tensor):
+        return [flat[o:o + int(torch.Size(s).numel())].view(s) for o, s in zip(self.padded_offsets, self.padded_shapes)]
+
+    def to(self, device):
+        self.index = self.index.to(device)
+        return self
+
+
+def containing_variant(arch: dict, use_viewdirs: bool, unbounded: bool, want_bf16: bool):
+    """The generated architecture variant an MLP of shape `arch` runs on: (variant arch dict, exact: bool), or None.  Exact match
+    first; else the smallest variant with the same structure and net_width / net_width_condition >= the asked ones (with
+    use_viewdirs=False the colour layer reads the trunk, so both stay equal).  Prefers variants that have kernels for the asked
+    precision."""
+    lib = L.lib()
+    best = None
+    for v in range(int(lib.mipnerf_num_variants())):
+        cfg, has_bf16 = L.Config(), C.c_int(0)
+        L.check(lib.mipnerf_variant_arch(v, C.byref(cfg), C.byref(has_bf16)), "variant_arch")
+        same = (cfg.net_depth == arch["net_depth"] and cfg.skip_index == arch["skip_index"] and
+                cfg.net_depth_condition == arch["net_depth_condition"] and cfg.num_rgb_channels == arch["num_rgb_channels"] and
+                cfg.num_density_channels == arch["num_density_channels"] and bool(cfg.use_viewdirs) == bool(use_viewdirs) and
+                bool(cfg.unbounded) == bool(unbounded) and
+                (42 if cfg.unbounded else 6) * (cfg.max_deg_point - cfg.min_deg_point) == arch["xyz_dim"] and
+                3 + 6 * cfg.deg_view == arch["view_dim"])
+        if not same or cfg.net_width < arch["net_width"] or cfg.net_width_condition < arch["net_width_condition"]:
+            continue
+        exact = cfg.net_width == arch["net_width"] and cfg.net_width_condition == arch["net_width_condition"]
+        if not use_viewdirs and not exact and cfg.net_width != cfg.net_width_condition:
+            continue
+        key = (not exact, bool(want_bf16) and not has_bf16.value, cfg.net_width * cfg.net_width + cfg.net_width * cfg.net_width_condition)
+        if best is None or key < best[0]:
+            padded = dict(arch, net_width=int(cfg.net_width), net_width_condition=int(cfg.net_width_condition))
+            best = (key, padded, exact)
+    return None if best is None else (best[1], best[2])
+
+
 class NativeContext:
     """Owns one `mipnerf_ctx` (configuration + packed weight streams on the current device)."""
 
-    def __init__(self, cfg: L.Config, device: torch.device):
+    def __init__(self, cfg: L.Config, device: torch.device, padding: Optional[WidthPadding] = None):
         self.device = device
         self.cfg = cfg
+        self.padding = padding.to(device) if padding is not None else None
+        self._padded_flat = None
         self._h = C.c_void_p()
         with torch.cuda.device(device):
             L.check(L.lib().mipnerf_create(C.byref(cfg), C.byref(self._h)), "mipnerf_create")
@@ -60,6 +160,16 @@ class NativeContext:
         want = int(L.lib().mipnerf_num_param_tensors(self._h))
         if len(params) != want:
             raise NotImplementedError(f"expected {want} parameter tensors for this architecture, got {len(params)}")
+        if self.padding is not None:
+            # widths between the generated shapes: the kernels see zero-padded copies (WidthPadding); one cat + one scatter
+            for i, p in enumerate(params):
+                if not p.is_cuda or p.device != self.device or p.dtype != torch.float32:
+                    raise RuntimeError(f"parameter {i} must be float32 on {self.device} (is {p.dtype} on {p.device})")
+            with torch.cuda.device(self.device):
+                if self._padded_flat is None:
+                    self._padded_flat = torch.zeros(self.padding.padded_numel, device=self.device, dtype=torch.float32)
+                self.padding.scatter(params, self._padded_flat)
+            params = self.padding.padded_views(self._padded_flat)
         keep = []
         arr = (C.c_void_p * want)()
         for i, p in enumerate(params):
@@ -99,6 +209,24 @@ class NativeContext:
             t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._scratch[name] = t
         return t
+
+    def grad_numel(self, shapes) -> int:
+        """Elements of the flat gradient buffer the native backward writes (the generated shape's, which is the parameters' own
+        unless the widths are padded)."""
+        if self.padding is not None:
+            return self.padding.padded_numel
+        return sum(int(torch.Size(s).numel()) for s in shapes)
+
+    def split_grads(self, grad_flat: torch.Tensor, shapes):
+        """flat native gradient -> one tensor per parameter, in the parameters' own shapes"""
+        if self.padding is not None:
+            grad_flat = self.padding.gather(grad_flat)
+        grads, off = [], 0
+        for shp in shapes:
+            n = int(torch.Size(shp).numel())
+            grads.append(grad_flat[off:off + n].view(shp))
+            off += n
+        return grads
 
     def set_option(self, option: int, value: int) -> None:
         L.check(L.lib().mipnerf_set_option(self._h, option, value), "mipnerf_set_option")
@@ -159,6 +287,12 @@ class MLP(torch.nn.Module):
         fall back to returned gradients automatically."""
         params = self.ordered_params()
         dev = params[0].device
+        e = self._cfg_extra
+        found = containing_variant(self.arch, bool(e.get("use_viewdirs", 1)), bool(e.get("unbounded", 0)), self.precision == L.PREC_BF16) \
+            if dev.type == "cuda" else None
+        if found is not None and not found[1]:
+            raise NotImplementedError("flat parameter mode (FlatAdam / GraphedTrainStep / zero-copy gradient reduction) needs an MLP of a "
+                                      "generated shape; this one runs zero-padded on a wider one (csrc/gen_mlp_bf16.py: VARIANTS)")
         total = sum(p.numel() for p in params)
         flat = torch.empty(total, device=dev, dtype=torch.float32)
         gflat = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -233,6 +367,11 @@ class MLP(torch.nn.Module):
             deg_point = a["xyz_dim"] // (42 if self._cfg_extra.get("unbounded", 0) else 6)
             deg_view = (a["view_dim"] - 3) // 6
             e = self._cfg_extra
+            padding = None
+            found = containing_variant(a, bool(e.get("use_viewdirs", 1)), bool(e.get("unbounded", 0)), self.precision == L.PREC_BF16)
+            if found is not None and not found[1]:
+                padding = WidthPadding(a, found[0], bool(e.get("use_viewdirs", 1)))
+                a = found[0]                     # the context is created for the containing generated shape
             cfg = L.Config(
                 num_samples=e.get("num_samples", 128), num_levels=e.get("num_levels", 2),
                 min_deg_point=e.get("min_deg_point", 0), max_deg_point=e.get("max_deg_point", deg_point),
@@ -243,7 +382,7 @@ class MLP(torch.nn.Module):
                 num_rgb_channels=a["num_rgb_channels"], num_density_channels=a["num_density_channels"],
                 resample_padding=e.get("resample_padding", 0.01), density_bias=e.get("density_bias", -1.0),
                 rgb_padding=e.get("rgb_padding", 0.001), density_noise=e.get("density_noise", 0.0), unbounded=e.get("unbounded", 0))
-            self._ctx = NativeContext(cfg, device)
+            self._ctx = NativeContext(cfg, device, padding)
         self._ctx.sync_params(self.ordered_params())
         return self._ctx
 
@@ -379,10 +518,31 @@ class MipNerf(torch.nn.Module):
             raise RuntimeError("MipNerf.forward needs rays on a HIP device; there is no CPU fallback "
                                "(the CPU restatement lives in oracle/ and is test-only)")
         with torch.cuda.device(o.device):      # native launches go to the CURRENT device's stream
+            if o.shape[0] == 0:
+                return self._forward_empty(o.device)
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 from .autograd import mipnerf_forward_train
                 return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
             return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
+
+    def _forward_empty(self, dev):
+        """Zero rays (an empty shard of a partitioned frame, an empty last chunk): the reference's torch ops run on empty
+        tensors and return empty per-level tuples (mip_nerf.py:172-248); the C ABI rejects B < 1, so the host answers.
+        Under autograd the outputs hang off the parameters, so a `.backward()` on this rank leaves zero gradients and a
+        data-parallel wrapper sees the same set of reduced tensors as on the other ranks."""
+        N = self.num_samples
+        z = None
+        if torch.is_grad_enabled():
+            ps = [p for p in self.parameters() if p.requires_grad]
+            if ps:
+                z = torch.stack([p.reshape(-1)[:1].sum() for p in ps]).sum() * 0.0
+        ret = []
+        for _ in range(self.num_levels):
+            tens = [torch.zeros(shape, device=dev) for shape in ((0, 3), (0,), (0,), (0, N), (0, N + 1))]
+            if z is not None:
+                tens = [t + z for t in tens[:4]] + tens[4:]         # the fence posts carry no gradient (stop-gradient resampler)
+            ret.append(tuple(tens))
+        return ret
 
     def train_step_native(self, rays: Rays, gt_rgb, randomized: bool, white_bkgd: bool, coarse_loss_mult: float = 0.1,
                           distloss_mult: float = 0.01, disable_multiscale_loss: bool = False, t_rand=None, u_rand=None,
@@ -419,7 +579,7 @@ class MipNerf(torch.nn.Module):
             mlp.gather_foreign_grads()          # re-attaches the .grad views
             grad, accumulate = mlp._flat_grad, 1 if mlp._flat_grad_valid else 0
         else:
-            total = sum(p.numel() for p in mlp.ordered_params())
+            total = ctx.grad_numel([p.shape for p in mlp.ordered_params()])
             grad, accumulate = torch.empty(total, device=dev, dtype=torch.float32), 0
         scalars = torch.empty(6, device=dev, dtype=torch.float32)
         outs, ret = None, None
@@ -440,11 +600,9 @@ class MipNerf(torch.nn.Module):
         if flat_mode:
             mlp._flat_grad_valid = True
         else:
-            off = 0
-            for p in mlp.ordered_params():
-                g = grad[off:off + p.numel()].view(p.shape)
+            ps = mlp.ordered_params()
+            for p, g in zip(ps, ctx.split_grads(grad, [p.shape for p in ps])):
                 p.grad = g if p.grad is None else p.grad.add_(g)
-                off += p.numel()
         return scalars, ret
 
     def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None, density_randn=None, out=None, ws=None):

@@ -22,6 +22,7 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-init              round 2: checksums of the freshly initialised parameters under a fixed torch seed
     --only-grad-options      round 2: training step on a black background, disparity sampling, multiscale loss off, randomized draws replayed
     --only-variant-cond / --only-variant-wide   round 3: two view layers; a 512-wide trunk (fp32-only architecture variants)
+    --only-variant-odd       round 3: widths that are not generated shapes (200 / 72, 100 / 40): run zero-padded on the containing shape
     --only-variant-depth     round 2: a 6-layer trunk with skip_index 3
     --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
     --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
@@ -842,6 +843,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-variant-wide" in sys.argv:   # round 3: a 512-wide trunk / 256-wide view layer (fp32-only architecture variant)
         variant_case("var_w512_24x64", 24, 64, param_seed=25, gain=20.0, ray_seed=25, mlp_net_width=512, mlp_net_width_condition=256)
+        sys.exit(0)
+    if "--only-variant-odd" in sys.argv:    # round 3: widths between the generated shapes (run zero-padded on the containing one)
+        variant_case("var_w200c72_48x64", 48, 64, param_seed=31, gain=20.0, ray_seed=31, mlp_net_width=200, mlp_net_width_condition=72)
+        variant_case("var_w100c40_48x64", 48, 64, param_seed=32, gain=20.0, ray_seed=32, mlp_net_width=100, mlp_net_width_condition=40)
         sys.exit(0)
     if "--only-variant-cond" in sys.argv:   # round 3: two view layers (mlp_net_depth_condition = 2; 26 parameter tensors)
         variant_case("var_dc2_48x64", 48, 64, 10, 40.0, 20, mlp_net_depth_condition=2)

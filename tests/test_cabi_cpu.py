@@ -177,3 +177,63 @@ def test_diagnostic_entry_points_validate_their_arguments(lib):
     assert lib.mipnerf_handoff_probe(1, 0, 16, 4, 1000, 0, 1, out6, None) == L.E_INVALID        # tile too small
     assert lib.mipnerf_handoff_probe(1, 0, 16, 64, 1 << 22, 0, 1, out6, None) == L.E_INVALID    # ring x tile x 128 pairs > 4 GiB
     assert b"handoff_probe" in lib.mipnerf_last_error()
+
+
+def _torch_mlp(params, arch, enc, venc):
+    """plain-torch restatement of MLP.forward (mip_nerf.py:75-111) on a state dict -- only to compare a padded with an unpadded net"""
+    import torch
+    x = enc
+    h = x
+    for i in range(arch["net_depth"]):
+        h = torch.relu(torch.nn.functional.linear(h, params[f"layers.{i}.0.weight"], params[f"layers.{i}.0.bias"]))
+        if i % arch["skip_index"] == 0 and i > 0:
+            h = torch.cat([h, x], -1)
+    dens = torch.nn.functional.linear(h, params["density_layer.weight"], params["density_layer.bias"])
+    b = torch.nn.functional.linear(h, params["extra_layer.weight"], params["extra_layer.bias"])
+    v = torch.cat([b, venc], -1)
+    for i in range(arch["net_depth_condition"]):
+        v = torch.relu(torch.nn.functional.linear(v, params[f"view_layers.{i}.0.weight"], params[f"view_layers.{i}.0.bias"]))
+    rgb = torch.nn.functional.linear(v, params["color_layer.weight"], params["color_layer.bias"])
+    return torch.cat([rgb, dens], -1)
+
+
+@pytest.mark.parametrize("w,wc,depth,skip,dc", [(200, 72, 8, 4, 1), (100, 40, 8, 4, 1), (40, 24, 6, 3, 1), (130, 90, 8, 4, 2)])
+def test_width_padding_keeps_the_function_and_its_gradient(lib, w, wc, depth, skip, dc):
+    """model.WidthPadding (host logic behind MLP widths that are not generated shapes): the variant search returns the smallest
+    containing generated shape; scattering the true parameters into zeros of that shape gives a network with the SAME outputs,
+    and the gather of its gradient IS the gradient of the true parameters (every padded entry's gradient is exactly 0)."""
+    import torch
+    from mipnerf_pl_amd import model as M
+    arch = dict(net_depth=depth, net_width=w, net_depth_condition=dc, net_width_condition=wc, skip_index=skip, num_rgb_channels=3,
+                num_density_channels=1, xyz_dim=96, view_dim=27)
+    found = M.containing_variant(arch, True, False, False)
+    assert found is not None and not found[1]
+    padded_arch = found[0]
+    assert padded_arch["net_width"] >= w and padded_arch["net_width"] % 32 == 0 and padded_arch["net_width_condition"] >= wc
+    assert M.containing_variant(dict(arch, net_width=padded_arch["net_width"], net_width_condition=padded_arch["net_width_condition"]),
+                                True, False, False)[1]                       # the containing shape itself is an exact match
+    pad = M.WidthPadding(arch, padded_arch)
+    layout = M.param_layout(arch)
+    gen = torch.Generator().manual_seed(w)
+    true = {n: (torch.rand(shp, generator=gen, dtype=torch.float64) - 0.5).requires_grad_() for n, shp, _ in layout}
+    assert pad.true_numel == sum(p.numel() for p in true.values()) and len(set(pad.index.tolist())) == pad.true_numel
+    flat = torch.zeros(pad.padded_numel, dtype=torch.float64)
+    pad.scatter(list(true.values()), flat)
+    flat.requires_grad_()
+    padded = dict(zip([n for n, _, _ in layout], pad.padded_views(flat)))
+    assert [tuple(v.shape) for v in padded.values()] == [shp for _, shp, _ in M.param_layout(padded_arch)]
+    enc = torch.randn(50, 96, generator=gen, dtype=torch.float64)
+    venc = torch.randn(50, 27, generator=gen, dtype=torch.float64)
+    y0 = _torch_mlp(true, arch, enc, venc)
+    y1 = _torch_mlp(padded, padded_arch, enc, venc)
+    assert float((y0 - y1).abs().max()) <= 1e-13 * float(y0.abs().max())      # summation order of the BLAS only
+    wgt = torch.randn(50, 4, generator=gen, dtype=torch.float64)
+    (y0 * wgt).sum().backward()
+    (y1 * wgt).sum().backward()
+    g_true = torch.cat([p.grad.reshape(-1) for p in true.values()])
+    assert float((pad.gather(flat.grad) - g_true).abs().max()) <= 1e-13 * float(g_true.abs().max())
+    mask = torch.ones(pad.padded_numel, dtype=torch.bool)
+    mask[pad.index] = False
+    assert float(flat.grad[mask].abs().max()) == 0.0                        # padded entries never move under any optimiser
+    # nothing wider than the widest generated shape
+    assert M.containing_variant(dict(arch, net_width=600), True, False, False) is None

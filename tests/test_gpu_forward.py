@@ -186,7 +186,11 @@ def test_density_noise_matches_reference(G, precision):
 
 VARIANT_KW = {"var_w128_48x64": dict(mlp_net_width=128, mlp_net_width_condition=128),
               "var_noview_48x64": dict(mlp_net_width_condition=256, use_viewdirs=False),
-              "var_d6s3_48x64": dict(mlp_net_depth=6, mlp_skip_index=3)}
+              "var_d6s3_48x64": dict(mlp_net_depth=6, mlp_skip_index=3),
+              # round 3: widths BETWEEN the generated shapes run zero-padded on the containing one (model.WidthPadding):
+              # 200 / 72 on the 256 / 128 kernels, 100 / 40 on the 128 / 128 kernels; forward, fp32 and bf16 training, native step
+              "var_w200c72_48x64": dict(mlp_net_width=200, mlp_net_width_condition=72),
+              "var_w100c40_48x64": dict(mlp_net_width=100, mlp_net_width_condition=40)}
 
 
 def _variant_arch(g):

@@ -210,7 +210,8 @@ def test_oracle_on_fullsize_golden_sample(golden_dir):
     ("ctor_levels1_40x64", dict(num_levels=1), 2e-4),
     ("ctor_scalars_40x64", dict(min_deg_point=1, max_deg_point=17, resample_padding=0.05, density_bias=-0.5, rgb_padding=0.01), 2e-4),
     ("ctor_noint_40x64", dict(disable_integration=True), 1e-2),      # level 1 is ill-conditioned without the integration
-    ("var_w128_48x64", dict(), 2e-4), ("var_noview_48x64", dict(use_viewdirs=False), 2e-4)])
+    ("var_w128_48x64", dict(), 2e-4), ("var_noview_48x64", dict(use_viewdirs=False), 2e-4),
+    ("var_w200c72_48x64", dict(), 2e-4), ("var_w100c40_48x64", dict(), 2e-4)])
 def test_oracle_constructor_variants(golden_dir, name, kw, tol1):
     """Oracle vs the reference's outputs for constructor arguments off their defaults (round-2 goldens)."""
     import os
