@@ -386,7 +386,9 @@ int mipnerf_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_
                          void* stream);
 /* CU -> CU hand-off probe: 128 producer workgroups stream `tiles` tiles of tile_bytes each to 128 consumer workgroups through
  * `ring`-slot rings in global memory with counter flags (producer and consumer on the same XCD or on neighbouring XCDs;
- * store_flavour 0 = plain stores + agent release, 1 = write-through sc1 stores), mfma_per_wave register-only MFMAs per tile
+ * store_flavour 0 = plain stores + agent release, 1 = write-through sc1 stores, 2 = plain stores, no fence, consumer loads bypass its L1
+ * (same XCD only); 3 / 4 = the per-WAVE forms of 1 / 2: wave w of the producer streams sub-tiles of tile_bytes / 8 to wave w of the consumer
+ * through its own ring and flags, no workgroup barrier, a whole sub-tile in flight per wave; 64 / 128 KiB tiles), mfma_per_wave register-only MFMAs per tile
  * on both sides, every word verified.  out6 = {aggregate GB/s, ms, producer stall fraction, consumer stall fraction,
  * mismatching 16-B words, 1 if a bounded poll timed out}.  Diagnostic: allocates and synchronises. */
 int mipnerf_handoff_probe(int same_xcd, int store_flavour, int tiles, int ring, int tile_bytes, int mfma_per_wave, int reps,

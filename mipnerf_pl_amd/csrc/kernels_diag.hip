@@ -5,6 +5,7 @@
 // conflict-free ds_read_b128 A fragment per MFMA -- exactly the operand traffic of k_mlp_bf16.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -196,7 +197,10 @@ __device__ __forceinline__ unsigned load_flag(const unsigned* p) {
 
 __device__ __forceinline__ void store_sc1_x4(uint4* p, uint4 v) {
     const u32x4 w = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+    // s_nop 1: a VMEM store of more than 8 bytes followed by a VALU write of its data VGPRs needs TWO wait states on gfx940+ (one on
+    // older gfx9); the compiler's hazard recogniser does not look inside asm and the next pattern computation reuses the registers at
+    // once.  Measured: with no / one wait state 1-3 % of the words arrive corrupted in the unrolled per-wave kernels (r03w), with two: 0.
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
 
 // 16-byte load that bypasses this CU's L1 (served by the XCD's L2): flavour 2 reads a same-XCD producer's plain stores with it
@@ -331,6 +335,122 @@ __global__ void __launch_bounds__(kProbeThreads) k_handoff_probe(uint4* __restri
     (void)smem;
 }
 
+// ---- probe v2: per-WAVE streams ---------------------------------------------------------------------------------------------
+// The workgroup-wide protocol above serialises flag -> loads -> compare per tile on the consumer (one round of loads in flight,
+// two barriers): its rate is partly a latency figure.  Here wave w of the producer workgroup streams sub-tiles (tile_bytes / 8) to
+// wave w of the consumer workgroup through its own ring and flags: no workgroup barrier anywhere, a whole sub-tile (PL 16-byte
+// vectors per lane) in flight per wave, and the eight waves of a CU drift apart so that one wave's flag / load latency overlaps the
+// others' transfers -- the most a CU pair can hand over with ordinary loads and stores.
+//   FLAVOUR 3: write-through (sc1) stores, vmcnt(0), flag; consumer: flag, agent-scope acquire (per wave), plain loads.  Any placement.
+//   FLAVOUR 4: plain stores (land in the XCD's L2), vmcnt(0), flag; consumer: flag, sc1 loads (bypass its L1), no fence.  Same XCD only.
+template <int FLAVOUR, int PL>
+__global__ void __launch_bounds__(kProbeThreads) k_handoff_waves(uint4* __restrict__ ring_mem, unsigned* __restrict__ ready,
+                                                                unsigned* __restrict__ consumed, unsigned* __restrict__ abort_word,
+                                                                unsigned* __restrict__ errors, int same_xcd, int tiles, int ring,
+                                                                int mfma_per_wave, const bf16x8* __restrict__ ab_src,
+                                                                float* __restrict__ sink, int active_pairs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // only to force one workgroup per CU
+    const int b = blockIdx.x;
+    int pair, is_consumer;
+    if (same_xcd) {
+        const int row = b >> 3, x = b & 7;
+        pair = (row >> 1) * 8 + x;
+        is_consumer = row & 1;
+    } else {
+        pair = b >> 1;
+        is_consumer = b & 1;
+    }
+    if (pair >= active_pairs) return;             // MIPNERF_PROBE_PAIRS: is the rate a per-pair or a chip-wide limit?
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int stream = pair * 8 + wave;
+    constexpr int kSub = PL * 64;                                    // 16-byte vectors per sub-tile
+    uint4* slots = ring_mem + (size_t)stream * ring * kSub;
+    bf16x8 A0 = ab_src[lane], B0 = ab_src[64 + lane];
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    unsigned bad = 0;
+    bool alive = true;
+    auto wait_for = [&](const unsigned* flag, unsigned need) {
+        unsigned spins = 0;
+        while (load_flag(flag) < need) {
+            if (++spins > kMaxSpins || load_flag(abort_word) != 0) {
+                __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return true;
+    };
+    for (int t = 0; t < tiles && alive; ++t) {
+        uint4* slot = slots + (size_t)(t % ring) * kSub;
+        if (!is_consumer) {
+            if (t >= ring) alive = wait_for(&consumed[stream], (unsigned)(t - ring + 1));
+            if (!alive) break;
+#pragma unroll
+            for (int i = 0; i < PL; ++i) {
+                const unsigned idx = (unsigned)(i * 64 + lane);
+                const uint4 v = probe_pattern((unsigned)stream, (unsigned)t, idx);
+                if (FLAVOUR == 3) store_sc1_x4(slot + idx, v);
+                else slot[idx] = v;
+            }
+            for (int m = 0; m < mfma_per_wave; m += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc1, 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores are acknowledged (L2 / memory side)
+            if (lane == 0) __hip_atomic_store(&ready[stream], (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            alive = wait_for(&ready[stream], (unsigned)(t + 1));
+            if (!alive) break;
+            uint4 v[PL];
+            if (FLAVOUR == 3) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+                for (int i = 0; i < PL; ++i) v[i] = slot[i * 64 + lane];
+                for (int m = 0; m < mfma_per_wave; m += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc1, 0, 0, 0);
+                }
+            } else {
+                u32x4 r[PL];
+#pragma unroll
+                for (int i = 0; i < PL; ++i) load_sc1_x4_issue(slot + i * 64 + lane, r[i]);
+                for (int m = 0; m < mfma_per_wave; m += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc1, 0, 0, 0);
+                }
+                // the asm loads are invisible to the compiler's waitcnt insertion; the registers are operands of the waits (in issue
+                // order, 8 per wait), so nothing reads them early
+#pragma unroll
+                for (int g = 0; g < PL / 8; ++g) {
+                    u32x4* q = r + g * 8;
+                    if (PL / 8 - 1 - g == 3) asm volatile("s_waitcnt vmcnt(24)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) :: "memory");
+                    else if (PL / 8 - 1 - g == 2) asm volatile("s_waitcnt vmcnt(16)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) :: "memory");
+                    else if (PL / 8 - 1 - g == 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) :: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) :: "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < PL; ++i) v[i] = make_uint4(r[i].x, r[i].y, r[i].z, r[i].w);
+            }
+#pragma unroll
+            for (int i = 0; i < PL; ++i) {
+                const uint4 w = probe_pattern((unsigned)stream, (unsigned)t, (unsigned)(i * 64 + lane));
+                bad += (v[i].x != w.x) | (v[i].y != w.y) | (v[i].z != w.z) | (v[i].w != w.w);
+            }
+            // every lane's data has arrived (it was compared): the slot may be overwritten
+            if (__builtin_amdgcn_readfirstlane((int)bad) >= 0 && lane == 0)
+                __hip_atomic_store(&consumed[stream], (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc0[r] + acc1[r];
+    if (s == 12345.678f) sink[b] = s;
+    if (bad) atomicAdd(errors, bad);
+    (void)smem;
+}
+
 }  // namespace
 
 // out[0] = aggregate GB/s handed off (payload bytes / kernel time), out[1] = ms, out[2] = mean producer stall fraction,
@@ -347,15 +467,25 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
     DG(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (cus != 256) { snprintf(msg, msg_cap, "probe assumes 256 CUs in 8 XCDs, device has %d", cus); return -2; }
     if (tile_bytes % (16 * kProbeThreads * 8) || ring < 1 || tiles < 1 || reps < 1) { snprintf(msg, msg_cap, "bad probe arguments"); return -2; }
+    if (flavour < 0 || flavour > 4 || (flavour >= 3 && tile_bytes != 65536 && tile_bytes != 131072) ||
+        ((flavour == 2 || flavour == 4) && !same_xcd)) {
+        snprintf(msg, msg_cap, "bad probe flavour (0-4; 3 / 4 take 64 / 128 KiB tiles; 2 / 4 are same-XCD protocols)");
+        return -2;
+    }
     const int pairs = 128, tile_vec = tile_bytes / 16;
+    int active = pairs;                           // per-wave protocols only: pairs 0 .. active-1 run (same_xcd: 8 per XCD row)
+    if (const char* e = getenv("MIPNERF_PROBE_PAIRS")) {
+        active = atoi(e);
+        if (active < 1 || active > pairs || flavour < 3) { snprintf(msg, msg_cap, "MIPNERF_PROBE_PAIRS must be 1..128 and needs flavour 3 / 4"); return -2; }
+    }
     uint4* ring_mem = nullptr;
     unsigned *ready = nullptr, *consumed = nullptr, *abort_word = nullptr, *errors = nullptr;
     unsigned long long* stall = nullptr;
     bf16x8* ab = nullptr;
     float* sink = nullptr;
     DG(hipMalloc(&ring_mem, (size_t)pairs * ring * tile_bytes));
-    DG(hipMalloc(&ready, pairs * 4));
-    DG(hipMalloc(&consumed, pairs * 4));
+    DG(hipMalloc(&ready, pairs * 8 * 4));          // probe v2: one counter per wave stream
+    DG(hipMalloc(&consumed, pairs * 8 * 4));
     DG(hipMalloc(&abort_word, 4));
     DG(hipMalloc(&errors, 4));
     DG(hipMalloc(&stall, 512 * 8));
@@ -371,15 +501,27 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
     DG(hipFuncSetAttribute((const void*)k_handoff_probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DG(hipFuncSetAttribute((const void*)k_handoff_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DG(hipFuncSetAttribute((const void*)k_handoff_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DG(hipFuncSetAttribute((const void*)k_handoff_waves<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DG(hipFuncSetAttribute((const void*)k_handoff_waves<3, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DG(hipFuncSetAttribute((const void*)k_handoff_waves<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    DG(hipFuncSetAttribute((const void*)k_handoff_waves<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     DG(hipEventCreate(&e0));
     DG(hipEventCreate(&e1));
     double best_ms = 1e30;
     for (int rep = 0; rep < reps + 1; ++rep) {    // first repetition = warm-up
-        DG(hipMemsetAsync(ready, 0, pairs * 4, st));
-        DG(hipMemsetAsync(consumed, 0, pairs * 4, st));
+        DG(hipMemsetAsync(ready, 0, pairs * 8 * 4, st));
+        DG(hipMemsetAsync(consumed, 0, pairs * 8 * 4, st));
         DG(hipEventRecord(e0, st));
-        if (flavour == 2) hipLaunchKernelGGL(k_handoff_probe<2>, dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word,
+        if (flavour >= 3) {
+#define WAVES(F, PLV)                                                                                                         \
+    hipLaunchKernelGGL((k_handoff_waves<F, PLV>), dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word, \
+                       errors, same_xcd, tiles, ring, mfma_per_wave, ab, sink, active)
+            const int pl = tile_bytes / (16 * kProbeThreads);
+            if (flavour == 3) { if (pl == 8) WAVES(3, 8); else WAVES(3, 16); }
+            else { if (pl == 8) WAVES(4, 8); else WAVES(4, 16); }
+#undef WAVES
+        } else if (flavour == 2) hipLaunchKernelGGL(k_handoff_probe<2>, dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word,
                                              stall, errors, same_xcd, tiles, ring, tile_vec, mfma_per_wave, ab, sink);
         else if (flavour) hipLaunchKernelGGL(k_handoff_probe<1>, dim3(256), dim3(kProbeThreads), lds, st, ring_mem, ready, consumed, abort_word,
                                         stall, errors, same_xcd, tiles, ring, tile_vec, mfma_per_wave, ab, sink);
@@ -402,7 +544,7 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
         const double f = h_stall[256 + b] ? (double)h_stall[b] / (double)h_stall[256 + b] : 0.0;
         (cons ? sc : sp) += f;
     }
-    out[0] = (double)pairs * tiles * tile_bytes / (best_ms * 1e-3) / 1e9;
+    out[0] = (double)active * tiles * tile_bytes / (best_ms * 1e-3) / 1e9;
     out[1] = best_ms;
     out[2] = sp / 128;
     out[3] = sc / 128;
