@@ -1303,8 +1303,9 @@ int mipnerf_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_
 int mipnerf_handoff_probe(int same_xcd, int store_flavour, int tiles, int ring, int tile_bytes, int mfma_per_wave, int reps, double* out6,
                           void* stream) {
     if (!out6 || tiles < 1 || tiles > (1 << 16) || ring < 1 || ring > 64 || tile_bytes < 65536 || tile_bytes > (1 << 22) || reps < 1 || reps > 16 ||
-        mfma_per_wave < 0 || mfma_per_wave > 4096 || (long long)ring * tile_bytes * 128 > (4ll << 30))
-        return fail(MIPNERF_E_INVALID, "handoff_probe: argument out of range");
+        mfma_per_wave < 0 || mfma_per_wave > 4096 || (long long)ring * tile_bytes * 128 > (4ll << 30) || store_flavour < 0 || store_flavour > 4 ||
+        ((store_flavour == 2 || store_flavour == 4) && !same_xcd) || (store_flavour >= 3 && tile_bytes != 65536 && tile_bytes != 131072))
+        return fail(MIPNERF_E_INVALID, "handoff_probe: argument out of range (flavours 0-4; 2 / 4 are same-XCD protocols; 3 / 4 take 64 / 128 KiB tiles)");
     char msg[256];
     const int rc = mip::run_handoff_probe(same_xcd, store_flavour, tiles, ring, tile_bytes, mfma_per_wave, reps, out6, S(stream), msg, sizeof msg);
     g_err = msg;

@@ -177,6 +177,9 @@ def test_diagnostic_entry_points_validate_their_arguments(lib):
     assert lib.mipnerf_handoff_probe(1, 0, 16, 4, 1000, 0, 1, out6, None) == L.E_INVALID        # tile too small
     assert lib.mipnerf_handoff_probe(1, 0, 16, 64, 1 << 22, 0, 1, out6, None) == L.E_INVALID    # ring x tile x 128 pairs > 4 GiB
     assert b"handoff_probe" in lib.mipnerf_last_error()
+    assert lib.mipnerf_handoff_probe(1, 5, 16, 4, 131072, 0, 1, out6, None) == L.E_INVALID      # no such protocol
+    assert lib.mipnerf_handoff_probe(0, 4, 16, 4, 131072, 0, 1, out6, None) == L.E_INVALID      # fence-free protocols are same-XCD only
+    assert lib.mipnerf_handoff_probe(1, 3, 16, 4, 262144, 0, 1, out6, None) == L.E_INVALID      # per-wave protocols: 64 / 128 KiB tiles
 
 
 def _torch_mlp(params, arch, enc, venc):

@@ -123,3 +123,22 @@ if forced:
     assert a["losses"] == b["losses"], (a["losses"], b["losses"])          # same kernels, identity all-reduce: bit-identical trajectories
     assert a["psum"] == b["psum"] and a["pabs"] == b["pabs"]
     assert a["losses"][-1] < a["losses"][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("same_xcd,flavour", [(1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (0, 0), (0, 1), (0, 3)])
+def test_handoff_probe_protocols_deliver_every_word(same_xcd, flavour):
+    """mipnerf_handoff_probe (milestone 1 of the layer pipeline): every CU -> CU protocol hands all 128 pairs' tiles over
+    with no wrong 16-byte word and no timed-out poll, with and without MFMA work beside the transfer; the fence-free protocols (2, 4)
+    are only defined between workgroups of one XCD."""
+    import ctypes as C
+    import torch
+    from mipnerf_pl_amd import _lib as L
+    torch.cuda.init()
+    st = torch.cuda.current_stream().cuda_stream
+    for mfma in (0, 64):
+        out = (C.c_double * 6)()
+        rc = L.lib().mipnerf_handoff_probe(same_xcd, flavour, 48, 2, 131072, mfma, 1, out, st)
+        assert rc == 0, L.last_error()
+        assert out[4] == 0 and out[5] == 0, (list(out), mfma)      # wrong words, timed-out polls
+        assert out[0] > 50.0                                      # GB/s aggregate: it moved
