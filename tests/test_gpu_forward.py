@@ -90,7 +90,12 @@ def test_errors_and_contract(G):
     with pytest.raises(RuntimeError):
         m(cpu_rays, False, True)      # no CPU fallback
     with pytest.raises(NotImplementedError):
-        MipNerf(mlp_net_width=64).cuda()(G.to_dev(orc.synthetic_rays(4)), False, True)   # MLP shape without a generated variant
+        MipNerf(mlp_net_width=640).cuda()(G.to_dev(orc.synthetic_rays(4)), False, True)  # wider than every generated variant
+    with pytest.raises(NotImplementedError):
+        MipNerf(mlp_net_depth=5).cuda()(G.to_dev(orc.synthetic_rays(4)), False, True)    # a depth nobody generated kernels for
+    with torch.no_grad():       # a width between the generated shapes runs zero-padded on the containing one (model.WidthPadding)
+        ret = MipNerf(num_samples=32, mlp_net_width=64).cuda()(G.to_dev(orc.synthetic_rays(4)), False, True)
+    assert ret[1][0].shape == (4, 3) and bool(torch.isfinite(ret[1][0]).all())
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
