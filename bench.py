@@ -52,6 +52,7 @@ def parse_args():
                     "autograd Functions (what a Lightning loop does) instead of the single native mipnerf_train_step call")
     ap.add_argument("--torch-adam", action="store_true", help="train: torch.optim.Adam on per-tensor gradients "
                     "(what the reference configures) instead of the fused flat Adam kernel")
+    ap.add_argument("--render-chunk", type=int, default=8192, help="render: rays per chunk of the frame (val.chunk_size)")
     ap.add_argument("--no-graph", action="store_true", help="render / train: eager launches instead of the captured hipGraph")
     ap.add_argument("--preheat-seconds", type=float, default=3.0, help="untimed steps for this long BEFORE the W warm-up steps of every "
                     "timed region: the package reaches its steady clock / power state (the first tens of steps after an idle period "
@@ -389,7 +390,7 @@ def run_render(args, e):
     FR = Rays(*[torch.from_numpy(np.tile(a, (reps, 1))[:nloc]).to(e.dev) for a in frame_np])
     model0, _ = make_model(args, e, N)
     hp = dict(DEFAULT_HPARAMS)
-    hp.update({"nerf.num_samples": N, "val.chunk_size": 8192})
+    hp.update({"nerf.num_samples": N, "val.chunk_size": int(args.render_chunk)})
     system = MipNeRFSystem(hp, precision=args.precision)
     system.mip_nerf.load_state_dict(model0.state_dict())
     system = system.to(e.dev)
@@ -414,7 +415,7 @@ def run_render(args, e):
            "scaling": "strong",
            "roofline": {"bound": "mfma", "kernel": "whole frame (k_mlp_bf16 >= 95 % of it)", "achieved": round(tflops, 2), "peak": peak,
                         "unit": "TFLOP/s per GPU", "frac": round(tflops / peak, 4), "traffic": None},
-           "config": {"workload": (f"BASELINE.json configs[4]: one 800x800 frame = 640,000 rays x ({N}+{N}) samples in 8192-ray chunks, "
+           "config": {"workload": (f"BASELINE.json configs[4]: one 800x800 frame = 640,000 rays x ({N}+{N}) samples in {int(args.render_chunk)}-ray chunks, "
                                    f"{'eager chunk loop' if args.no_graph else 'chunk forward replayed from a captured hipGraph'}, rays split "
                                    f"over {e.world} rank(s), rgb all-gathered"),
                       "mode": "render", "samples_per_level": N, "parallelism": f"ray-split x{e.world}, all_gather of 12 B/ray"}}
