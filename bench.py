@@ -432,13 +432,15 @@ def run_ceiling(args, e):
     out = {"unit": "TFLOP/s", "operands": "weights U(-0.1,0.1), activations relu(N(0,1)), bf16", "waves_per_simd": 2,
            "seconds_per_variant": args.ceiling_seconds, "peak": PEAK_TFLOPS["bf16"], "variants": []}
     st = torch.cuda.current_stream().cuda_stream
-    for lds in (0, 1):
+    for lds in (0, 1, 2):
         r = (C.c_double * 3)()
         L.check(L.lib().mipnerf_mfma_ceiling(lds, 2, 1, float(args.ceiling_seconds), r, st), "mfma_ceiling")
-        out["variants"].append({"lds_weight_reads_per_mfma": lds, "tflops": round(r[0], 1), "frac_of_peak": round(r[0] / PEAK_TFLOPS["bf16"], 4),
+        out["variants"].append({"lds_weight_reads_per_mfma": min(lds, 1), "weight_dma_l2_to_lds": lds == 2, "tflops": round(r[0], 1),
+                                "frac_of_peak": round(r[0] / PEAK_TFLOPS["bf16"], 4),
                                 "ms_per_launch": round(r[1], 4), "effective_clock_ghz": round(r[2], 3)})
     out["register_fed"] = out["variants"][0]["frac_of_peak"]
     out["lds_fed"] = out["variants"][1]["frac_of_peak"]
+    out["lds_and_dma_fed"] = out["variants"][2]["frac_of_peak"]     # + the kernel's L2 -> LDS weight stream (global_load_lds) at its rate
     return out
 
 
@@ -671,6 +673,8 @@ def main():
             line["ceiling"] = ceiling
             if line.get("roofline") and "lds_fed" in ceiling and ceiling["lds_fed"] > 0:
                 line["roofline"]["frac_of_measured_lds_fed_ceiling"] = round(line["roofline"]["frac"] / ceiling["lds_fed"], 4)
+                if ceiling.get("lds_and_dma_fed", 0) > 0:
+                    line["roofline"]["frac_of_measured_lds_and_dma_fed_ceiling"] = round(line["roofline"]["frac"] / ceiling["lds_and_dma_fed"], 4)
         for k, r in recs.items():
             r.update({"metric": "ray-samples/sec", "unit": "ray-samples/s", "n_gpus": e.world, "per_gpu": round(r["value"] / e.world, 1)})
             line[k] = r

@@ -379,7 +379,8 @@ int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
 int mipnerf_mlp_launch_stats(mipnerf_ctx* ctx, double* total_ms, int64_t* launches);
 /* What a back-to-back v_mfma_f32_32x32x16_bf16 stream sustains on THIS chip (the ceiling k_mlp_bf16's roofline fraction is
  * read against): 256 workgroups of waves_per_simd x 4 waves, register-resident operands (lds_reads_per_mfma = 0) or one
- * ds_read_b128 weight fragment per MFMA as in k_mlp_bf16 (1); operands all zero or MLP-like random (weights U(-0.1,0.1),
+ * ds_read_b128 weight fragment per MFMA as in k_mlp_bf16 (1), or (2) the same plus k_mlp_bf16's weight DMA: every wave moves 8 one-KiB
+ * chunks of an L2-resident 1.19-MiB stream into the LDS ring per 64 of its MFMAs with global_load_lds; operands all zero or MLP-like random (weights U(-0.1,0.1),
  * activations relu(N(0,1))).  Runs for `seconds` (first half un-measured heat-up).  out3 = {TFLOP/s, ms per launch,
  * shader clock in GHz implied by the MFMA issue rate}.  Diagnostic: allocates and synchronises. */
 int mipnerf_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_operands, double seconds, double* out3,

@@ -21,10 +21,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kIters = 256;    // outer iterations per launch
 constexpr int kUnroll = 64;    // MFMAs per iteration
+constexpr unsigned kStreamChunks = 1216;   // one-KiB chunks of the shipped network's weight stream (mlp_plan.py): 1.19 MiB
 
 template <int LDS>
 __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__ a_src, const bf16x8* __restrict__ b_src,
-                                                     float* __restrict__ out, int iters) {
+                                                     float* __restrict__ out, int iters, const bf16x8* __restrict__ dma_src) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     bf16x8 A[8], B[16];
@@ -36,18 +37,51 @@ __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__
         for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) reinterpret_cast<bf16x8*>(smem)[i] = a_src[i];
         __syncthreads();
     }
+    if (LDS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const char* lane_base = smem + lane * 16;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: feeds SGPR asm operands
     for (int it = 0; it < iters; ++it) {
         const char* base = lane_base + (it & 1) * 32768;
+        if (LDS == 2) {
+            // the weight stream of k_mlp_bf16: every wave DMAs 4 of every 32 one-KiB chunks its workgroup consumes (global_load_lds, L2 ->
+            // LDS), i.e. 8 chunks per 64 MFMAs of its own; source = a 1.19-MiB stream that stays in the XCD's L2, destination = the half
+            // of the ring the MFMAs are NOT reading in this iteration.  The previous iteration's DMAs are drained first (the kernel waits
+            // for them before its ring barrier).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned chunk0 = ((unsigned)(it * 8 + wave) * 8u) % (kStreamChunks - 8);
+            const char* g = reinterpret_cast<const char*>(dma_src) + (size_t)chunk0 * 1024;
+            char* l = smem + ((it + 1) & 1) * 32768 + (wave & 3) * 8192;
+            const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)l;
+            const unsigned lane16 = (unsigned)lane * 16u;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %2\n\t"
+                "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+                "s_mov_b32 m0, %4\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %5\n\t"
+                "global_load_lds_dwordx4 %1, %5 offset:1024\n\t"
+                "global_load_lds_dwordx4 %1, %5 offset:2048\n\t"
+                "global_load_lds_dwordx4 %1, %5 offset:3072\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(lane16), "s"(g), "s"(lds_addr), "s"(lds_addr + 4096u), "s"(g + 4096)
+                : "memory");
+        }
 #pragma unroll
         for (int j = 0; j < kUnroll; ++j) {
             bf16x8 a;
-            if (LDS == 1) a = *reinterpret_cast<const bf16x8*>(base + (j & 31) * 1024);
+            if (LDS >= 1) a = *reinterpret_cast<const bf16x8*>(base + (j & 31) * 1024);
             else a = A[j & 7];
             acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B[(j * 5) & 15], acc[j & 3], 0, 0, 0);
         }
@@ -58,6 +92,7 @@ __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__
                 for (int r = 0; r < 16; ++r) acc[i][r] *= 1e-3f;
         }
     }
+    if (LDS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -108,8 +143,15 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
             hb[i] = f2bf(g > 0 ? g : 0.0f);
         }
     }
-    bf16x8 *dA = nullptr, *dB = nullptr;
+    bf16x8 *dA = nullptr, *dB = nullptr, *dS = nullptr;
     float* dOut = nullptr;
+    std::vector<uint16_t> hs((size_t)kStreamChunks * 512, 0);
+    if (random_operands) {
+        Rng r2{0xD1B54A32D192ED03ull};
+        for (auto& x : hs) x = f2bf((r2.uni() - 0.5f) * 0.2f);
+    }
+    DG(hipMalloc(&dS, hs.size() * 2));
+    DG(hipMemcpyAsync(dS, hs.data(), hs.size() * 2, hipMemcpyHostToDevice, st));
     DG(hipMalloc(&dA, nA * 2));
     DG(hipMalloc(&dB, nB * 2));
     DG(hipMalloc(&dOut, (size_t)cus * 512 * 4));
@@ -121,9 +163,11 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
     DG(hipEventCreate(&e1));
     const int threads = 256 * waves_per_simd;
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     auto launch = [&]() {
-        if (lds_reads_per_mfma) hipLaunchKernelGGL(k_mfma_ceiling<1>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters);
-        else hipLaunchKernelGGL(k_mfma_ceiling<0>, dim3(cus), dim3(threads), 0, st, dA, dB, dOut, kIters);
+        if (lds_reads_per_mfma == 2) hipLaunchKernelGGL(k_mfma_ceiling<2>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS);
+        else if (lds_reads_per_mfma) hipLaunchKernelGGL(k_mfma_ceiling<1>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS);
+        else hipLaunchKernelGGL(k_mfma_ceiling<0>, dim3(cus), dim3(threads), 0, st, dA, dB, dOut, kIters, dS);
     };
     const double flop = 2.0 * 32 * 32 * 16 * (double)kUnroll * kIters * (threads / 64) * cus;
     launch();
@@ -158,6 +202,7 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
     hipEventDestroy(e1);
     hipFree(dA);
     hipFree(dB);
+    hipFree(dS);
     hipFree(dOut);
     snprintf(msg, msg_cap, "ok");
     return 0;
