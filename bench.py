@@ -432,15 +432,21 @@ def run_ceiling(args, e):
     out = {"unit": "TFLOP/s", "operands": "weights U(-0.1,0.1), activations relu(N(0,1)), bf16", "waves_per_simd": 2,
            "seconds_per_variant": args.ceiling_seconds, "peak": PEAK_TFLOPS["bf16"], "variants": []}
     st = torch.cuda.current_stream().cuda_stream
-    for lds in (0, 1, 2):
+    for lds in (0, 1, 2, 3):
         r = (C.c_double * 3)()
         L.check(L.lib().mipnerf_mfma_ceiling(lds, 2, 1, float(args.ceiling_seconds), r, st), "mfma_ceiling")
-        out["variants"].append({"lds_weight_reads_per_mfma": min(lds, 1), "weight_dma_l2_to_lds": lds == 2, "tflops": round(r[0], 1),
+        out["variants"].append({"lds_weight_reads_per_mfma": min(lds, 1), "weight_dma_l2_to_lds": lds >= 2,
+                                "saved_activation_stores": "4608 B/sample non-temporal (k_mlp_bf16_trainfwd's stream)" if lds == 3 else None,
+                                "tflops": round(r[0], 1),
                                 "frac_of_peak": round(r[0] / PEAK_TFLOPS["bf16"], 4),
                                 "ms_per_launch": round(r[1], 4), "effective_clock_ghz": round(r[2], 3)})
     out["register_fed"] = out["variants"][0]["frac_of_peak"]
     out["lds_fed"] = out["variants"][1]["frac_of_peak"]
     out["lds_and_dma_fed"] = out["variants"][2]["frac_of_peak"]     # + the kernel's L2 -> LDS weight stream (global_load_lds) at its rate
+    # + the training forward's saved-activation stream (one 1-KiB non-temporal store per wave per 9.4 MFMAs, 3.7 GB per launch): what the
+    # matrix pipe sustains while the producers of the training step write their T-blocks; the stores run at store_TBps
+    out["lds_dma_and_store_fed"] = out["variants"][3]["frac_of_peak"]
+    out["store_TBps_in_that_variant"] = round(256 * 8 * 256 * 7 * 1024 / (out["variants"][3]["ms_per_launch"] * 1e-3) / 1e12, 3)
     return out
 
 

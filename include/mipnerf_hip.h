@@ -380,7 +380,9 @@ int mipnerf_mlp_launch_stats(mipnerf_ctx* ctx, double* total_ms, int64_t* launch
 /* What a back-to-back v_mfma_f32_32x32x16_bf16 stream sustains on THIS chip (the ceiling k_mlp_bf16's roofline fraction is
  * read against): 256 workgroups of waves_per_simd x 4 waves, register-resident operands (lds_reads_per_mfma = 0) or one
  * ds_read_b128 weight fragment per MFMA as in k_mlp_bf16 (1), or (2) the same plus k_mlp_bf16's weight DMA: every wave moves 8 one-KiB
- * chunks of an L2-resident 1.19-MiB stream into the LDS ring per 64 of its MFMAs with global_load_lds; operands all zero or MLP-like random (weights U(-0.1,0.1),
+ * chunks of an L2-resident 1.19-MiB stream into the LDS ring per 64 of its MFMAs with global_load_lds, or (3) that plus the training forward's
+ * saved-activation stream: one 1-KiB non-temporal store per wave per 9.4 MFMAs to fresh addresses (3.7 GB per launch; 2 waves per SIMD);
+ * operands all zero or MLP-like random (weights U(-0.1,0.1),
  * activations relu(N(0,1))).  Runs for `seconds` (first half un-measured heat-up).  out3 = {TFLOP/s, ms per launch,
  * shader clock in GHz implied by the MFMA issue rate}.  Diagnostic: allocates and synchronises. */
 int mipnerf_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_operands, double seconds, double* out3,

@@ -25,7 +25,8 @@ constexpr unsigned kStreamChunks = 1216;   // one-KiB chunks of the shipped netw
 
 template <int LDS>
 __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__ a_src, const bf16x8* __restrict__ b_src,
-                                                     float* __restrict__ out, int iters, const bf16x8* __restrict__ dma_src) {
+                                                     float* __restrict__ out, int iters, const bf16x8* __restrict__ dma_src,
+                                                     bf16x8* __restrict__ store_dst) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     bf16x8 A[8], B[16];
@@ -37,7 +38,7 @@ __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__
         for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) reinterpret_cast<bf16x8*>(smem)[i] = a_src[i];
         __syncthreads();
     }
-    if (LDS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (LDS >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -47,12 +48,13 @@ __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform: feeds SGPR asm operands
     for (int it = 0; it < iters; ++it) {
         const char* base = lane_base + (it & 1) * 32768;
-        if (LDS == 2) {
+        if (LDS >= 2) {
             // the weight stream of k_mlp_bf16: every wave DMAs 4 of every 32 one-KiB chunks its workgroup consumes (global_load_lds, L2 ->
             // LDS), i.e. 8 chunks per 64 MFMAs of its own; source = a 1.19-MiB stream that stays in the XCD's L2, destination = the half
             // of the ring the MFMAs are NOT reading in this iteration.  The previous iteration's DMAs are drained first (the kernel waits
             // for them before its ring barrier).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (LDS == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      // the DMAs are done; last iteration's 7 stores may still fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned chunk0 = ((unsigned)(it * 8 + wave) * 8u) % (kStreamChunks - 8);
             const char* g = reinterpret_cast<const char*>(dma_src) + (size_t)chunk0 * 1024;
             char* l = smem + ((it + 1) & 1) * 32768 + (wave & 3) * 8192;
@@ -84,6 +86,12 @@ __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__
             if (LDS >= 1) a = *reinterpret_cast<const bf16x8*>(base + (j & 31) * 1024);
             else a = A[j & 7];
             acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B[(j * 5) & 15], acc[j & 3], 0, 0, 0);
+            if (LDS == 3 && (j % 9) == 4) {
+                // the saved-activation stream of k_mlp_bf16_trainfwd: 4,608 B per sample = one 1-KiB non-temporal store per wave every
+                // 9.4 MFMAs (7 per 64), each to a fresh address (write-once, 3.7 GB per launch)
+                bf16x8* dst = store_dst + ((((size_t)blockIdx.x * 8 + wave) * (size_t)iters + it) * 7 + j / 9) * 64 + lane;
+                __builtin_nontemporal_store(B[j & 15], dst);
+            }
         }
         if ((it & 15) == 15) {      // keep the accumulators bounded (the MLP re-initialises them every 16-22 MFMAs)
 #pragma unroll
@@ -92,7 +100,7 @@ __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__
                 for (int r = 0; r < 16; ++r) acc[i][r] *= 1e-3f;
         }
     }
-    if (LDS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (LDS >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -164,10 +172,14 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
     const int threads = 256 * waves_per_simd;
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    bf16x8* dStore = nullptr;
+    if (lds_reads_per_mfma == 3) DG(hipMalloc(&dStore, (size_t)cus * 8 * kIters * 7 * 1024));       // 3.7 GB: every store address is written once per launch
     auto launch = [&]() {
-        if (lds_reads_per_mfma == 2) hipLaunchKernelGGL(k_mfma_ceiling<2>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS);
-        else if (lds_reads_per_mfma) hipLaunchKernelGGL(k_mfma_ceiling<1>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS);
-        else hipLaunchKernelGGL(k_mfma_ceiling<0>, dim3(cus), dim3(threads), 0, st, dA, dB, dOut, kIters, dS);
+        if (lds_reads_per_mfma == 3) hipLaunchKernelGGL(k_mfma_ceiling<3>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
+        else if (lds_reads_per_mfma == 2) hipLaunchKernelGGL(k_mfma_ceiling<2>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
+        else if (lds_reads_per_mfma) hipLaunchKernelGGL(k_mfma_ceiling<1>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
+        else hipLaunchKernelGGL(k_mfma_ceiling<0>, dim3(cus), dim3(threads), 0, st, dA, dB, dOut, kIters, dS, dStore);
     };
     const double flop = 2.0 * 32 * 32 * 16 * (double)kUnroll * kIters * (threads / 64) * cus;
     launch();
@@ -203,6 +215,7 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
     hipFree(dA);
     hipFree(dB);
     hipFree(dS);
+    hipFree(dStore);
     hipFree(dOut);
     snprintf(msg, msg_cap, "ok");
     return 0;

@@ -170,7 +170,7 @@ def test_diagnostic_entry_points_validate_their_arguments(lib):
     """mipnerf_mfma_ceiling / mipnerf_handoff_probe (round 3) reject bad arguments before touching the device."""
     out3, out6 = (C.c_double * 3)(), (C.c_double * 6)()
     assert lib.mipnerf_mfma_ceiling(0, 3, 1, 1.0, out3, None) == L.E_INVALID          # waves per SIMD must be 1 or 2
-    assert lib.mipnerf_mfma_ceiling(3, 2, 1, 1.0, out3, None) == L.E_INVALID          # feeding mode 0, 1 or 2
+    assert lib.mipnerf_mfma_ceiling(4, 2, 1, 1.0, out3, None) == L.E_INVALID          # feeding mode 0 ... 3
     assert lib.mipnerf_mfma_ceiling(0, 2, 1, 100.0, out3, None) == L.E_INVALID        # bounded run time
     assert lib.mipnerf_mfma_ceiling(0, 2, 1, 1.0, None, None) == L.E_INVALID
     assert lib.mipnerf_handoff_probe(1, 0, 0, 4, 131072, 0, 1, out6, None) == L.E_INVALID       # no tiles
