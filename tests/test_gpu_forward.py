@@ -503,3 +503,30 @@ def test_wide_trunk_variant_fp32(G):
     with pytest.raises(NotImplementedError):
         with torch.no_grad():
             MipNerf(num_samples=int(g["num_samples"]), mlp_net_width=512, mlp_net_width_condition=256, precision="bf16").to(G.DEV)(rays, False, True)
+
+
+@pytest.mark.parametrize("kw", [dict(mlp_net_width=130, mlp_net_width_condition=90, mlp_net_depth_condition=2),
+                                dict(mlp_net_width=72, mlp_net_width_condition=24, mlp_net_depth=6, mlp_skip_index=3),
+                                dict(mlp_net_width=300, mlp_net_width_condition=200)])
+def test_padded_widths_on_every_structural_variant_fp32(G, kw):
+    """model.WidthPadding on the OTHER generated structures (two view layers, the 6-layer / skip-3 trunk, the 512-wide fp32 shape):
+    MLP.forward and its parameter gradients against plain torch ops on the same module (fp32: forward 1e-5 relative, gradients 1e-4)."""
+    from mipnerf_pl_amd import MipNerf
+    torch.manual_seed(7)
+    model = MipNerf(num_samples=32, precision="fp32", **kw).to(G.DEV)
+    assert model.mlp.native(torch.device(G.DEV)).padding is not None
+    x = torch.randn(20, 32, 96, device=G.DEV)
+    v = torch.randn(20, 27, device=G.DEV)
+    rgb, dens = model.mlp(x, v)
+    got = torch.cat([rgb, dens], -1)
+    ((got * torch.linspace(-1, 1, got.numel(), device=G.DEV).reshape(got.shape)).sum()).backward()
+    g_native = [p.grad.clone() for p in model.mlp.parameters()]
+    model.mlp.zero_grad(set_to_none=True)
+    ref = G.mlp_torch(model.mlp, x, v, torch.float32)
+    ((ref * torch.linspace(-1, 1, ref.numel(), device=G.DEV).reshape(ref.shape)).sum()).backward()
+    scale = float(ref.detach().abs().max())
+    assert G.maxdiff(got, ref) <= 1e-5 * scale, (G.maxdiff(got, ref), scale)
+    for (n, p), g in zip(model.mlp.named_parameters(), g_native):
+        assert g.shape == p.shape
+        assert G.maxdiff(g, p.grad) <= 1e-4 * max(float(p.grad.abs().max()), 1e-6), n
+    G.record(f"padded_widths {kw.get('mlp_net_width')}", fwd_rel=G.maxdiff(got, ref) / scale)
