@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/mipnerf_hip.h"
@@ -812,13 +813,27 @@ int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host) {
     if (splits_host) {
         for (int j = 0; j < tt.njobs; ++j) sp[j] = splits_host[j] < 0 ? 0 : splits_host[j];
     } else {
-        // Equal number of workgroups per job (measured on MI355X, scripts/prof_train.py: 1.00 ms vs 1.17 ms for a
-        // bytes-proportional split at 4096x128 samples): a stage has a fixed cost (barrier + DMA latency) that the
-        // small jobs cannot hide, so balancing stages, not bytes, is what equalises the finish times.
+        // Workgroups per job ~ (blocks the job moves per stage) + kStageFixedBlocks: a stage costs its bytes plus a fixed part (barrier +
+        // DMA latency; a job alone on 16 workgroups takes 0.09 us + 0.046 us per 2-KiB block per stage, scripts/prof_train.py
+        // --experiments).  Measured on MI355X at 4096 x 128 samples per level (profiles/r03aa_wgrad_splits.txt): bytes-proportional
+        // (fixed part 0) 0.954 ms, equal workgroups per job (the rounds 1-2 default; fixed part -> infinity) 0.851-0.853 ms, fixed part
+        // of 4 blocks 0.817 ms -- the small jobs no longer hold 21 CUs each long after they could have finished on 11.  All of the
+        // grid is handed out (largest remainders first).
+        constexpr double kStageFixedBlocks = 4.0;
+        std::vector<double> w(tt.njobs);
+        double wsum = 0.0;
+        for (int j = 0; j < tt.njobs; ++j) wsum += (w[j] = tt.jobs[j * 20 + 0] + tt.jobs[j * 20 + 1] + kStageFixedBlocks);
+        int total = 0;
+        std::vector<std::pair<double, int>> frac(tt.njobs);
         for (int j = 0; j < tt.njobs; ++j) {
-            sp[j] = c->grid_limit / tt.njobs;
-            if (sp[j] < 1) sp[j] = 1;
+            const double x = w[j] / wsum * c->grid_limit;
+            sp[j] = (int)x < 1 ? 1 : (int)x;
+            frac[j] = {x - sp[j], j};
+            total += sp[j];
         }
+        std::sort(frac.begin(), frac.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+            return a.first > b.first || (a.first == b.first && a.second < b.second); });
+        for (int k = 0; total < c->grid_limit && k < tt.njobs; ++k, ++total) ++sp[frac[k].second];
     }
     std::vector<int4> wgtab;
     std::vector<int2> slots(tt.njobs);

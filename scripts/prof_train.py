@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--experiments", action="store_true")
+    ap.add_argument("--job-ints", type=int, default=0, help="experiments with MIPNERF_LIB=<another build>: int32 per row of ITS job table")
     ap.add_argument("--wgrad-only", action="store_true", help="time only the wgrad kernel (for rocprofv3 --pmc passes)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -103,6 +104,21 @@ def main():
         return
     names = [j.name for j in tp.jobs]
     nj = len(names)
+    if args.job_ints:       # A/B against a library built from another commit: take the job list from ITS table
+        n = int(lib.mipnerf_debug_table_variant(0, 5, None, 0))
+        buf = (C.c_int32 * n)()
+        lib.mipnerf_debug_table_variant(0, 5, buf, n)
+        jt = np.array(buf[:]).reshape(-1, args.job_ints)
+        nj = jt.shape[0]
+        names = [f"job{j}" for j in range(nj)]
+
+        class _J:
+            pass
+        tp.jobs = []
+        for r in jt:
+            j = _J()
+            j.a_blocks, j.b_blocks = list(range(int(r[0]))), list(range(int(r[1])))
+            tp.jobs.append(j)
 
     def set_splits(sp):
         nonlocal part
@@ -127,6 +143,16 @@ def main():
     for each in (18, 36):
         set_splits([each] * nj)
         print(json.dumps(dict(exp="equal_splits", total=each * nj, ms=timed(wgrad_noreduce, 5))), flush=True)
+    # (b2) round 3 (merged skip-layer job: 19 blocks): workgroups per job ~ blocks + c0, c0 = the fixed cost of a stage in block units
+    for total in (256,):
+        for c0 in (0, 4, 8, 12, 16, 24, 32, 64, 1e6):
+            w = cost + c0
+            sp = np.maximum(1, np.floor(w / w.sum() * total)).astype(int)
+            order = np.argsort(-(w / w.sum() * total - sp))            # hand the remainder to the largest fractional parts
+            for k in range(int(total - sp.sum())):
+                sp[order[k % nj]] += 1
+            set_splits(list(int(x) for x in sp))
+            print(json.dumps(dict(exp="blocks_plus_c0", c0=c0, total=int(sp.sum()), splits=[int(x) for x in sp], ms=timed(wgrad_noreduce, 8))), flush=True)
     # (c) main jobs only / small jobs only at default proportions
     sp = np.maximum(1, np.floor(cost / cost.sum() * 256)).astype(int)
     big = [int(s) if cost[i] == 16 else 0 for i, s in enumerate(sp)]
