@@ -20,7 +20,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
-constexpr int kStages = 4;
+#ifndef MIP_WGRAD_STAGES
+#define MIP_WGRAD_STAGES 4
+#endif
+constexpr int kStages = MIP_WGRAD_STAGES;      // LDS ring depth (build knob MLP_WGRAD_STAGES: 3 / 5 measured no better, profiles/r03aa_wgrad_splits.txt)
 constexpr int kStageBytes = 16 * 2048;       // [8 activation blocks | 8 delta blocks] x 2 KiB
 constexpr int kWgradLds = kStages * kStageBytes;
 
