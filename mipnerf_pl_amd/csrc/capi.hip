@@ -116,7 +116,14 @@ void build_tables(Tables& T, const PlanDesc& P) {
     net.nlayers = kNumOps;
     net.width = kNetWidth;
     net.xyz_dim = kXyzDim;
-    const int ecols = kXyzDim > 32 ? kXyzDim : 32;
+    // Wide encodings (the 672 off-axis features of the unbounded-scene model): a 64-sample tile with the encoding resident does not
+    // fit the CU's LDS.  Instead of halving the tile (half the reuse of every weight chunk), the two layers that read the encoding
+    // stream that B operand from global memory (it stays in L1 / L2: 64 rows x 64 B per k block), and the encoding columns shrink to
+    // the view features + the VALU heads' partials.
+    const int ecols_full = kXyzDim > 32 ? kXyzDim : 32;
+    const bool stream_enc = mip::mlp_f32_tile_samples(2 * kNetWidth + ecols_full + 4) < 64 && mip::mlp_f32_tile_samples(2 * kNetWidth + 64 + 4) == 64;
+    const int ecols = stream_enc ? 64 : ecols_full;
+    net.pad = stream_enc ? 1 : 0;
     net.enc_col = 2 * kNetWidth;
     net.dens_col = 2 * kNetWidth + ecols;
     net.num_rgb = P.num_rgb;
@@ -145,6 +152,9 @@ void build_tables(Tables& T, const PlanDesc& P) {
         L.kind = op.kind;
         L.chunk0 = (int)cf;
         L.stage_view = (op.kind == 1 && P.use_viewdirs) ? 1 : 0;
+        // bit 0 / 1: K segment 0 / 1 is the sample encoding and is streamed from global memory (see above)
+        L.pad = (stream_enc && op.segs[0].kind == 0 && op.segs[0].ncols == kXyzDim ? 1 : 0) |
+                (stream_enc && op.nsegs > 1 && op.segs[1].kind == 0 && op.segs[1].ncols == kXyzDim ? 2 : 0);
         if (op.kind == 0 || (op.kind == 1 && op.ntiles > 1)) cur_col = out_col;     // a density-only head moves nothing
         for (int t = 0; t < op.ntiles; ++t)
             for (int k = 0; k < kb; ++k) {

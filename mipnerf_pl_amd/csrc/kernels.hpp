@@ -150,17 +150,17 @@ struct F32Layer {
     int kind;        // 0: write tiles to X[:, x_out + 32 t]; 1: head (last tile = density); 2: colour
     int chunk0;      // first 2-KiB chunk of this layer in the fp32 stream
     int stage_view;  // 1: load the view encoding into the encoding columns during this layer
-    int pad;
+    int pad;         // bit 0 / 1: K segment 0 / 1 = the sample encoding streamed from global memory (F32Net.pad = 1: wide encodings)
 };
 struct F32Net {
     int nlayers;
     int width;       // net_width
     int xyz_dim;
-    int ldx;         // LDS row stride in floats: 2 * width + max(xyz_dim, 32) + 4
+    int ldx;         // LDS row stride in floats: 2 * width + max(xyz_dim, 32) + 4 (2 * width + 64 + 4 when the encoding is streamed)
     int enc_col;     // 2 * width
     int dens_col;    // first spare column behind the encoding
     int num_rgb;
-    int pad;
+    int pad;         // 1: the sample encoding is NOT staged in LDS (it would not fit a 64-sample tile); layers flag the segments that stream it
     const float* dens_w;   // fp32 master parameters of the two thin heads (device pointers, set per launch):
     const float* dens_b;   //   density_layer.weight [1, W] / .bias, color_layer.weight [num_rgb, K] / .bias
     const float* col_w;

@@ -36,7 +36,9 @@ constexpr int kF32Rounds = 2;   // hidden tiles per wave: widths up to 512 (16 t
 // TS = samples per workgroup tile: 64 (two 32-sample MFMA halves per weight chunk; every shape whose LDS rows fit: 64 x ldx x 4 B
 // <= 160 KiB) or 32 (one half; wide encodings such as the 672 off-axis features of the unbounded-scene model: half the reuse of
 // every weight chunk, same arithmetic and summation order per sample)
-template <int TS>
+// STREAM = the sample encoding is not staged in LDS: the layers that read it take that B operand from global memory (wide encodings;
+// a separate instantiation, so that the resident-encoding kernel keeps its inner loop)
+template <int TS, bool STREAM>
 __global__ void __launch_bounds__(kF32Waves * 64)
 k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __restrict__ bias_tab,
           const float* __restrict__ enc, const float* __restrict__ viewenc, float4* __restrict__ rgb_sigma,
@@ -79,8 +81,8 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
     for (int tile = blockIdx.x; tile < ntiles_total; tile += gridDim.x) {
         const int64_t s0 = (int64_t)tile * kF32TileSamples;
         __syncthreads();     // the previous tile's last reads of X are done
-        // ---- stage the encoding: X[s][ecol + c] = enc[s0+s][c]
-        {
+        // ---- stage the encoding: X[s][ecol + c] = enc[s0+s][c]  (not for wide encodings: their two readers stream it, see the k loop)
+        if (!STREAM) {
             const int vec_per_row = net.xyz_dim / 4;
             for (int i = tid; i < kF32TileSamples * vec_per_row; i += blockDim.x) {
                 const int r = i / vec_per_row, c4 = i - r * vec_per_row;
@@ -114,16 +116,49 @@ k_mlp_f32(const F32Net net, const float* __restrict__ wstream, const float* __re
                     const float* xb = X + n * ldx + ly.x_in1 + hi * 8 - ly.kb0 * 16;         // segment 1 (indexed by the global kb)
                     float4 a0 = *reinterpret_cast<const float4*>(wp);
                     float4 a1 = *reinterpret_cast<const float4*>(wp + 4);
+                    // streamed encoding segments (wide encodings): lane (hi, n) reads its 8 k values of k block kb straight from the
+                    // global encoding rows of samples n and 32 + n, one k block ahead (the same values the LDS copy would hold)
+                    const int gseg = STREAM ? ly.pad : 0;                      // wave-uniform; 0 at compile time in the resident kernel
+                    const float* ge0 = nullptr;
+                    const float* ge1 = nullptr;
+                    if (STREAM && gseg) {
+                        int64_t r0 = s0 + n, r1 = s0 + 32 + n;
+                        if (r0 >= M) r0 = M - 1;
+                        if (r1 >= M) r1 = M - 1;
+                        ge0 = enc + r0 * net.xyz_dim + hi * 8;
+                        ge1 = enc + r1 * net.xyz_dim + hi * 8;
+                    }
+                    // (plain code, no lambdas: by-reference captures would push the four registers to scratch)
+#define MIP_F32_IS_GLOB(KB) (((KB) < ly.kb0 ? (gseg & 1) : (gseg & 2)) != 0)
+#define MIP_F32_GLOAD(KB)                                                          \
+    do {                                                                           \
+        const int c_ = ((KB) < ly.kb0 ? (KB) : (KB) - ly.kb0) * 16;                \
+        g00 = *reinterpret_cast<const float4*>(ge0 + c_);                          \
+        g01 = *reinterpret_cast<const float4*>(ge0 + c_ + 4);                      \
+        if (NT > 1) {                                                              \
+            g10 = *reinterpret_cast<const float4*>(ge1 + c_);                      \
+            g11 = *reinterpret_cast<const float4*>(ge1 + c_ + 4);                  \
+        }                                                                          \
+    } while (0)
+                    float4 g00 = make_float4(0.f, 0.f, 0.f, 0.f), g01 = g00, g10 = g00, g11 = g00;
+                    if (STREAM && gseg && kbt > 0 && MIP_F32_IS_GLOB(0)) MIP_F32_GLOAD(0);
                     for (int kb = 0; kb < kbt; ++kb) {
                         const int kn = kb + 1 < kbt ? kb + 1 : kb;
                         const float4 n0 = *reinterpret_cast<const float4*>(wp + (size_t)kn * 512);
                         const float4 n1 = *reinterpret_cast<const float4*>(wp + (size_t)kn * 512 + 4);
-                        const float* x0 = (kb < ly.kb0 ? xa : xb) + kb * 16;
-                        const float* x1 = NT > 1 ? x0 + 32 * ldx : x0;
-                        const float4 b00 = *reinterpret_cast<const float4*>(x0);
-                        const float4 b01 = *reinterpret_cast<const float4*>(x0 + 4);
-                        const float4 b10 = *reinterpret_cast<const float4*>(x1);
-                        const float4 b11 = *reinterpret_cast<const float4*>(x1 + 4);
+                        float4 b00, b01, b10, b11;
+                        if (STREAM && gseg && MIP_F32_IS_GLOB(kb)) {
+                            b00 = g00; b01 = g01;
+                            if (NT > 1) { b10 = g10; b11 = g11; } else { b10 = g00; b11 = g01; }
+                        } else {
+                            const float* x0 = (kb < ly.kb0 ? xa : xb) + kb * 16;
+                            const float* x1 = NT > 1 ? x0 + 32 * ldx : x0;
+                            b00 = *reinterpret_cast<const float4*>(x0);
+                            b01 = *reinterpret_cast<const float4*>(x0 + 4);
+                            b10 = *reinterpret_cast<const float4*>(x1);
+                            b11 = *reinterpret_cast<const float4*>(x1 + 4);
+                        }
+                        if (STREAM && gseg && kb + 1 < kbt && MIP_F32_IS_GLOB(kb + 1)) MIP_F32_GLOAD(kb + 1);      // next k block's B operand, under this block's 16 MFMAs
                         const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                         const float b0[8] = {b00.x, b00.y, b00.z, b00.w, b01.x, b01.y, b01.z, b01.w};
                         const float b1[8] = {b10.x, b10.y, b10.z, b10.w, b11.x, b11.y, b11.z, b11.w};
@@ -248,21 +283,27 @@ hipError_t launch_mlp_f32(const F32Net& net_in, const float* stream_w, const flo
     if (ts == 0) return hipErrorInvalidValue;      // not even a 32-sample tile fits the CU's LDS
     const int ntiles = (int)((M + ts - 1) / ts);
     const int lds = ts * net.ldx * (int)sizeof(float);
-    static int attr_lds[2] = {0, 0};
-    if (attr_lds[ts == 64] < lds) {
-        hipError_t er = ts == 64 ? hipFuncSetAttribute((const void*)k_mlp_f32<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
-                                 : hipFuncSetAttribute((const void*)k_mlp_f32<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const bool stream = net.pad != 0;
+    if (stream && ts != 64) return hipErrorInvalidValue;       // the streamed-encoding kernel exists for 64-sample tiles
+    static int attr_lds[3] = {0, 0, 0};
+    const int which = stream ? 2 : (ts == 64 ? 1 : 0);
+    if (attr_lds[which] < lds) {
+        hipError_t er = which == 2 ? hipFuncSetAttribute((const void*)k_mlp_f32<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                      : which == 1 ? hipFuncSetAttribute((const void*)k_mlp_f32<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)
+                                   : hipFuncSetAttribute((const void*)k_mlp_f32<32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (er != hipSuccess) return er;
-        attr_lds[ts == 64] = lds;
+        attr_lds[which] = lds;
     }
     int grid = ntiles < 256 * 16 ? ntiles : 256 * 16;
     if (grid < 1) grid = 1;
-    if (ts == 64)
-        hipLaunchKernelGGL(k_mlp_f32<64>, dim3(grid), dim3(kF32Waves * 64), lds, st, net, stream_w, bias_tab, enc, viewenc,
-                           (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save, save_bits, dnoise, dnoise_scale);
-    else
-        hipLaunchKernelGGL(k_mlp_f32<32>, dim3(grid), dim3(kF32Waves * 64), lds, st, net, stream_w, bias_tab, enc, viewenc,
-                           (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save, save_bits, dnoise, dnoise_scale);
+#define MIP_F32_LAUNCH(TSV, STR)                                                                                                       \
+    hipLaunchKernelGGL((k_mlp_f32<TSV, STR>), dim3(grid), dim3(kF32Waves * 64), lds, st, net, stream_w, bias_tab, enc, viewenc,         \
+                       (float4*)rgb_sigma, (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, save, save_bits, dnoise, \
+                       dnoise_scale)
+    if (which == 2) MIP_F32_LAUNCH(64, true);
+    else if (which == 1) MIP_F32_LAUNCH(64, false);
+    else MIP_F32_LAUNCH(32, false);
+#undef MIP_F32_LAUNCH
     return hipGetLastError();
 }
 
