@@ -125,6 +125,29 @@ struct Rng {
     }
 };
 
+// device buffers / events of a diagnostic run: released on every exit path (the DG macro returns early on a HIP error)
+struct DevBufs {
+    std::vector<void*> ptrs;
+    std::vector<hipEvent_t> events;
+    template <typename T>
+    hipError_t alloc(T** p, size_t bytes) {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, bytes);
+        if (e == hipSuccess) ptrs.push_back(q);
+        *p = static_cast<T*>(q);
+        return e;
+    }
+    hipError_t event(hipEvent_t* ev) {
+        const hipError_t e = hipEventCreate(ev);
+        if (e == hipSuccess) events.push_back(*ev);
+        return e;
+    }
+    ~DevBufs() {
+        for (hipEvent_t ev : events) (void)hipEventDestroy(ev);
+        for (void* q : ptrs) (void)hipFree(q);
+    }
+};
+
 }  // namespace
 
 // Returns 0 on success.  tflops: algorithmic 2*32*32*16 flop per MFMA over the measured half of `seconds`;
@@ -137,6 +160,7 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
         if (e_ != hipSuccess) { snprintf(msg, msg_cap, "%s: %s", #x, hipGetErrorString(e_)); return -1; } \
     } while (0)
     int dev = 0, cus = 0;
+    DevBufs res;
     DG(hipGetDevice(&dev));
     DG(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const size_t nA = 64 * 64 * 8, nB = 16 * 64 * 8;
@@ -158,23 +182,23 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
         Rng r2{0xD1B54A32D192ED03ull};
         for (auto& x : hs) x = f2bf((r2.uni() - 0.5f) * 0.2f);
     }
-    DG(hipMalloc(&dS, hs.size() * 2));
+    DG(res.alloc(&dS, hs.size() * 2));
     DG(hipMemcpyAsync(dS, hs.data(), hs.size() * 2, hipMemcpyHostToDevice, st));
-    DG(hipMalloc(&dA, nA * 2));
-    DG(hipMalloc(&dB, nB * 2));
-    DG(hipMalloc(&dOut, (size_t)cus * 512 * 4));
+    DG(res.alloc(&dA, nA * 2));
+    DG(res.alloc(&dB, nB * 2));
+    DG(res.alloc(&dOut, (size_t)cus * 512 * 4));
     DG(hipMemcpyAsync(dA, ha.data(), nA * 2, hipMemcpyHostToDevice, st));
     DG(hipMemcpyAsync(dB, hb.data(), nB * 2, hipMemcpyHostToDevice, st));
     DG(hipStreamSynchronize(st));
     hipEvent_t e0, e1;
-    DG(hipEventCreate(&e0));
-    DG(hipEventCreate(&e1));
+    DG(res.event(&e0));
+    DG(res.event(&e1));
     const int threads = 256 * waves_per_simd;
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     bf16x8* dStore = nullptr;
-    if (lds_reads_per_mfma == 3) DG(hipMalloc(&dStore, (size_t)cus * 8 * kIters * 7 * 1024));       // 3.7 GB: every store address is written once per launch
+    if (lds_reads_per_mfma == 3) DG(res.alloc(&dStore, (size_t)cus * 8 * kIters * 7 * 1024));       // 3.7 GB: every store address is written once per launch
     auto launch = [&]() {
         if (lds_reads_per_mfma == 3) hipLaunchKernelGGL(k_mfma_ceiling<3>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
         else if (lds_reads_per_mfma == 2) hipLaunchKernelGGL(k_mfma_ceiling<2>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
@@ -210,13 +234,6 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
     *ms_per_launch = per;
     *tflops = flop / (per * 1e-3) / 1e12;
     *clock_ghz = (double)kUnroll * kIters * 32.0 * waves_per_simd / (per * 1e-3) / 1e9;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(dA);
-    hipFree(dB);
-    hipFree(dS);
-    hipFree(dStore);
-    hipFree(dOut);
     snprintf(msg, msg_cap, "ok");
     return 0;
 #undef DG
@@ -521,6 +538,7 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
         if (e_ != hipSuccess) { snprintf(msg, msg_cap, "%s: %s", #x, hipGetErrorString(e_)); return -1; } \
     } while (0)
     int dev = 0, cus = 0;
+    DevBufs res;
     DG(hipGetDevice(&dev));
     DG(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (cus != 256) { snprintf(msg, msg_cap, "probe assumes 256 CUs in 8 XCDs, device has %d", cus); return -2; }
@@ -541,14 +559,14 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
     unsigned long long* stall = nullptr;
     bf16x8* ab = nullptr;
     float* sink = nullptr;
-    DG(hipMalloc(&ring_mem, (size_t)pairs * ring * tile_bytes));
-    DG(hipMalloc(&ready, pairs * 8 * 4));          // probe v2: one counter per wave stream
-    DG(hipMalloc(&consumed, pairs * 8 * 4));
-    DG(hipMalloc(&abort_word, 4));
-    DG(hipMalloc(&errors, 4));
-    DG(hipMalloc(&stall, 512 * 8));
-    DG(hipMalloc(&ab, 128 * 16));
-    DG(hipMalloc(&sink, 256 * 4));
+    DG(res.alloc(&ring_mem, (size_t)pairs * ring * tile_bytes));
+    DG(res.alloc(&ready, pairs * 8 * 4));          // probe v2: one counter per wave stream
+    DG(res.alloc(&consumed, pairs * 8 * 4));
+    DG(res.alloc(&abort_word, 4));
+    DG(res.alloc(&errors, 4));
+    DG(res.alloc(&stall, 512 * 8));
+    DG(res.alloc(&ab, 128 * 16));
+    DG(res.alloc(&sink, 256 * 4));
     std::vector<uint16_t> hab(128 * 8);
     Rng r{0x1234567ull};
     for (auto& x : hab) x = f2bf(r.uni() - 0.3f);
@@ -564,8 +582,8 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
     DG(hipFuncSetAttribute((const void*)k_handoff_waves<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     DG(hipFuncSetAttribute((const void*)k_handoff_waves<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
-    DG(hipEventCreate(&e0));
-    DG(hipEventCreate(&e1));
+    DG(res.event(&e0));
+    DG(res.event(&e1));
     double best_ms = 1e30;
     for (int rep = 0; rep < reps + 1; ++rep) {    // first repetition = warm-up
         DG(hipMemsetAsync(ready, 0, pairs * 8 * 4, st));
@@ -608,9 +626,6 @@ int run_handoff_probe(int same_xcd, int flavour, int tiles, int ring, int tile_b
     out[3] = sc / 128;
     out[4] = (double)h_err;
     out[5] = (double)h_abort;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(ring_mem); hipFree(ready); hipFree(consumed); hipFree(abort_word); hipFree(errors); hipFree(stall); hipFree(ab); hipFree(sink);
     snprintf(msg, msg_cap, "ok");
     return 0;
 #undef DG
