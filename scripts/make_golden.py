@@ -27,6 +27,10 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-ctor              round 2: num_levels=1; disable_integration / deg range / paddings / density bias off their defaults
     --only-metrics / --only-raygen / --only-mlp-grad     single round-1 files
 
+Thread count: torch's CPU GEMMs sum in a thread-count-dependent order, so values move in the last bits with it.  Every committed
+file was written with the default (GOLDEN_THREADS unset = os.cpu_count() = 8 in the build container) and regenerates value for value
+that way; the quality runs name their thread counts explicitly (3 / 2 / 1: they ARE the reference's spread).
+
 The reference's own tests hold no golden vectors (it has no tests), so these files
 are the pin for oracle/mipnerf_oracle.py and, through it, for the HIP path.
 Import recipe: SURVEY.md section 8(c) -- stub `cv2` (only used at datasets.py:196),
