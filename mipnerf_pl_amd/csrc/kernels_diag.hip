@@ -26,7 +26,7 @@ constexpr unsigned kStreamChunks = 1216;   // one-KiB chunks of the shipped netw
 template <int LDS>
 __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__ a_src, const bf16x8* __restrict__ b_src,
                                                      float* __restrict__ out, int iters, const bf16x8* __restrict__ dma_src,
-                                                     bf16x8* __restrict__ store_dst, int store_pattern) {
+                                                     bf16x8* __restrict__ store_dst) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     bf16x8 A[8], B[16];
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__
             // LDS), i.e. 8 chunks per 64 MFMAs of its own; source = a 1.19-MiB stream that stays in the XCD's L2, destination = the half
             // of the ring the MFMAs are NOT reading in this iteration.  The previous iteration's DMAs are drained first (the kernel waits
             // for them before its ring barrier).
-            if (LDS == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      // the DMAs are done; last iteration's 7 stores may still fly
+            if (LDS >= 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");      // the DMAs are done; last iteration's 7 stores may still fly
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned chunk0 = ((unsigned)(it * 8 + wave) * 8u) % (kStreamChunks - 8);
             const char* g = reinterpret_cast<const char*>(dma_src) + (size_t)chunk0 * 1024;
@@ -86,12 +86,13 @@ __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__
             if (LDS >= 1) a = *reinterpret_cast<const bf16x8*>(base + (j & 31) * 1024);
             else a = A[j & 7];
             acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, B[(j * 5) & 15], acc[j & 3], 0, 0, 0);
-            if (LDS == 3 && (j % 9) == 4) {
+            if (LDS >= 3 && (j % 9) == 4) {
                 // the saved-activation stream of k_mlp_bf16_trainfwd: 4,608 B per sample = one 1-KiB non-temporal store per wave every
                 // 9.4 MFMAs (7 per 64), each to a fresh address (write-once, 3.7 GB per launch)
-                // store_pattern 0: every wave fills its own contiguous region (tile-major T-blocks, what the training kernels do);
-                // 1: at every step the 2048 waves of the chip write ADJACENT 1-KiB chunks (block-major: [store index][wave])
-                bf16x8* dst = store_pattern == 0
+                // LDS == 3: every wave fills its own contiguous region (tile-major T-blocks, what the training kernels do);
+                // LDS == 4: at every step the 2048 waves of the chip write ADJACENT 1-KiB chunks (block-major: [store index][wave]) --
+                // a separate instantiation (MIPNERF_CEILING_STORE_PATTERN=1), so that neither pays for choosing at run time
+                bf16x8* dst = LDS == 3
                     ? store_dst + ((((size_t)blockIdx.x * 8 + wave) * (size_t)iters + it) * 7 + j / 9) * 64 + lane
                     : store_dst + (((size_t)it * 7 + j / 9) * ((size_t)gridDim.x * 8) + (size_t)blockIdx.x * 8 + wave) * 64 + lane;
                 __builtin_nontemporal_store(B[j & 15], dst);
@@ -201,15 +202,17 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     bf16x8* dStore = nullptr;
     const char* pat_env = getenv("MIPNERF_CEILING_STORE_PATTERN");      // experiment knob of feeding mode 3 (see the kernel)
     const int store_pattern = pat_env ? atoi(pat_env) : 0;
     if (lds_reads_per_mfma == 3) DG(res.alloc(&dStore, (size_t)cus * 8 * kIters * 7 * 1024));       // 3.7 GB: every store address is written once per launch
     auto launch = [&]() {
-        if (lds_reads_per_mfma == 3) hipLaunchKernelGGL(k_mfma_ceiling<3>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore, store_pattern);
-        else if (lds_reads_per_mfma == 2) hipLaunchKernelGGL(k_mfma_ceiling<2>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore, store_pattern);
-        else if (lds_reads_per_mfma) hipLaunchKernelGGL(k_mfma_ceiling<1>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore, store_pattern);
-        else hipLaunchKernelGGL(k_mfma_ceiling<0>, dim3(cus), dim3(threads), 0, st, dA, dB, dOut, kIters, dS, dStore, store_pattern);
+        if (lds_reads_per_mfma == 3 && store_pattern == 1) hipLaunchKernelGGL(k_mfma_ceiling<4>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
+        else if (lds_reads_per_mfma == 3) hipLaunchKernelGGL(k_mfma_ceiling<3>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
+        else if (lds_reads_per_mfma == 2) hipLaunchKernelGGL(k_mfma_ceiling<2>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
+        else if (lds_reads_per_mfma) hipLaunchKernelGGL(k_mfma_ceiling<1>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
+        else hipLaunchKernelGGL(k_mfma_ceiling<0>, dim3(cus), dim3(threads), 0, st, dA, dB, dOut, kIters, dS, dStore);
     };
     const double flop = 2.0 * 32 * 32 * 16 * (double)kUnroll * kIters * (threads / 64) * cus;
     launch();
