@@ -447,6 +447,10 @@ def run_ceiling(args, e):
     # matrix pipe sustains while the producers of the training step write their T-blocks; the stores run at store_TBps
     out["lds_dma_and_store_fed"] = out["variants"][3]["frac_of_peak"]
     out["store_TBps_in_that_variant"] = round(256 * 8 * 256 * 7 * 1024 / (out["variants"][3]["ms_per_launch"] * 1e-3) / 1e12, 3)
+    # the fp32 matrix instruction of the parity mode / configs[3] (v_mfma_f32_32x32x2_f32), register-fed
+    r = (C.c_double * 3)()
+    L.check(L.lib().mipnerf_mfma_ceiling(10, 2, 1, float(args.ceiling_seconds), r, st), "mfma_ceiling fp32")
+    out["fp32_register_fed"] = {"tflops": round(r[0], 1), "frac_of_peak": round(r[0] / PEAK_TFLOPS["fp32"], 4), "effective_clock_ghz": round(r[2], 3)}
     return out
 
 
@@ -679,6 +683,9 @@ def main():
             line["ceiling"] = ceiling
             if line.get("roofline") and "lds_fed" in ceiling and ceiling["lds_fed"] > 0:
                 line["roofline"]["frac_of_measured_lds_fed_ceiling"] = round(line["roofline"]["frac"] / ceiling["lds_fed"], 4)
+                if "fp32" in recs and recs["fp32"].get("roofline") and ceiling.get("fp32_register_fed", {}).get("frac_of_peak", 0) > 0:
+                    recs["fp32"]["roofline"]["frac_of_measured_register_fed_ceiling"] = round(
+                        recs["fp32"]["roofline"]["frac"] / ceiling["fp32_register_fed"]["frac_of_peak"], 4)
                 if ceiling.get("lds_and_dma_fed", 0) > 0:
                     line["roofline"]["frac_of_measured_lds_and_dma_fed_ceiling"] = round(line["roofline"]["frac"] / ceiling["lds_and_dma_fed"], 4)
         for k, r in recs.items():

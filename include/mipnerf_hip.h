@@ -382,6 +382,7 @@ int mipnerf_mlp_launch_stats(mipnerf_ctx* ctx, double* total_ms, int64_t* launch
  * ds_read_b128 weight fragment per MFMA as in k_mlp_bf16 (1), or (2) the same plus k_mlp_bf16's weight DMA: every wave moves 8 one-KiB
  * chunks of an L2-resident 1.19-MiB stream into the LDS ring per 64 of its MFMAs with global_load_lds, or (3) that plus the training forward's
  * saved-activation stream: one 1-KiB non-temporal store per wave per 9.4 MFMAs to fresh addresses (3.7 GB per launch; 2 waves per SIMD);
+ * (10) = the fp32 matrix instruction of the parity mode (v_mfma_f32_32x32x2_f32), register-fed, TFLOP/s against the 157.3 of the datasheet;
  * operands all zero or MLP-like random (weights U(-0.1,0.1),
  * activations relu(N(0,1))).  Runs for `seconds` (first half un-measured heat-up).  out3 = {TFLOP/s, ms per launch,
  * shader clock in GHz implied by the MFMA issue rate}.  Diagnostic: allocates and synchronises. */

@@ -1317,9 +1317,9 @@ int mipnerf_selftest(void* stream) {
 }
 
 int mipnerf_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_operands, double seconds, double* out3, void* stream) {
-    if (!out3 || waves_per_simd < 1 || waves_per_simd > 2 || lds_reads_per_mfma < 0 || lds_reads_per_mfma > 3 || !(seconds > 0) || seconds > 30 ||
+    if (!out3 || waves_per_simd < 1 || waves_per_simd > 2 || lds_reads_per_mfma < 0 || (lds_reads_per_mfma > 3 && lds_reads_per_mfma != 10) || !(seconds > 0) || seconds > 30 ||
         (lds_reads_per_mfma == 3 && waves_per_simd != 2))
-        return fail(MIPNERF_E_INVALID, "mfma_ceiling: waves_per_simd in {1,2}, lds_reads_per_mfma (feeding mode) in {0,1,2,3; 3 needs 2 waves per SIMD}, 0 < seconds <= 30");
+        return fail(MIPNERF_E_INVALID, "mfma_ceiling: waves_per_simd in {1,2}, lds_reads_per_mfma (feeding mode) in {0,1,2,3,10; 3 needs 2 waves per SIMD}, 0 < seconds <= 30");
     char msg[256];
     const int rc = mip::run_mfma_ceiling(lds_reads_per_mfma, waves_per_simd, random_operands, seconds, out3, out3 + 1, out3 + 2, S(stream), msg, sizeof msg);
     g_err = msg;

@@ -114,6 +114,39 @@ __global__ void __launch_bounds__(512) k_mfma_ceiling(const bf16x8* __restrict__
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the fp32 matrix instruction of the parity mode (v_mfma_f32_32x32x2_f32: 4,096 flop, 64 cycles per SIMD), register-fed, back to back
+__global__ void __launch_bounds__(512) k_mfma_ceiling_f32(const float* __restrict__ a_src, const float* __restrict__ b_src,
+                                                         float* __restrict__ out, int iters) {
+    const int lane = threadIdx.x & 63;
+    float A[8], B[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) A[i] = a_src[i * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) B[i] = b_src[i * 64 + lane];
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < kUnroll; ++j)
+            acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[j & 7], B[(j * 5) & 15], acc[j & 3], 0, 0, 0);
+        if ((it & 15) == 15) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= 1e-3f;
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 uint16_t f2bf(float f) {
     uint32_t u;
     memcpy(&u, &f, 4);
@@ -199,6 +232,26 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
     DG(res.event(&e0));
     DG(res.event(&e1));
     const int threads = 256 * waves_per_simd;
+    const bool fp32_mode = lds_reads_per_mfma == 10;
+    float *fA = nullptr, *fB = nullptr;
+    if (fp32_mode) {
+        std::vector<float> ha32(8 * 64, 0.0f), hb32(16 * 64, 0.0f);
+        if (random_operands) {
+            Rng r3{0xA0761D6478BD642Full};
+            for (auto& x : ha32) x = (r3.uni() - 0.5f) * 0.2f;
+            for (auto& x : hb32) {
+                float g = 0;
+                for (int k = 0; k < 12; ++k) g += r3.uni();
+                g -= 6.0f;
+                x = g > 0 ? g : 0.0f;
+            }
+        }
+        DG(res.alloc(&fA, ha32.size() * 4));
+        DG(res.alloc(&fB, hb32.size() * 4));
+        DG(hipMemcpyAsync(fA, ha32.data(), ha32.size() * 4, hipMemcpyHostToDevice, st));
+        DG(hipMemcpyAsync(fB, hb32.data(), hb32.size() * 4, hipMemcpyHostToDevice, st));
+        DG(hipStreamSynchronize(st));
+    }
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     DG(hipFuncSetAttribute((const void*)k_mfma_ceiling<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
@@ -208,13 +261,14 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
     const int store_pattern = pat_env ? atoi(pat_env) : 0;
     if (lds_reads_per_mfma == 3) DG(res.alloc(&dStore, (size_t)cus * 8 * kIters * 7 * 1024));       // 3.7 GB: every store address is written once per launch
     auto launch = [&]() {
+        if (fp32_mode) { hipLaunchKernelGGL(k_mfma_ceiling_f32, dim3(cus), dim3(threads), 0, st, fA, fB, dOut, kIters); return; }
         if (lds_reads_per_mfma == 3 && store_pattern == 1) hipLaunchKernelGGL(k_mfma_ceiling<4>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
         else if (lds_reads_per_mfma == 3) hipLaunchKernelGGL(k_mfma_ceiling<3>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
         else if (lds_reads_per_mfma == 2) hipLaunchKernelGGL(k_mfma_ceiling<2>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
         else if (lds_reads_per_mfma) hipLaunchKernelGGL(k_mfma_ceiling<1>, dim3(cus), dim3(threads), 65536, st, dA, dB, dOut, kIters, dS, dStore);
         else hipLaunchKernelGGL(k_mfma_ceiling<0>, dim3(cus), dim3(threads), 0, st, dA, dB, dOut, kIters, dS, dStore);
     };
-    const double flop = 2.0 * 32 * 32 * 16 * (double)kUnroll * kIters * (threads / 64) * cus;
+    const double flop = 2.0 * 32 * 32 * (fp32_mode ? 2 : 16) * (double)kUnroll * kIters * (threads / 64) * cus;
     launch();
     DG(hipStreamSynchronize(st));
     const int batch = 20;
@@ -242,7 +296,7 @@ int run_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_oper
     const double per = tot_ms / launches;
     *ms_per_launch = per;
     *tflops = flop / (per * 1e-3) / 1e12;
-    *clock_ghz = (double)kUnroll * kIters * 32.0 * waves_per_simd / (per * 1e-3) / 1e9;
+    *clock_ghz = (double)kUnroll * kIters * (fp32_mode ? 64.0 : 32.0) * waves_per_simd / (per * 1e-3) / 1e9;
     snprintf(msg, msg_cap, "ok");
     return 0;
 #undef DG
