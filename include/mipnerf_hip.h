@@ -303,8 +303,9 @@ int mipnerf_mlp_wgrad(mipnerf_ctx* ctx, int64_t num_points, const void* act, con
  * doubles torch holds (ABI 4; floats before): bias corrections, lr / (1 - beta1^t) and 1 - beta are formed in double. */
 int mipnerf_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                       double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
-/* Tuning: workgroups per weight-gradient job (HOST array, 14 entries for the compiled MLP; 0 skips a job, for
- * timing only).  NULL restores the default.  Changes partial_bytes of mipnerf_mlp_train_sizes; synchronises. */
+/* Tuning: workgroups per weight-gradient job (HOST array, one entry per job of the context's architecture: 12 for the shipped MLP;
+ * 0 skips a job, for timing only).  NULL restores the default (workgroups ~ the 2-KiB blocks a job moves per stage + 4, all CUs
+ * handed out).  Changes partial_bytes of mipnerf_mlp_train_sizes; synchronises. */
 int mipnerf_set_wgrad_splits(mipnerf_ctx* ctx, const int32_t* splits_host);
 
 /* ---- parity-mode (fp32) MLP training: the fused fp32 forward also writes every layer output into `save`

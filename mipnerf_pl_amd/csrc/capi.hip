@@ -814,7 +814,7 @@ int mipnerf_adam_step_scheduled(int64_t n, float* param, const float* grad, floa
 }
 
 // Replace the wgrad work split: splits_host[njobs] workgroups per job (0 = skip the job: its gradients are then
-// NOT produced -- timing experiments only).  NULL restores the default (CUs / njobs workgroups per job).
+// NOT produced -- timing experiments only).  NULL restores the default (workgroups per job ~ blocks per stage + 4, all CUs handed out).
 int mipnerf_set_wgrad_splits(mipnerf_ctx* c, const int32_t* splits_host) {
     if (!c) return fail(MIPNERF_E_INVALID, "ctx is null");
     NEED_BF16_TRAIN("set_wgrad_splits");
