@@ -11,6 +11,8 @@ Run (only possible in the build container; the GPU box has no /root/reference):
     --only-fullsize-train    round 3: loss + all 24 gradients of the reference's training step at 4096x128 (configs[1], configs[2] inputs; ~2 min)
     --only-quality-run TAG THREADS SEED / --only-quality-merge   round 3: reference training runs (600 steps x 1024 rays x 128 samples) on the
                              procedural multi-scale scene, test PSNR at 4 scales (2-4 h of CPU per run)
+    --only-trained-field / --only-fullsize-trained   round 4: the reference trained on the procedural scene (600 steps, ~30 min), then its
+                             forward at 4096x128 / 8192x256 and one training step on the scene's own rays (empty / opaque / soft rays)
     --only-360               round 3: contract() and sample_along_rays_360 fence posts / means of the reference (the parts of its dead 360 code that are right)
     --only-trajectory        round 2: 300-step training trajectories (deterministic / randomized) of the reference's own loop,
                              each run twice (all threads / 1 thread) to record the reference's self-divergence (~20 min)
@@ -556,6 +558,127 @@ def fullsize_train_case(name, batch, num_samples, param_seed, gain, ray_seed, mu
           f"(reference fwd+bwd {dt:.1f} s on {torch.get_num_threads()} threads)")
 
 
+TRAINED_FIELD = dict(batch=1024, num_samples=64, steps=600, lr_init=2e-3, lr_final=2e-5, max_steps=600, lr_delay_steps=50,
+                     lr_delay_mult=0.01, id_seed=4711, param_seed=11, draw_seed=12)
+
+
+def _scene_datasets():
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dataset_fixture as fx
+    from datasets.datasets import Multicam as RefMulticam
+    root = os.environ.get("QUALITY_SCENE_DIR", "/tmp/quality_scene_ms")
+    if not os.path.exists(os.path.join(root, "metadata.json")):
+        fx.write_multicam_scene(root)
+    return fx, RefMulticam(root, "train", True, "all_images")
+
+
+def _scene_batch(train, b):
+    # .astype(float32): see quality_run (numpy >= 2 promotes the reference's radii to float64)
+    R = RefRays(*[torch.from_numpy(np.ascontiguousarray(getattr(train.rays, f)[b], dtype=np.float32)) for f in RefRays._fields])
+    return R, torch.from_numpy(np.ascontiguousarray(train.images[b], dtype=np.float32))
+
+
+def trained_field_run(name):
+    """Round 4: a REALISTIC field for the headline-size parity tests.  The unmodified reference (MipNerf + the loss of
+    nerf_system.py:99-111 + torch.optim.Adam + its MipLRDecay) trained on the procedural multi-scale scene of tests/dataset_fixture.py
+    (white background, five blobs: empty space, surfaces, soft edges), randomized, N = 64, 1024 rays per step; the 24 parameter tensors
+    it ends with are stored.  (The quality goldens of round 3 kept PSNRs only.)"""
+    import time
+    from utils.lr_schedule import MipLRDecay as RefLR
+    Q = TRAINED_FIELD
+    fx, train = _scene_datasets()
+    ids = fx.quality_batch_ids(len(train), Q["steps"], Q["batch"], Q["id_seed"])
+    torch.manual_seed(Q["param_seed"])
+    model = RefMipNerf(num_samples=Q["num_samples"])
+    opt = torch.optim.Adam(model.parameters(), lr=Q["lr_init"])
+    sch = RefLR(opt, Q["lr_init"], Q["lr_final"], Q["max_steps"], Q["lr_delay_steps"], Q["lr_delay_mult"])
+    torch.manual_seed(Q["draw_seed"])
+    losses, psnrs = [], []
+    t0 = time.perf_counter()
+    for k in range(Q["steps"]):
+        R, rgbs = _scene_batch(train, ids[k])
+        ret = model(R, True, True)
+        mask = R.lossmult
+        ls = [(mask * (rgb - rgbs[..., :3]) ** 2).sum() / mask.sum() for rgb, _, _, _, _ in ret]
+        dl = [refmip.distloss(w, t) for _, _, _, w, t in ret]
+        loss = 0.1 * (ls[0] + 0.01 * dl[0]) + ls[1] + 0.01 * dl[-1]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sch.step()
+        losses.append(loss.item())
+        psnrs.append(float(-10.0 * np.log10(np.mean((ret[1][0].detach().numpy() - rgbs.numpy()) ** 2))))
+        if k % 25 == 0 or k == Q["steps"] - 1:
+            print(f"  [trained_field] step {k} loss {losses[-1]:.5f} train psnr {psnrs[-1]:.2f} dB  ({time.perf_counter() - t0:.0f} s)", flush=True)
+    out = {"cfg_" + k: v for k, v in Q.items()}
+    out.update(losses=np.asarray(losses, np.float32), train_psnr=np.asarray(psnrs, np.float32), threads=torch.get_num_threads())
+    for k, p in model.named_parameters():
+        out["p_" + k.replace("mlp.", "")] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz: final loss {np.mean(losses[-20:]):.5f}, train psnr {np.mean(psnrs[-20:]):.2f} dB, {time.perf_counter() - t0:.0f} s")
+
+
+def fullsize_trained_case(name, field, batch, num_samples, ray_seed, train_step):
+    """Headline-size goldens on a realistic field: the reference's forward (mip_nerf.py:172-248; its sampler mip.py:168-229,
+    compositing mip.py:366-401) at 4096 x 128 / 8192 x 256 on rays OF THE SCENE THE FIELD WAS TRAINED ON -- a seeded draw from the
+    multi-scale training set: background, grazing and object rays at four pixel footprints --, every ray of both levels stored; with
+    `train_step` also the loss of nerf_system.py:99-111 against the scene's pixels and the whole gradient.  Inputs (rays, pixels) are
+    stored in the file; the parameters live in `field`.npz.  The golden asserts its own mix of rays: >= 20 % empty (acc < 0.05), >= 20 %
+    opaque (acc > 0.95), >= 5 % in between."""
+    import hashlib
+    import time
+    fx, train = _scene_datasets()
+    f = np.load(os.path.join(OUT, field + ".npz"))
+    params = {k[2:]: f[k] for k in f.files if k.startswith("p_")}
+    ids = np.random.default_rng(ray_seed).permutation(len(train))[:batch]
+    R, rgbs = _scene_batch(train, ids)
+    model = RefMipNerf(num_samples=num_samples)
+    load_params(model, params)
+    out = dict(num_samples=num_samples, batch=batch, ray_seed=ray_seed, field=field, gt=rgbs.numpy())
+    out.update({"rays_" + k: getattr(R, k).numpy() for k in RefRays._fields})
+    h = hashlib.sha256()
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    out["field_sha256"] = h.hexdigest()
+    model.eval()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ret = model(R, False, True)
+        dt = time.perf_counter() - t0
+    for lvl, (rgb, dist, acc, w, t) in enumerate(ret):
+        out[f"l{lvl}_rgb"] = rgb.numpy()
+        out[f"l{lvl}_distance"] = dist.numpy()
+        out[f"l{lvl}_acc"] = acc.numpy()
+        out[f"l{lvl}_wsum_t"] = (w * 0.5 * (t[:, :-1] + t[:, 1:])).sum(-1).numpy()
+        out[f"l{lvl}_wmax"] = w.max(-1).values.numpy()                       # how peaked the ray's weights are (surface vs fog)
+    acc = out["l1_acc"]
+    frac = dict(empty=float((acc < 0.05).mean()), opaque=float((acc > 0.95).mean()), between=float(((acc >= 0.05) & (acc <= 0.95)).mean()))
+    assert frac["empty"] >= 0.20 and frac["opaque"] >= 0.20 and frac["between"] >= 0.05, frac
+    out.update({"frac_" + k: v for k, v in frac.items()})
+    psnr = float(-10.0 * np.log10(np.mean((out["l1_rgb"] - out["gt"]) ** 2)))
+    print(f"  [{name}] reference forward {dt:.1f} s; rays: {frac}; PSNR vs the scene's pixels {psnr:.2f} dB; "
+          f"distance range [{out['l1_distance'].min():.3f}, {out['l1_distance'].max():.3f}]")
+    if train_step:
+        model.train()
+        t0 = time.perf_counter()
+        ret = model(R, False, True)
+        mask = R.lossmult
+        losses = [(mask * (rgb - rgbs[..., :3]) ** 2).sum() / mask.sum() for rgb, _, _, _, _ in ret]
+        dls = [refmip.distloss(w, t) for _, _, _, w, t in ret]
+        loss = 0.1 * (losses[0] + 0.01 * dls[0]) + losses[1] + 0.01 * dls[-1]
+        loss.backward()
+        out.update(loss=np.float32(loss.item()), mse=np.array([l.item() for l in losses], np.float32),
+                   distloss=np.array([d.item() for d in dls], np.float32))
+        for k, p in model.named_parameters():
+            g = p.grad.detach().numpy().ravel()
+            out["g_l2_" + k.replace("mlp.", "")] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["g_full"] = np.concatenate([p.grad.detach().numpy().ravel() for _, p in model.named_parameters()]).astype(np.float32)
+        print(f"  [{name}] training step: loss {loss.item():.6f} mse {out['mse']} distloss {out['distloss']} ({time.perf_counter() - t0:.1f} s)")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz")
+
+
+
 def quality_run(tag, threads, draw_seed):
     """Quality stand-in at realistic scale: the UNMODIFIED reference trained on the procedural multi-scale
     Blender-format scene of tests/dataset_fixture.py (Multicam dataset class -> rays; MipNerf; loss of nerf_system.py:99-111 with
@@ -873,6 +996,13 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--only-noise" in sys.argv:          # round 2: density_noise > 0
         noise_case("fwd_noise_48x64_trained", 48, 64, param_seed=9, gain=4.0, ray_seed=9, torch_seed=77, density_noise=1.0)
+        sys.exit(0)
+    if "--only-trained-field" in sys.argv:   # round 4: the reference trained on the procedural scene, parameters stored (~30 min)
+        trained_field_run("trained_field")
+        sys.exit(0)
+    if "--only-fullsize-trained" in sys.argv:   # round 4: headline-size forward / training-step goldens on that field
+        fullsize_trained_case("fulltrained_c2_4096x128", "trained_field", 4096, 128, ray_seed=200, train_step=True)
+        fullsize_trained_case("fulltrained_c4_8192x256", "trained_field", 8192, 256, ray_seed=201, train_step=False)
         sys.exit(0)
     if "--only-quality-run" in sys.argv:     # round 3: one reference training run on the procedural multi-scale scene (hours of CPU)
         i = sys.argv.index("--only-quality-run")
