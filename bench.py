@@ -432,9 +432,12 @@ def run_ceiling(args, e):
     out = {"unit": "TFLOP/s", "operands": "weights U(-0.1,0.1), activations relu(N(0,1)), bf16", "waves_per_simd": 2,
            "seconds_per_variant": args.ceiling_seconds, "peak": PEAK_TFLOPS["bf16"], "variants": []}
     st = torch.cuda.current_stream().cuda_stream
+    D = L.diag_lib()          # measurement tooling lives in its own library (include/mipnerf_diag.h), not in the drop-in .so
+    if D is None:
+        return {"absent": "libmipnerf_diag.so was not built (python -m mipnerf_pl_amd.build)"}
     for lds in (0, 1, 2, 3):
         r = (C.c_double * 3)()
-        L.check(L.lib().mipnerf_mfma_ceiling(lds, 2, 1, float(args.ceiling_seconds), r, st), "mfma_ceiling")
+        L.diag_check(D.mipnerf_mfma_ceiling(lds, 2, 1, float(args.ceiling_seconds), r, st), "mfma_ceiling")
         out["variants"].append({"lds_weight_reads_per_mfma": min(lds, 1), "weight_dma_l2_to_lds": lds >= 2,
                                 "saved_activation_stores": "4608 B/sample non-temporal (k_mlp_bf16_trainfwd's stream)" if lds == 3 else None,
                                 "tflops": round(r[0], 1),
@@ -449,7 +452,7 @@ def run_ceiling(args, e):
     out["store_TBps_in_that_variant"] = round(256 * 8 * 256 * 7 * 1024 / (out["variants"][3]["ms_per_launch"] * 1e-3) / 1e12, 3)
     # the fp32 matrix instruction of the parity mode / configs[3] (v_mfma_f32_32x32x2_f32), register-fed
     r = (C.c_double * 3)()
-    L.check(L.lib().mipnerf_mfma_ceiling(10, 2, 1, float(args.ceiling_seconds), r, st), "mfma_ceiling fp32")
+    L.diag_check(D.mipnerf_mfma_ceiling(10, 2, 1, float(args.ceiling_seconds), r, st), "mfma_ceiling fp32")
     out["fp32_register_fed"] = {"tflops": round(r[0], 1), "frac_of_peak": round(r[0] / PEAK_TFLOPS["fp32"], 4), "effective_clock_ghz": round(r[2], 3)}
     return out
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MIPNERF_ABI_VERSION 4
+#define MIPNERF_ABI_VERSION 5
 
 enum {
     MIPNERF_OK = 0,
@@ -378,26 +378,6 @@ int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
 /* Sum of the elapsed times (ms) and the number of MLP launches recorded since the last call
  * (option 2); synchronises on the recorded events. */
 int mipnerf_mlp_launch_stats(mipnerf_ctx* ctx, double* total_ms, int64_t* launches);
-/* What a back-to-back v_mfma_f32_32x32x16_bf16 stream sustains on THIS chip (the ceiling k_mlp_bf16's roofline fraction is
- * read against): 256 workgroups of waves_per_simd x 4 waves, register-resident operands (lds_reads_per_mfma = 0) or one
- * ds_read_b128 weight fragment per MFMA as in k_mlp_bf16 (1), or (2) the same plus k_mlp_bf16's weight DMA: every wave moves 8 one-KiB
- * chunks of an L2-resident 1.19-MiB stream into the LDS ring per 64 of its MFMAs with global_load_lds, or (3) that plus the training forward's
- * saved-activation stream: one 1-KiB non-temporal store per wave per 9.4 MFMAs to fresh addresses (3.7 GB per launch; 2 waves per SIMD);
- * (10) = the fp32 matrix instruction of the parity mode (v_mfma_f32_32x32x2_f32), register-fed, TFLOP/s against the 157.3 of the datasheet;
- * operands all zero or MLP-like random (weights U(-0.1,0.1),
- * activations relu(N(0,1))).  Runs for `seconds` (first half un-measured heat-up).  out3 = {TFLOP/s, ms per launch,
- * shader clock in GHz implied by the MFMA issue rate}.  Diagnostic: allocates and synchronises. */
-int mipnerf_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_operands, double seconds, double* out3,
-                         void* stream);
-/* CU -> CU hand-off probe: 128 producer workgroups stream `tiles` tiles of tile_bytes each to 128 consumer workgroups through
- * `ring`-slot rings in global memory with counter flags (producer and consumer on the same XCD or on neighbouring XCDs;
- * store_flavour 0 = plain stores + agent release, 1 = write-through sc1 stores, 2 = plain stores, no fence, consumer loads bypass its L1
- * (same XCD only); 3 / 4 = the per-WAVE forms of 1 / 2: wave w of the producer streams sub-tiles of tile_bytes / 8 to wave w of the consumer
- * through its own ring and flags, no workgroup barrier, a whole sub-tile in flight per wave; 64 / 128 KiB tiles), mfma_per_wave register-only MFMAs per tile
- * on both sides, every word verified.  out6 = {aggregate GB/s, ms, producer stall fraction, consumer stall fraction,
- * mismatching 16-B words, 1 if a bounded poll timed out}.  Diagnostic: allocates and synchronises. */
-int mipnerf_handoff_probe(int same_xcd, int store_flavour, int tiles, int ring, int tile_bytes, int mfma_per_wave, int reps,
-                          double* out6, void* stream);
 /* Host-only exports of the static plan tables (no GPU needed), used by the CPU tests to
  * prove the C++ plan expansion equals mipnerf_pl_amd/mlp_plan.py.  which: 0 = bf16 stream
  * pack table, 1 = bias table, 2 = fp32 stream pack table (flat parameter indices, -1 = 0),

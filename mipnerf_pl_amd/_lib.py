@@ -98,14 +98,44 @@ SIGNATURES = {
     "mipnerf_selftest": (C.c_int, [_P]),
     "mipnerf_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
     "mipnerf_mlp_launch_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
-    "mipnerf_mfma_ceiling": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), _P]),
-    "mipnerf_handoff_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     "mipnerf_debug_table": (_I64, [C.c_int, _P, _I64]),
     "mipnerf_debug_table_variant": (_I64, [C.c_int, C.c_int, _P, _I64]),
     "mipnerf_debug_f32net": (_I64, [_P, _I64]),
 }
 
+# include/mipnerf_diag.h: measurement tooling in its own library (bench.py, scripts/handoff_probe.py); never needed by the product path
+DIAG_LIB_PATH = os.environ.get("MIPNERF_DIAG_LIB", os.path.join(HERE, "csrc", "libmipnerf_diag.so"))
+DIAG_SIGNATURES = {
+    "mipnerf_diag_last_error": (C.c_char_p, []),
+    "mipnerf_mfma_ceiling": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double), _P]),
+    "mipnerf_handoff_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
+}
+
 _lib = None
+_diag = None
+
+
+def diag_lib():
+    """libmipnerf_diag.so or None when it was not built (callers report the diagnostics as absent)."""
+    global _diag
+    if _diag is None and os.path.exists(DIAG_LIB_PATH):
+        try:
+            import torch  # noqa: F401  (same HIP runtime instance, see lib())
+        except ImportError:
+            pass
+        h = C.CDLL(DIAG_LIB_PATH)
+        for name, (res, args) in DIAG_SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _diag = h
+    return _diag
+
+
+def diag_check(rc: int, what: str = "") -> None:
+    if rc != OK:
+        msg = (diag_lib().mipnerf_diag_last_error() or b"").decode(errors="replace")
+        raise (ValueError if rc == E_INVALID else RuntimeError)(f"{what}: {msg} (code {rc})")
 
 
 def lib():

@@ -1316,28 +1316,6 @@ int mipnerf_selftest(void* stream) {
     return bad == 0 ? MIPNERF_OK : (0x100 | bad);
 }
 
-int mipnerf_mfma_ceiling(int lds_reads_per_mfma, int waves_per_simd, int random_operands, double seconds, double* out3, void* stream) {
-    if (!out3 || waves_per_simd < 1 || waves_per_simd > 2 || lds_reads_per_mfma < 0 || (lds_reads_per_mfma > 3 && lds_reads_per_mfma != 10) || !(seconds > 0) || seconds > 30 ||
-        (lds_reads_per_mfma == 3 && waves_per_simd != 2))
-        return fail(MIPNERF_E_INVALID, "mfma_ceiling: waves_per_simd in {1,2}, lds_reads_per_mfma (feeding mode) in {0,1,2,3,10; 3 needs 2 waves per SIMD}, 0 < seconds <= 30");
-    char msg[256];
-    const int rc = mip::run_mfma_ceiling(lds_reads_per_mfma, waves_per_simd, random_operands, seconds, out3, out3 + 1, out3 + 2, S(stream), msg, sizeof msg);
-    g_err = msg;
-    return rc == 0 ? MIPNERF_OK : MIPNERF_E_HIP;
-}
-
-int mipnerf_handoff_probe(int same_xcd, int store_flavour, int tiles, int ring, int tile_bytes, int mfma_per_wave, int reps, double* out6,
-                          void* stream) {
-    if (!out6 || tiles < 1 || tiles > (1 << 16) || ring < 1 || ring > 64 || tile_bytes < 65536 || tile_bytes > (1 << 22) || reps < 1 || reps > 16 ||
-        mfma_per_wave < 0 || mfma_per_wave > 4096 || (long long)ring * tile_bytes * 128 > (4ll << 30) || store_flavour < 0 || store_flavour > 4 ||
-        ((store_flavour == 2 || store_flavour == 4) && !same_xcd) || (store_flavour >= 3 && tile_bytes != 65536 && tile_bytes != 131072))
-        return fail(MIPNERF_E_INVALID, "handoff_probe: argument out of range (flavours 0-4; 2 / 4 are same-XCD protocols; 3 / 4 take 64 / 128 KiB tiles)");
-    char msg[256];
-    const int rc = mip::run_handoff_probe(same_xcd, store_flavour, tiles, ring, tile_bytes, mfma_per_wave, reps, out6, S(stream), msg, sizeof msg);
-    g_err = msg;
-    return rc == 0 ? MIPNERF_OK : (rc == -2 ? MIPNERF_E_INVALID : MIPNERF_E_HIP);
-}
-
 // Host-only debug export of the plan tables (flat parameter indices), used by the CPU tests to prove the
 // C++ expansion equals mlp_plan.py.  which: 0 bf16 pack, 1 bias, 2 fp32 pack.  Returns element count.
 int64_t mipnerf_debug_table_variant(int variant, int which, int32_t* out_host, int64_t cap) {

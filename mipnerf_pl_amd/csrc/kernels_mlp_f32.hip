@@ -285,7 +285,10 @@ hipError_t launch_mlp_f32(const F32Net& net_in, const float* stream_w, const flo
     const int lds = ts * net.ldx * (int)sizeof(float);
     const bool stream = net.pad != 0;
     if (stream && ts != 64) return hipErrorInvalidValue;       // the streamed-encoding kernel exists for 64-sample tiles
-    static int attr_lds[3] = {0, 0, 0};
+    static int attr_lds_dev[64][3] = {};      // the attribute is per device: a process may drive several GPUs
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    int* attr_lds = attr_lds_dev[dev];
     const int which = stream ? 2 : (ts == 64 ? 1 : 0);
     if (attr_lds[which] < lds) {
         hipError_t er = which == 2 ? hipFuncSetAttribute((const void*)k_mlp_f32<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)

@@ -391,8 +391,8 @@ class RayLoader:
             order = torch.arange(n, device=ds.device)
         self.epoch += 1
         pad = self._local_count() * self.world_size - n
-        if pad:
-            order = torch.cat([order, order[:pad]])
+        if pad:      # DistributedSampler's rule: wrap around, repeating the list when the pad exceeds it (n < world_size - 1)
+            order = order.repeat(pad // max(n, 1) + 2)[:n + pad]
         order = order[self.rank::self.world_size]
         for b in range(len(self)):
             yield ds.rays_at(order[b * self.batch_size:(b + 1) * self.batch_size])

@@ -50,5 +50,6 @@ class DeviceMipLRDecay(MipLRDecay):
     def step(self, epoch=None):
         # the optimiser step may have been a graph replay (GraphedTrainStep) that never went through optimizer.step():
         # torch's "lr_scheduler.step() before optimizer.step()" warning does not apply
-        self.optimizer._opt_called = True
+        if getattr(self.optimizer, "_graph_driven", False):       # set by GraphedTrainStep; otherwise torch's warning stays armed
+            self.optimizer._opt_called = True
         return super().step() if epoch is None else super().step(epoch)

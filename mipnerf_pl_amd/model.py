@@ -371,6 +371,15 @@ class MLP(torch.nn.Module):
             found = containing_variant(a, bool(e.get("use_viewdirs", 1)), bool(e.get("unbounded", 0)), self.precision == L.PREC_BF16)
             if found is not None and not found[1]:
                 padding = WidthPadding(a, found[0], bool(e.get("use_viewdirs", 1)))
+                if self.is_flat():               # (flatten_parameters' own guard only runs when the module already sat on the GPU)
+                    raise NotImplementedError("flat parameter mode needs an MLP of a generated shape; this one runs zero-padded on "
+                                              f"{found[0]['net_width']} / {found[0]['net_width_condition']}: the native backward would "
+                                              "write the padded gradient past the end of the true-size flat buffer")
+                import warnings
+                warnings.warn(f"MLP {a['net_width']} / {a['net_width_condition']} is not a generated shape: it runs zero-padded on the "
+                              f"{found[0]['net_width']} / {found[0]['net_width_condition']} kernels at "
+                              f"{padding.padded_numel / padding.true_numel:.2f}x the multiply-adds, plus one cat + scatter of all parameters "
+                              "per optimiser step (add the shape to csrc/gen_mlp_bf16.py: VARIANTS and rebuild to avoid both)", stacklevel=3)
                 a = found[0]                     # the context is created for the containing generated shape
             cfg = L.Config(
                 num_samples=e.get("num_samples", 128), num_levels=e.get("num_levels", 2),

@@ -47,6 +47,7 @@ class GraphedTrainStep:
         self.time_allreduce = False        # True: a HIP event pair around every all-reduce (allreduce_stats)
         self._ar_events = []
         optimizer.grad_scale = 1.0 / self.world
+        optimizer._graph_driven = True      # its steps are graph replays: lr_schedule.DeviceMipLRDecay.step reads this
         self.rays = Rays(*[torch.zeros(self.B, k, device=device) for k in (3, 3, 3, 1, 1, 1, 1)])
         self.rays.directions[:, 2] = 1.0
         self.rays.viewdirs[:, 2] = 1.0

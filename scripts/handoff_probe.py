@@ -42,11 +42,11 @@ def main():
     with open(args.out, "w") as f:
         for same, flavour, ring, tile_bytes, mfma in grid:
             out = (C.c_double * 6)()
-            rc = L.lib().mipnerf_handoff_probe(same, flavour, args.tiles, ring, tile_bytes, mfma, 3, out, st)
+            rc = L.diag_lib().mipnerf_handoff_probe(same, flavour, args.tiles, ring, tile_bytes, mfma, 3, out, st)
             row = {"same_xcd": same, "stores": ("plain + agent release", "sc1 write-through", "plain, no fence; consumer loads bypass L1 (sc1)",
                                                                    "per-wave streams: sc1 write-through, per-wave acquire", "per-wave streams: plain, no fence, sc1 loads")[flavour], "ring": ring,
                    "tile_bytes": tile_bytes, "tiles_per_pair": args.tiles, "mfma_per_wave_per_tile": mfma, "rc": rc,
-                   "msg": L.last_error()}
+                   "msg": (L.diag_lib().mipnerf_diag_last_error() or b"").decode()}
             if rc == 0:
                 # the MFMA filler alone bounds the rate: tiles * mfma * 8 waves * 32 cycles ... reported as the time the same loop
                 # would take with no hand-off at 2.0 GHz is left to the reader; stall fractions say who waited

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_compiled_arch(lib):
-    assert lib.mipnerf_abi_version() == 4
+    assert lib.mipnerf_abi_version() == 5
     cfg = L.Config()
     assert lib.mipnerf_compiled_arch(C.byref(cfg)) == 0
     assert (cfg.net_depth, cfg.net_width, cfg.net_depth_condition, cfg.net_width_condition, cfg.skip_index) == (8, 256, 1, 128, 4)
@@ -166,9 +166,29 @@ def test_variant_dataflow_emulation_matches_oracle():
         np.testing.assert_allclose(dens, dd[:, 0, 0], atol=2e-5)
 
 
+def test_diagnostics_live_in_their_own_library(lib):
+    """VERDICT r03 hygiene: the drop-in library is the hot path only -- the MFMA ceilings and the hand-off probe are exported by
+    libmipnerf_diag.so (include/mipnerf_diag.h), header == exports == ctypes table, and NOT by libmipnerf_hip.so."""
+    src = open(os.path.join(REPO, "include", "mipnerf_diag.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mipnerf_[a-z0-9_]+)\s*\(", src)))
+    assert names == sorted(L.DIAG_SIGNATURES) and len(names) == 3
+    d = L.diag_lib()
+    assert d is not None
+    for n in names:
+        assert hasattr(d, n)
+        if n != "mipnerf_diag_last_error":
+            assert not hasattr(lib, n), f"{n} still exported by the drop-in library"
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True).stdout
+    assert "ceiling" not in syms and "handoff" not in syms
+
+
 def test_diagnostic_entry_points_validate_their_arguments(lib):
-    """mipnerf_mfma_ceiling / mipnerf_handoff_probe (round 3) reject bad arguments before touching the device."""
+    """mipnerf_mfma_ceiling / mipnerf_handoff_probe reject bad arguments before touching the device; a later SUCCESSFUL validation
+    does not clear the message."""
     out3, out6 = (C.c_double * 3)(), (C.c_double * 6)()
+    lib = L.diag_lib()
     assert lib.mipnerf_mfma_ceiling(0, 3, 1, 1.0, out3, None) == L.E_INVALID          # waves per SIMD must be 1 or 2
     assert lib.mipnerf_mfma_ceiling(4, 2, 1, 1.0, out3, None) == L.E_INVALID          # feeding mode 0 ... 3
     assert lib.mipnerf_mfma_ceiling(0, 2, 1, 100.0, out3, None) == L.E_INVALID        # bounded run time
@@ -176,7 +196,7 @@ def test_diagnostic_entry_points_validate_their_arguments(lib):
     assert lib.mipnerf_handoff_probe(1, 0, 0, 4, 131072, 0, 1, out6, None) == L.E_INVALID       # no tiles
     assert lib.mipnerf_handoff_probe(1, 0, 16, 4, 1000, 0, 1, out6, None) == L.E_INVALID        # tile too small
     assert lib.mipnerf_handoff_probe(1, 0, 16, 64, 1 << 22, 0, 1, out6, None) == L.E_INVALID    # ring x tile x 128 pairs > 4 GiB
-    assert b"handoff_probe" in lib.mipnerf_last_error()
+    assert b"handoff_probe" in lib.mipnerf_diag_last_error()
     assert lib.mipnerf_handoff_probe(1, 5, 16, 4, 131072, 0, 1, out6, None) == L.E_INVALID      # no such protocol
     assert lib.mipnerf_handoff_probe(0, 4, 16, 4, 131072, 0, 1, out6, None) == L.E_INVALID      # fence-free protocols are same-XCD only
     assert lib.mipnerf_handoff_probe(1, 3, 16, 4, 262144, 0, 1, out6, None) == L.E_INVALID      # per-wave protocols: 64 / 128 KiB tiles

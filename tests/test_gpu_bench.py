@@ -142,7 +142,7 @@ def test_handoff_probe_protocols_deliver_every_word(same_xcd, flavour):
     st = torch.cuda.current_stream().cuda_stream
     for mfma in (0, 64):
         out = (C.c_double * 6)()
-        rc = L.lib().mipnerf_handoff_probe(same_xcd, flavour, 48, 2, 131072, mfma, 1, out, st)
-        assert rc == 0, L.last_error()
+        rc = L.diag_lib().mipnerf_handoff_probe(same_xcd, flavour, 48, 2, 131072, mfma, 1, out, st)
+        assert rc == 0, L.diag_lib().mipnerf_diag_last_error()
         assert out[4] == 0 and out[5] == 0, (list(out), mfma)      # wrong words, timed-out polls
         assert out[0] > 50.0                                      # GB/s aggregate: it moved

@@ -101,7 +101,8 @@ def test_rayloader_equal_batches_per_rank_when_pixels_do_not_divide():
         def rays_at(self, ids):
             return ids
 
-    for n, world, bs in ((10, 3, 2), (101, 4, 5), (64, 8, 8), (7, 8, 1), (1000, 7, 13)):
+    # (1, 4, 1), (2, 8, 1): n < world - 1 -- the pad exceeds the list, DistributedSampler repeats it
+    for n, world, bs in ((10, 3, 2), (101, 4, 5), (64, 8, 8), (7, 8, 1), (1000, 7, 13), (1, 4, 1), (2, 8, 1)):
         lens, seen = set(), torch.zeros(n, dtype=torch.int64)
         counts = []
         for r in range(world):
@@ -114,7 +115,7 @@ def test_rayloader_equal_batches_per_rank_when_pixels_do_not_divide():
                 seen[b] += 1
         assert len(lens) == 1, (n, world, lens)                      # same number of batches on every rank
         assert len(set(counts)) == 1 and counts[0] == -(-n // world)   # same number of rays on every rank
-        assert int(seen.min()) >= 1 and int(seen.sum()) == world * (-(-n // world)) and int(seen.max()) <= 2 + (world > n)
+        assert int(seen.min()) >= 1 and int(seen.sum()) == world * (-(-n // world)) and int(seen.max()) <= max(2, -(-world // n))
 
 
 def test_device_lr_scheduler_is_a_torch_lrscheduler():
@@ -124,6 +125,10 @@ def test_device_lr_scheduler_is_a_torch_lrscheduler():
     opt = torch.optim.Adam([p], lr=1.0)
     args = dict(lr_init=2e-3, lr_final=1e-4, max_steps=300, lr_delay_steps=30, lr_delay_mult=0.01)
     import warnings
+    # without GraphedTrainStep driving the optimiser torch's scheduler-before-optimiser warning stays armed
+    with pytest.warns(UserWarning, match="before `optimizer.step"):
+        DeviceMipLRDecay(torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=1.0), **args).step()
+    opt._graph_driven = True             # what GraphedTrainStep.__init__ sets on its FlatAdam
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         s = DeviceMipLRDecay(opt, **args)
