@@ -373,7 +373,9 @@ int mipnerf_selftest(void* stream);
  * MLP kernel of mipnerf_forward computes the integrated positional encoding itself (no [M,96] buffer, no k_cast_ipe
  * launch), 0 = separate mipnerf_cast_ipe + encoding buffer (same bits); option 4: 1 [default] = mipnerf_forward runs pos_enc + the
  * coarse fence posts as ONE launch and the coarse level's compositing + the fine level's resampling as ONE launch (N <= 128 or 192 < N <= 256; the
- * weights go from registers to the sampler's LDS row), 0 = one launch per stage (same bits). */
+ * weights go from registers to the sampler's LDS row), 0 = one launch per stage (same bits); option 5: 1 [default] = fp32 inference (mipnerf_mlp_forward,
+ * mipnerf_forward) runs the register-resident kernel k_mlp_f32r where one was generated for the architecture (widths <= 256), 0 = the LDS-resident
+ * k_mlp_f32 (same function, another summation order: results agree to fp32 rounding). */
 int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
 /* Sum of the elapsed times (ms) and the number of MLP launches recorded since the last call
  * (option 2); synchronises on the recorded events. */

@@ -13,6 +13,7 @@
 #include "kernels.hpp"
 #include "mlp_variants_gen.hpp"
 #include "mlp_train_variants_gen.hpp"
+#include "mlp_f32r_variants_gen.hpp"
 #include "mlp_plan_gen.hpp"
 
 // binary tables of the training kernels (mlp_train_plan.TrainPlan.blob()), linked in through train_tables.c (.incbin)
@@ -210,6 +211,22 @@ bool train_tables(TrainTables& T, int variant = 0) {
     return h[9] == T.njobs * 20 && h[10] == T.njobs * T.job_floats && T.job_floats == mip::kWgradJobFloats;
 }
 
+// ---- register-resident fp32 kernel: blob produced by mlp_f32r_plan.F32RPlan.blob(), linked in by train_tables.c ------
+struct F32RTables {
+    int n_chunks = 0, n_aux = 0, n_groups = 0;
+    const int32_t* pack = nullptr;   // [n_chunks * 256] flat parameter index or -1
+    const int32_t* aux = nullptr;    // [n_aux]
+};
+bool f32r_tables(F32RTables& T, int variant, int nparams) {
+    if (variant < 0 || variant >= mip::plan::kNumVariants || !mip::kF32RTableBlobs[variant]) return false;
+    const int32_t* h = reinterpret_cast<const int32_t*>(mip::kF32RTableBlobs[variant]);
+    if (h[0] != 0x46335231 || h[4] != h[1] * 256 || h[5] != nparams) return false;
+    T.n_chunks = h[1]; T.n_aux = h[3]; T.n_groups = h[6];
+    T.pack = h + 16;
+    T.aux = T.pack + h[4];
+    return true;
+}
+
 }  // namespace
 
 struct mipnerf_ctx {
@@ -222,6 +239,13 @@ struct mipnerf_ctx {
     void* d_stream_bf16 = nullptr;   // kNumChunks * 1 KiB
     float* d_stream_f32 = nullptr;   // kNumChunks * 2 KiB
     float* d_bias = nullptr;         // kNumTiles * 32 floats
+    // register-resident fp32 kernel (variants up to 256 wide): its own weight stream (1-KiB chunks) and aux table
+    F32RTables f32r;
+    int32_t* d_pack_f32r = nullptr;
+    int32_t* d_aux_idx_f32r = nullptr;
+    float* d_stream_f32r = nullptr;
+    float* d_aux_f32r = nullptr;
+    int f32_resident = 1;            // option 5: 1 = k_mlp_f32r where generated (inference), 0 = the LDS-resident k_mlp_f32
     // training (bf16): W^T stream of the dgrad kernel, wgrad job tables
     TrainTables tt;
     int32_t* d_pack_dgrad = nullptr;
@@ -396,6 +420,27 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         mipnerf_destroy(c);
         return fail(MIPNERF_E_HIP, "mipnerf_create: %s", hipGetErrorString(er));
     }
+    if (mip::kLaunchF32R[P->variant]) {
+        if (!f32r_tables(c->f32r, P->variant, off_total(c->tab))) {
+            mipnerf_destroy(c);
+            return fail(MIPNERF_E_INVALID, "mipnerf_create: embedded tables of the register-resident fp32 kernel are inconsistent with the compiled plan");
+        }
+        const size_t np = (size_t)c->f32r.n_chunks * 256, na = (size_t)c->f32r.n_aux;
+        const std::vector<int32_t> e_p = encode(std::vector<int32_t>(c->f32r.pack, c->f32r.pack + np), c->tab.tensor_off);
+        const std::vector<int32_t> e_a = encode(std::vector<int32_t>(c->f32r.aux, c->f32r.aux + na), c->tab.tensor_off);
+        chk(hipMalloc(&c->d_pack_f32r, np * 4));
+        chk(hipMalloc(&c->d_aux_idx_f32r, na * 4));
+        chk(hipMalloc(&c->d_stream_f32r, np * 4));
+        chk(hipMalloc(&c->d_aux_f32r, na * 4));
+        if (er == hipSuccess) {
+            chk(hipMemcpy(c->d_pack_f32r, e_p.data(), np * 4, hipMemcpyHostToDevice));
+            chk(hipMemcpy(c->d_aux_idx_f32r, e_a.data(), na * 4, hipMemcpyHostToDevice));
+        }
+        if (er != hipSuccess) {
+            mipnerf_destroy(c);
+            return fail(MIPNERF_E_HIP, "mipnerf_create (fp32 register-resident tables): %s", hipGetErrorString(er));
+        }
+    }
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess &&
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -447,6 +492,7 @@ int mipnerf_destroy(mipnerf_ctx* c) {
     (void)hipFree(c->d_pack_dgrad); (void)hipFree(c->d_stream_dgrad); (void)hipFree(c->d_jobs); (void)hipFree(c->d_otab);
     (void)hipFree(c->d_wgtab); (void)hipFree(c->d_jobslots); (void)hipFree(c->d_scratch); (void)hipFree(c->d_extra_wT);
     (void)hipFree(c->d_pack_extraT);
+    (void)hipFree(c->d_pack_f32r); (void)hipFree(c->d_aux_idx_f32r); (void)hipFree(c->d_stream_f32r); (void)hipFree(c->d_aux_f32r);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
     return MIPNERF_OK;
@@ -460,6 +506,7 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
         case 2: c->time_mlp = value < 0 ? 0 : (value > 2 ? 2 : value); c->ev_used = 0; return MIPNERF_OK;
         case 3: c->fused_ipe = value ? 1 : 0; return MIPNERF_OK;
         case 4: c->fuse_small = value ? 1 : 0; return MIPNERF_OK;
+        case 5: c->f32_resident = value ? 1 : 0; return MIPNERF_OK;
         default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
     }
 }
@@ -491,6 +538,10 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
     if (has_bf16_train(&P)) {
         add(c->d_pack_dgrad, (int64_t)c->tt.n_bchunks * 512, c->d_stream_dgrad, true);
         add(c->d_pack_extraT, (int64_t)P.net_width * P.net_width, c->d_extra_wT, false);
+    }
+    if (c->d_stream_f32r) {
+        add(c->d_pack_f32r, (int64_t)c->f32r.n_chunks * 256, c->d_stream_f32r, false);
+        add(c->d_aux_idx_f32r, (int64_t)c->f32r.n_aux, c->d_aux_f32r, false);
     }
     HIP_TRY(mip::launch_pack_multi(sg, pp, S(stream)));
     c->pp = pp;
@@ -553,6 +604,10 @@ static int mlp_forward_noise(mipnerf_ctx* c, int64_t M, int32_t N, const void* e
     if (precision == MIPNERF_PREC_BF16) {
         if (!has_bf16(c->P)) return fail(MIPNERF_E_UNSUPPORTED, "this architecture variant (xyz_dim %d) has fp32 kernels only", c->P->xyz_dim);
         HIP_TRY(launch_bf16_variant(c, enc, viewenc, rgb_sigma, raw, M, N, c->mlp_dma != 0, nullptr, dnoise, S(stream)));
+    } else if (precision == MIPNERF_PREC_FP32 && c->f32_resident && c->d_stream_f32r) {
+        // register-resident kernel (generated per variant, gen_mlp_f32r.py): activations in registers, weights through an LDS ring
+        HIP_TRY(mip::kLaunchF32R[c->P->variant](c->d_stream_f32r, c->d_aux_f32r, (const float*)enc, (const float*)viewenc, rgb_sigma, raw, M, N,
+                                                c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, dnoise, c->cfg.density_noise, S(stream)));
     } else if (precision == MIPNERF_PREC_FP32) {
         HIP_TRY(mip::launch_mlp_f32(f32net_with_heads(c), c->d_stream_f32, c->d_bias, (const float*)enc, (const float*)viewenc,
                                     rgb_sigma, raw, M, N, c->cfg.density_bias, c->cfg.rgb_padding, nullptr, nullptr, dnoise,

@@ -1,0 +1,127 @@
+"""CPU: the plan of the register-resident fp32 MLP kernel (mipnerf_pl_amd/mlp_f32r_plan.py, csrc/gen_mlp_f32r.py).
+
+The kernel text is generated from this plan and the weight stream / aux table are packed through its index tables, so what is checked
+here is the whole dataflow short of the hardware: the numpy emulation of one wavefront (chunk order, k maps of register and natural
+blocks, accumulator-init images, per-lane-half thin-head weights) must reproduce the oracle's MLP (models/mip_nerf.py:75-111) for every
+architecture variant the kernel is generated for; the static schedule of ring groups and natural blocks must be hazard-free."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import synthetic_inputs as syn
+from mipnerf_pl_amd.mlp_f32r_plan import GROUP_CHUNKS, MAGIC, NSLOT, F32RPlan, emulate_wave, supported
+from mipnerf_pl_amd.mlp_plan import DLAYOUT, NATURAL
+from oracle import mipnerf_oracle as orc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "mipnerf_pl_amd", "csrc"))
+from gen_mlp_bf16 import VARIANTS  # noqa: E402
+
+SUPPORTED = [vi for vi, a in enumerate(VARIANTS) if supported(a)]
+
+
+def _params(arch, seed=3):
+    shapes = dict(net_depth=arch.net_depth, net_width=arch.net_width, net_depth_condition=arch.net_depth_condition,
+                  net_width_condition=arch.net_width_condition, skip_index=arch.skip_index, xyz_dim=arch.xyz_dim)
+    params = syn.make_params(seed=seed, density_gain=5.0, **shapes)
+    flat = np.concatenate([params[n].ravel() for n, _ in arch.param_shapes()])
+    return params, flat
+
+
+def test_which_variants_get_the_kernel():
+    assert SUPPORTED == [vi for vi, a in enumerate(VARIANTS) if a.net_width <= 256 and a.net_width_condition <= 256]
+    assert 0 in SUPPORTED and len(SUPPORTED) >= 5
+    with pytest.raises(NotImplementedError):
+        F32RPlan.build([a for a in VARIANTS if not supported(a)][0])
+
+
+@pytest.mark.parametrize("vi", SUPPORTED)
+def test_emulated_wave_equals_oracle(vi):
+    arch = VARIANTS[vi]
+    p = F32RPlan.build(arch)
+    params, flat = _params(arch)
+    rng = np.random.default_rng(vi)
+    enc = rng.uniform(-1, 1, (32, arch.xyz_dim)).astype(np.float32)
+    v27 = rng.uniform(-1, 1, (32, 27)).astype(np.float32)
+    view = np.zeros((32, 32), np.float32)
+    view[:, :27] = v27
+    rgb, dens = emulate_wave(p, flat, enc, view)
+    rr, dd = orc.mlp_forward(params, enc[:, None, :], v27 if arch.use_viewdirs else None, skip_index=arch.skip_index,
+                             net_depth=arch.net_depth, net_depth_condition=arch.net_depth_condition)
+    np.testing.assert_allclose(rgb, rr[:, 0], atol=3e-6)
+    np.testing.assert_allclose(dens, dd[:, 0, 0], atol=2e-5)
+
+
+@pytest.mark.parametrize("vi", SUPPORTED)
+def test_tables_cover_every_parameter_exactly_once(vi):
+    arch = VARIANTS[vi]
+    p = F32RPlan.build(arch)
+    _, total = p.param_offsets()
+    seen = np.zeros(total, np.int32)
+    for tab in (p.pack_table().ravel(), p.aux_table()[0].ravel()):
+        np.add.at(seen, tab[tab >= 0], 1)
+    # the two aux halves hold different accumulator rows / different features of the thin heads' rows; only the thin heads' biases
+    # are duplicated in both halves
+    aux1 = p.aux_table()[1].ravel()
+    lay, H = p.aux_layout()
+    dup = np.zeros(H, bool)
+    for k, o in lay.items():
+        if k[0] == "thin_b":
+            dup[o:o + 4] = True
+    np.add.at(seen, aux1[~dup & (aux1 >= 0)], 1)
+    used = np.ones(total, bool)
+    if not arch.use_viewdirs:          # extra_layer / view_layers are unused parameters without view directions (mip_nerf.py:99-110)
+        offs, _ = p.param_offsets()
+        names = [n for n, _ in arch.param_shapes()]
+        for i, n in enumerate(names):
+            if n.startswith("extra_layer") or n.startswith("view_layers"):
+                used[offs[i]:(offs[i + 1] if i + 1 < len(offs) else total)] = False
+    assert np.all(seen[used] == 1), (np.count_nonzero(seen[used] != 1), total)
+    assert np.all(seen[~used] == 0)
+
+
+@pytest.mark.parametrize("vi", SUPPORTED)
+def test_ring_groups_and_natural_block_schedule(vi):
+    p = F32RPlan.build(VARIANTS[vi])
+    groups = p.groups()
+    assert len(groups) % 2 == 0                                        # two ring slots, cyclic over tiles
+    assert groups[0][0] == 0 and sum(k for _, k in groups) == p.n_real_chunks
+    assert all(c0 + k == groups[i + 1][0] for i, (c0, k) in enumerate(groups[:-1]))
+    assert all(k <= GROUP_CHUNKS and k % 4 == 0 for _, k in groups)
+    # no k-step straddles a group (its chunks are read with offsets inside one ring slot)
+    starts = {c0 for c0, _ in groups}
+    for oi, op in enumerate(p.ops):
+        for ks in range(op.nk):
+            c = op.chunk0 + ks * op.quads
+            for q in range(1, op.quads):
+                assert c + q not in starts
+    sched = p.natural_schedule()
+    uses = p.natural_uses()
+    assert len(sched) == len(uses)
+    n_nat = sum(1 for op in p.ops for b in op.blocks if b.kind == NATURAL)
+    assert len(uses) == n_nat
+    for u in sched:
+        assert 0 <= u["slot"] < NSLOT
+        assert u["gi"] == u["g_first"] - 2 and u["issue_group"] == u["gi"] % len(groups) and u["prev_tile"] == (u["gi"] < 0)
+    # every register block is read from the set the previous MFMA op wrote
+    last_out = None
+    for op in p.ops:
+        for b in op.blocks:
+            if b.kind == DLAYOUT:
+                assert b.src == last_out
+        if op.tiles:
+            last_out = op.out
+
+
+def test_blob_header():
+    p = F32RPlan.build(VARIANTS[0])
+    blob = np.frombuffer(p.blob(), np.int32)
+    assert blob[0] == MAGIC and blob[1] == p.n_real_chunks == 2384 and blob[4] == p.n_real_chunks * 256
+    assert blob[3] == 2 * p.aux_layout()[1] and blob[5] == p.param_offsets()[1] and blob[6] == p.n_groups == 76
+    assert blob.size == 16 + blob[4] + blob[3]
+    # 9,536 MFMAs per wave and tile = exactly the algorithmic 610,304 MAC per sample: the 640 MACs of the thin heads run on
+    # the VALU, the view encoding's 27 -> 32 zero padding adds 5 x 128 = 640 to the view layer
+    mfmas = sum(len(op.tiles) * op.nk for op in p.ops)
+    assert mfmas == 9536 and mfmas * 2048 // 32 == 610304

@@ -78,9 +78,76 @@ def test_full_size_every_ray(G, name, precision):
         assert errs["l1_distance"] <= 0.1, errs                                    # measured 2.2e-2
 
 
+@pytest.mark.parametrize("name", ["fulltrained_c2_4096x128", "fulltrained_c4_8192x256"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_size_every_ray_on_a_trained_field(G, name, precision):
+    """the headline sizes (4096 x 128, 8192 x 256) on a REALISTIC field -- the reference trained on the procedural
+    multi-scale scene (make_golden.py --only-trained-field: 600 steps, 37.4 dB), evaluated by the unmodified reference on rays of that
+    scene: a third empty (acc < 0.05: the white-background term 1 - acc, the sampler's padding branch mip.py:181-185), nearly half
+    opaque surfaces (peaked weights, fine samples concentrated at the hit), a fifth soft rims / grazing rays.  Same bounds as the
+    fog-field goldens of round 2, per class of ray."""
+    g = G.load_golden(name)
+    params = _field_params(G, g)
+    rays = _stored_rays(g)
+    assert float(g["frac_empty"]) >= 0.2 and float(g["frac_opaque"]) >= 0.2 and float(g["frac_between"]) >= 0.05
+    model = G.make_model(params, int(g["num_samples"]), precision)
+    with torch.no_grad():
+        ret = model(G.to_dev(rays), False, True)
+    acc_ref = g["l1_acc"]
+    classes = {"empty": acc_ref < 0.05, "opaque": acc_ref > 0.95, "between": (acc_ref >= 0.05) & (acc_ref <= 0.95)}
+    errs = {}
+    for lvl in range(2):
+        rgb, dist, acc, w, t = ret[lvl]
+        wt = (w * 0.5 * (t[:, :-1] + t[:, 1:])).sum(-1)
+        got = dict(rgb=rgb.cpu().numpy(), distance=dist.cpu().numpy(), acc=acc.cpu().numpy(), wsum_t=wt.cpu().numpy(),
+                   wmax=w.max(-1).values.cpu().numpy())
+        for nm, v in got.items():
+            d = np.abs(v.astype(np.float64) - g[f"l{lvl}_{nm}"].astype(np.float64))
+            errs[f"l{lvl}_{nm}"] = float(d.max())
+            if lvl == 1 and nm in ("rgb", "distance", "acc"):
+                for cn, m in classes.items():
+                    errs[f"l1_{nm}_{cn}"] = float(d[m].max())
+    errs["psnr_l1_rgb"] = _psnr(ret[1][0].cpu().numpy(), g["l1_rgb"])
+    errs["psnr_vs_scene_pixels"] = _psnr(ret[1][0].cpu().numpy(), g["gt"])
+    errs["ref_psnr_vs_scene_pixels"] = _psnr(g["l1_rgb"], g["gt"])
+    G.record(f"fullsize_trained {name} {precision}", **errs)
+    if precision == "fp32":
+        for k, e in errs.items():
+            if k.startswith("psnr") or k.startswith("ref_"):
+                continue
+            kind = k.split("_", 1)[1].split("_")[0]
+            tol = G.TOL_FP32["distance" if kind in ("distance", "wsum") else ("weights" if kind == "wmax" else kind)]
+            assert e <= tol, f"{name} fp32 {k}: {e} > {tol}"
+        assert abs(errs["psnr_vs_scene_pixels"] - errs["ref_psnr_vs_scene_pixels"]) < 1e-3
+    else:
+        assert errs["psnr_l1_rgb"] > 55.0, errs
+        assert errs["l0_rgb"] <= 2e-2 and errs["l1_rgb"] <= 2e-2, errs
+        assert errs["l0_acc"] <= 2e-2 and errs["l1_acc"] <= 2e-2, errs
+        assert errs["l1_rgb_empty"] <= 5e-3 and errs["l1_acc_empty"] <= 5e-3, errs        # empty space stays empty in bf16
+        assert errs["l1_distance"] <= 0.1, errs
+        assert abs(errs["psnr_vs_scene_pixels"] - errs["ref_psnr_vs_scene_pixels"]) < 0.1       # the north star's 0.1 dB, on this frame
+
+
 # ---- full-size training step (round 3) --------------------------------------------------------------------------------
-def _train_inputs(g):
+def _field_params(G, g):
+    """parameters of a golden computed on the TRAINED field (tests/golden/trained_field.npz, make_golden.py --only-trained-field)"""
+    f = G.load_golden(str(g["field"]))
+    params = {k[2:]: f[k] for k in f if k.startswith("p_")}
+    h = hashlib.sha256()
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    assert h.hexdigest() == str(g["field_sha256"]), "golden was written for another trained_field.npz"
+    return params
+
+
+def _stored_rays(g):
+    return syn.Rays(*[np.ascontiguousarray(g["rays_" + k]) for k in syn.Rays._fields])
+
+
+def _train_inputs(g, G=None):
     B, N = int(g["batch"]), int(g["num_samples"])
+    if "field" in g:          # round 4: rays and pixels of the procedural scene are stored in the golden
+        return _stored_rays(g), _field_params(G, g), np.ascontiguousarray(g["gt"]), (None, None)
     rays = syn.synthetic_rays(B, seed=int(g["ray_seed"]), multiscale=bool(g["multiscale"]))
     params = syn.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
     gt = np.random.default_rng(1).uniform(0, 1, size=(B, 3)).astype(np.float32)
@@ -112,7 +179,8 @@ def _grad_split(system, flat):
     return out
 
 
-@pytest.mark.parametrize("name", ["fulltrain_c2_4096x128", "fulltrain_c3_4096x128_ms", "fulltrain_c3_4096x128_ms_rand"])
+@pytest.mark.parametrize("name", ["fulltrain_c2_4096x128", "fulltrain_c3_4096x128_ms", "fulltrain_c3_4096x128_ms_rand",
+                                  "fulltrained_c2_4096x128"])
 def test_full_size_training_step_vs_reference(G, name):
     """loss + all 24 gradients of ONE training step at the size the metric is quoted on (4096 rays x 128
     samples; configs[1] single-scale and configs[2] multi-scale lossmult / radii; deterministic and with the reference's two
@@ -123,8 +191,8 @@ def test_full_size_training_step_vs_reference(G, name):
     cosine with the REFERENCE's gradient >= 0.99 and its norm within 5 %."""
     from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
     g = G.load_golden(name)
-    rays_np, params, gt_np, (t_rand, u_rand) = _train_inputs(g)
-    randomized = bool(int(g["randomized"]))
+    rays_np, params, gt_np, (t_rand, u_rand) = _train_inputs(g, G)
+    randomized = bool(int(g["randomized"])) if "randomized" in g else False
     rays, gt = G.to_dev(rays_np), torch.from_numpy(gt_np).to(DEV)
     hp = dict(DEFAULT_HPARAMS)
     hp.update({'nerf.num_samples': int(g["num_samples"]), 'train.randomized': randomized})
@@ -140,10 +208,12 @@ def test_full_size_training_step_vs_reference(G, name):
     for lvl in range(2):
         rec[f"fp32_l{lvl}_rgb"] = G.maxdiff(ret[lvl][0], g[f"l{lvl}_rgb"])
         assert rec[f"fp32_l{lvl}_rgb"] <= G.TOL_FP32["rgb"]
-        assert abs(float(mses[lvl]) - float(g["mse"][lvl])) <= 2e-5 * float(g["mse"][lvl])
+        # (d mse ~ 2 mean(residual x d rgb) x 3: at a trained field's residuals of ~0.02 an rgb error of 1e-6 is 1.6e-4 of the mse)
+        rec[f"fp32_mse{lvl}_rel"] = abs(float(mses[lvl]) - float(g["mse"][lvl])) / float(g["mse"][lvl])
+        assert abs(float(mses[lvl]) - float(g["mse"][lvl])) <= 2e-5 * float(g["mse"][lvl]) + 3e-6 * float(g["mse"][lvl]) ** 0.5
         assert abs(float(dls[lvl]) - float(g["distloss"][lvl])) <= 1e-4 * float(g["distloss"][lvl])
     rec["fp32_loss_rel"] = abs(float(loss) - float(g["loss"])) / float(g["loss"])
-    assert rec["fp32_loss_rel"] <= 2e-5
+    assert abs(float(loss) - float(g["loss"])) <= 2e-5 * float(g["loss"]) + 3e-6 * float(g["mse"][1]) ** 0.5
     ref = _grad_split(system, ref_full)
     worst = 0.0
     enc_cols = {"layers.0.0.weight": 0, "layers.5.0.weight": 256}      # first column of the 96 encoding features (mip_nerf.py:96-97)
@@ -163,7 +233,8 @@ def test_full_size_training_step_vs_reference(G, name):
             cols = enc_cols[k]
             A, R = a.reshape(p.shape)[:, cols:cols + 96], ref[k].reshape(p.shape)[:, cols:cols + 96]
             deg = (np.arange(96) % 48) // 3
-            by_deg = [float(np.linalg.norm((A - R)[:, deg == l]) / np.linalg.norm(R[:, deg == l])) for l in range(16)]
+            # (a degree whose features the IPE has damped to exactly zero has an exactly-zero gradient on both sides)
+            by_deg = [float(np.linalg.norm((A - R)[:, deg == l]) / max(np.linalg.norm(R[:, deg == l]), 1e-30)) for l in range(16)]
             rel_low = float(np.linalg.norm((A - R)[:, deg <= 4]) / np.linalg.norm(R[:, deg <= 4]))
             rec[f"fp32_{k}_rel_deg0to4"], rec[f"fp32_{k}_rel_whole"] = rel_low, rel
             for l in range(16):
@@ -183,7 +254,8 @@ def test_full_size_training_step_vs_reference(G, name):
             worst = max(worst, rel)
             assert rel <= 1e-3, (k, rel)
         stride = max(1, a.size // 64)
-        assert np.max(np.abs(a[::stride][:64] - g["g_smp_" + k])) <= (5e-3 if k in enc_cols else 1e-3) * max(np.abs(g["g_smp_" + k]).max(), l2 / np.sqrt(a.size))
+        smp = g["g_smp_" + k] if "g_smp_" + k in g else ref[k][::stride][:64]
+        assert np.max(np.abs(a[::stride][:64] - smp)) <= (5e-3 if k in enc_cols else 1e-3) * max(np.abs(smp).max(), l2 / np.sqrt(a.size))
     rec["fp32_worst_grad_rel_l2"] = worst
     del system, ret, loss
     torch.cuda.empty_cache()
@@ -196,17 +268,55 @@ def test_full_size_training_step_vs_reference(G, name):
     rec["bf16_loss_abs"] = abs(float(sc[0]) - float(g["loss"]))
     assert rec["bf16_loss_abs"] <= 1e-3, (sc, float(g["loss"]))
     assert abs(float(sc[1]) - float(g["mse"][0])) <= 1e-3 and abs(float(sc[2]) - float(g["mse"][1])) <= 1e-3
-    cos_worst, norm_worst = 1.0, 0.0
+    cos_worst, norm_worst, per = 1.0, 0.0, {}
+    names = [k for k, _ in nsys.mip_nerf.mlp.named_parameters()]
     for k, p in nsys.mip_nerf.mlp.named_parameters():
         a = p.grad.detach().cpu().numpy().ravel().astype(np.float64)
         na, nb = np.linalg.norm(a), np.linalg.norm(ref[k])
-        cos = float(a @ ref[k] / max(na * nb, 1e-30))
-        cos_worst = min(cos_worst, cos)
-        norm_worst = max(norm_worst, abs(na - nb) / nb)
-        assert cos >= 0.99, (k, cos)
-        assert abs(na - nb) <= 0.05 * nb, (k, na, nb)
+        per[k] = (float(a @ ref[k] / max(na * nb, 1e-30)), float(abs(na - nb) / nb))
+        rec[f"bf16_cos_{k}"], rec[f"bf16_normrel_{k}"] = per[k]
+    # the tensor behind the worst cosine on the fog fields (0.9917 on fulltrain_c2) is layers.0.0.weight: it multiplies the 96 integrated
+    # positional-encoding features (+-1 oscillations whose phase at degree l moves by 2^l x the bf16 / fast-sine error of the argument),
+    # and its delta has come through all eight dgrad layers in bf16.  Its cosine is recorded by degree and bounded below (see the asserts)
+    k0 = "layers.0.0.weight"
+    A0 = nsys.mip_nerf.mlp.layers[0][0].weight.grad.detach().cpu().numpy().astype(np.float64)
+    R0 = ref[k0].reshape(A0.shape)
+    deg = (np.arange(96) % 48) // 3
+    cos_deg = [float((A0[:, deg == l] * R0[:, deg == l]).sum() / max(np.linalg.norm(A0[:, deg == l]) * np.linalg.norm(R0[:, deg == l]), 1e-30))
+               for l in range(16)]
+    for l in range(16):
+        rec[f"bf16_{k0}_cos_deg{l}"] = cos_deg[l]
+    low = deg <= 5
+    rec[f"bf16_{k0}_cos_deg0to5"] = float((A0[:, low] * R0[:, low]).sum() / (np.linalg.norm(A0[:, low]) * np.linalg.norm(R0[:, low])))
+    wc = min(per, key=lambda k: per[k][0])
+    wn = max(per, key=lambda k: per[k][1])
+    cos_worst, norm_worst = per[wc][0], per[wn][1]
+    rec["bf16_worst_cos_tensor_index"], rec["bf16_worst_norm_tensor_index"] = names.index(wc), names.index(wn)
+    print(f"{name}: worst cosine {cos_worst:.5f} ({wc}), worst norm error {norm_worst:.4f} ({wn})")
+    # Bounds.  On the fog fields (loss 0.1-0.3, residuals O(0.3)) cosine >= 0.99 and norm within 5 % per tensor.  On the TRAINED field the
+    # loss is 2e-3: dL/drgb = 2 mask (rgb - gt) / sum(mask) is proportional to residuals of +-0.02, and the bf16 FORWARD's rgb (within
+    # 2e-3 of the reference's, PSNR 72 dB) moves such a residual by ~10 % -- so the bf16 step's gradient is the gradient at a slightly
+    # different output and legitimately differs by that much in magnitude (measured: colour / view / bottleneck tensors 7-9 %, trunk
+    # 2-5 %; fp32 mode holds 1e-3 on the same golden, so it is the operand precision, not the dataflow), while every tensor's
+    # direction still agrees to cosine >= 0.992.  Bounds there: cosine >= 0.985, norm within 15 %, whole gradient >= 0.99.
+    cos_min, norm_max = (0.985, 0.15) if "field" in g else (0.99, 0.05)
+    G.record(f"fullsize_train {name} (bf16 per tensor)", **{k: v for k, v in rec.items() if k.startswith("bf16_")})
+    for k in names:
+        assert per[k][0] >= cos_min, (k, per[k])
+        assert per[k][1] <= norm_max, (k, per[k])
+    if "field" not in g:
+        # measured on fulltrain_c2 (the worst of the three): degree 0: 0.9975, 1: 0.994, 3: 0.991, 5: 0.988, 9: 0.978, 11: 0.943, 14-15: noise
+        # (features damped to ~0); degrees 0-5 together 0.994.  The profile falls with the degree (phase error 2^l x argument error) from
+        # a floor set by the delta's own bf16 noise after eight dgrad layers, contracted against features that do not average it out
+        assert rec[f"bf16_{k0}_cos_deg0to5"] >= 0.99 and cos_deg[0] >= 0.995 and min(cos_deg[:10]) >= 0.97, cos_deg
+        assert cos_deg[0] > cos_deg[5] > cos_deg[11], cos_deg
+        for k in names:
+            if k != k0:
+                assert per[k][0] >= 0.998, (k, per[k])        # every tensor but the encoding-fed first layer
     fa = torch.cat([p.grad.reshape(-1) for p in nsys.mip_nerf.mlp.parameters()]).cpu().numpy().astype(np.float64)
     rec["bf16_cos_whole_gradient"] = float(fa @ ref_full / (np.linalg.norm(fa) * np.linalg.norm(ref_full)))
+    print(f"{name}: bf16 whole-gradient cosine {rec['bf16_cos_whole_gradient']:.6f}")
+    assert rec["bf16_cos_whole_gradient"] >= (0.99 if "field" in g else 0.9995)
     rec["bf16_worst_tensor_cos"] = cos_worst
     rec["bf16_worst_tensor_norm_rel"] = norm_worst
     G.record(f"fullsize_train {name}", **rec)
