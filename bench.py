@@ -223,7 +223,7 @@ def run_inference(args, e):
     samples_per_step = B * N * model.num_levels
     value = samples_per_step * e.world * args.steps / dt
     peak = PEAK_TFLOPS[args.precision]
-    kname = "k_mlp_bf16" if model.precision == L.PREC_BF16 else "k_mlp_f32"
+    kname = "k_mlp_bf16" if model.precision == L.PREC_BF16 else "k_mlp_f32r (register-resident, generated; round 3: the LDS-resident k_mlp_f32)"
     roofline = None
     if nl > 0:
         launch_ms = tot_ms / nl
@@ -516,7 +516,8 @@ def run_fp32_c4(args, e):
         unb = {"error": f"{type(ex).__name__}: {ex}"}
     return {"unbounded": unb, "value": round(B * N * 2 * e.world * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warm,
             "scaling": "weak", "dtype": "fp32",
-            "roofline": {"bound": "mfma", "kernel": "k_mlp_f32", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "k_mlp_f32r (register-resident, generated by csrc/gen_mlp_f32r.py; round 3: the LDS-resident k_mlp_f32)",
+                         "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(tflops / peak, 4), "traffic": None, "launch_ms": round(launch_ms, 4), "launches_timed": nl,
                          "samples_per_launch": M, "flop_per_sample": FLOP_PER_SAMPLE},
             "config": {"workload": (f"BASELINE.json configs[3] shape: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) samples per GPU, "

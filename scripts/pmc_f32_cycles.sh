@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: k_mlp_f32 (fp32 parity mode) in cycles: GRBM / SQ counters of the headline-shaped fp32 forward (4096 x (128+128))
+# rounds 3-4: the fp32 MLP kernel (k_mlp_f32 in round 3, the register-resident k_mlp_f32r since round 4) in cycles: GRBM / SQ counters of the headline-shaped fp32 forward (4096 x (128+128))
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_f32
@@ -8,11 +8,11 @@ export TMPDIR=/tmp
 cd /tmp
 rm -rf $OUT/pmc
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc -o pmc -- python $ROOT/bench.py --mode inference --precision fp32 --steps 6 --warmup 2 --no-cpu-baseline --sustain-seconds 0 --preheat-seconds 0 > $OUT/pmc.log 2>&1
-python - $OUT/pmc <<'PY' | tee $ROOT/gpurun_out/r03ag_f32_cycles.txt
+python - $OUT/pmc <<'PY' | tee $ROOT/gpurun_out/${F32_CYCLES_OUT:-r04e_f32r_cycles.txt}
 import csv, sys, glob, collections
 d = sys.argv[1]
 M = 524288
-flop = 1220608 * M * 1.02
+flop = 1220608 * M      # k_mlp_f32r executes exactly the algorithmic MACs on the matrix pipe (k_mlp_f32 of round 3: x 1.02)
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0])):
     if "k_mlp_f32" in r["Kernel_Name"]:
