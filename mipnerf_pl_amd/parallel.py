@@ -78,9 +78,13 @@ class FlatGradAllReduce:
             off += n
 
 
-def gather_rendered(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
-    """all_gather of per-ray outputs produced from shard_rays() shards -> [n_total, ...] on every rank."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+def gather_rendered(local: torch.Tensor, n_total: int, group=None, force_collective: bool = False) -> torch.Tensor:
+    """all_gather of per-ray outputs produced from shard_rays() shards -> [n_total, ...] on every rank.
+    force_collective: go through the communicator at world 1 too (a 1-rank RCCL all_gather is legal: how a single-GPU box
+    exercises the multi-GPU rendering path end to end)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return local
+    if dist.get_world_size(group) == 1 and not force_collective:
         return local
     world = dist.get_world_size(group)
     sizes = [shard_bounds(n_total, r, world) for r in range(world)]
