@@ -398,7 +398,7 @@ def measure_one_rank_rccl_allreduce(numel, dev):
             port = sk.getsockname()[1]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ["MASTER_PORT"] = str(port)
-        os.environ.setdefault("NCCL_DEBUG", "WARN")       # no version banner on stdout
+        os.environ["NCCL_DEBUG"] = "WARN"                 # no version banner on stdout (this 1-rank communicator only)
         dist.init_process_group("nccl", rank=0, world_size=1)
         buf = torch.zeros(numel, device=dev)
         dist.all_reduce(buf)                      # creates the communicator (seconds)

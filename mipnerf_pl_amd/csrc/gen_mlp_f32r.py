@@ -30,6 +30,8 @@ from mipnerf_pl_amd.mlp_f32r_plan import GROUP_CHUNKS, NSLOT, RING_SLOTS, F32RPl
 GROUP_BYTES = GROUP_CHUNKS * 1024
 RING_BYTES = RING_SLOTS * GROUP_BYTES
 WAVES = 4
+PIECE_WINDOW = float(os.environ.get("MLP_F32R_PIECE_WINDOW", "0.5"))
+GEN_ABLATE = int(os.environ.get("MLP_F32R_GEN_ABLATE", "0"))      # timing experiments (wrong results): 1 no LDS-DMA, 2 no accumulator images, 4 no thin heads, 8 no ReLU   # fraction of a ring group's k-steps that carry its LDS-DMA pieces
 TILE_SAMPLES = 32 * WAVES
 
 
@@ -45,35 +47,48 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 // the ring group and the natural blocks issued two groups ago have landed (this wave's pieces: vmcnt; everybody's: the barrier), and every
 // wave is done reading the slot the next group goes to
-#define GROUP_BEGIN() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
+#if defined(MLP_F32R_ABLATE) && MLP_F32R_ABLATE == 1          // timing experiments only (races): no barrier / no waits at all
+#define GROUP_BEGIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#elif defined(MLP_F32R_ABLATE) && MLP_F32R_ABLATE == 2
+#define GROUP_BEGIN() asm volatile("" ::: "memory")
+#else
+#define GROUP_BEGIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 __device__ __forceinline__ float relu1(float x) { return __builtin_fmaxf(x, 0.0f); }
 
-// One 1-KiB LDS-DMA piece of the weight stream: wave-uniform 64-bit base in SGPRs + 32-bit lane offset (saddr form), lands lane-linear
-// at M0.  Inline asm on purpose (see gen_mlp_bf16.py: hipcc models the builtin as a flat access that degrades every later lgkmcnt wait).
+// One 1-KiB LDS-DMA piece of the weight stream: wave-uniform 64-bit base in SGPRs + 32-bit lane offset (saddr form) + an immediate that the
+// hardware adds to BOTH the global address and the LDS destination (M0 + imm + lane * 16), so the four pieces of a batch share one base
+// and one M0 value.  Inline asm on purpose (see gen_mlp_bf16.py: hipcc models the builtin as a flat access that degrades every later
+// lgkmcnt wait).  The bases are made opaque per batch (OPAQUE_S): otherwise the compiler hoists ~600 loop-invariant 64-bit piece addresses
+// out of the tile loop, spills them to VGPR lanes and pays two v_readlane per piece (measured: the pieces cost 4 % of the kernel that way).
+#define OPAQUE_S(x) asm volatile("" : "+s"(x))
+template <int IMM>
 __device__ __forceinline__ void dma_piece(const char* gbase, unsigned lds_addr, unsigned lane16) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:%4\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(lane16), "s"(gbase), "s"(lds_addr)
+        : "v"(lane16), "s"(gbase), "s"(lds_addr), "n"(IMM)
         : "memory");
 }
-// One piece of a natural block: every lane brings 16 bytes of ITS sample's row (per-lane 64-bit address).
-__device__ __forceinline__ void dma_piece_v(const float* src, unsigned lds_addr) {
+// One piece of a natural block: every lane brings 16 bytes of ITS sample's row: per-lane 64-bit row address + immediate; M0 is the LDS
+// target minus that immediate.
+template <int IMM>
+__device__ __forceinline__ void dma_piece_v(const float* row, unsigned m0_val) {
     unsigned keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off offset:%3\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(src), "s"(lds_addr)
+        : "v"(row), "s"(m0_val), "n"(IMM)
         : "memory");
 }
 """
@@ -116,13 +131,32 @@ class Gen:
         op, blk, j = st["op"], st["blk"], st["j"]
         assert blk.kind == DLAYOUT
         reg = f"{blk.src}[{blk.index}][{j}]"
-        return f"relu1({reg})" if op.in_relu else reg
+        return f"relu1({reg})" if op.in_relu and not (GEN_ABLATE & 8) else reg
 
-    def nat_piece_src(self, u, q, nxt):
+    def nat_pieces(self, u, nxt, indent="        "):
+        """the four LDS-DMA statements of one natural block (the first carries the opaque copy of the wave's LDS base)"""
         op = self.p.ops[u["op"]]
         blk = op.blocks[u["block"]]
-        base = ("encp" if blk.src == "enc" else "viewp") + ("_nxt" if nxt else "_cur")
-        return f"{base} + {32 * blk.index + 4 * q}"
+        row = ("encp" if blk.src == "enc" else "viewp") + ("_nxt" if nxt else "_cur")
+        out = []
+        for q in range(4):
+            imm = (32 * blk.index + 4 * q) * 4
+            assert 0 <= imm < 4096
+            pre = "nl = nat_lds; OPAQUE_S(nl); " if q == 0 else ""
+            out.append(f"{pre}dma_piece_v<{imm}>({row}, nl + ({u['slot'] * 4096 + q * 1024 - imm}));")
+        return out
+
+    def ring_pieces(self, gn, groups):
+        """the LDS-DMA statements of ring group gn: batches of four pieces share a base (immediate offsets 0 .. 3072)"""
+        c0, k = groups[gn]
+        npw = k // WAVES
+        out = []
+        for i in range(npw):
+            pre = ""
+            if i % 4 == 0:
+                pre = (f"gp = sw{npw}; OPAQUE_S(gp); gp += {c0 * 1024 + i * 1024}; lp = lw{npw}; OPAQUE_S(lp); lp += {(gn & 1) * GROUP_BYTES + i * 1024}; ")
+            out.append(f"{pre}dma_piece<{(i % 4) * 1024}>(gp, lp, lane16);")
+        return out
 
     # ---- the tile body ------------------------------------------------------------------------------
     def body(self):
@@ -169,122 +203,145 @@ class Gen:
         for s_ in bias_tile_start:
             E("        " + s_)
         pieces = []                # LDS-DMA statements waiting for a k-step to ride on
-        cur_g = -1
-        have_a = False             # a0 / a1 hold this step's A fragments (read by the previous step)
-        have_bq = None             # (op, block, quad) held in `bq`
+        have_bq = self.first_bq_key(steps)      # the prologue / the previous tile's last step has read the first natural quad
         b_ready = False            # `b` holds this step's B operand (computed by the previous step)
         thin_decl = set()
         nsteps = len(steps)
+        mfma_idx = [i for i, st in enumerate(steps) if st["nq"]]
+        nxt_mfma = {}              # step index -> the next MFMA step (cyclic over tiles)
+        for k, i in enumerate(mfma_idx):
+            nxt_mfma[i] = steps[mfma_idx[(k + 1) % len(mfma_idx)]]
+        group_len = {gi: sum(1 for i in mfma_idx if c0 <= steps[i]["cpos"] < c0 + k) for gi, (c0, k) in enumerate(groups)}
+        begun = 0                  # ring group whose BEGIN was emitted last (group 0's: by the prologue / the previous tile)
+        since_begin = 1            # MFMA steps since that BEGIN (it sits one k-step before its group)
         for i, st in enumerate(steps):
             op, oi, blk, j, nq = st["op"], st["oi"], st["blk"], st["j"], st["nq"]
-            nxt = steps[i + 1] if i + 1 < nsteps else None
+            nxt = steps[(i + 1) % nsteps]
             src_txt = f"reg {blk.src}[{blk.index}]" if blk.kind == DLAYOUT else f"{blk.src} block {blk.index}"
             E(f"        // {op.name} k-step {st['ks']} ({src_txt}, {j})")
-            if nq and st["cpos"] in gstart:
-                g = gstart[st["cpos"]]
-                assert g == cur_g + 1, (g, cur_g)
-                while pieces:                                # (should be empty: a group has at least as many k-steps as pieces)
-                    E("        " + pieces.pop(0))
-                E("        GROUP_BEGIN();")
-                self.group_pieces(g, groups, pieces, fetch_at)
-                cur_g = g
-                have_a = False
+            nm = nxt_mfma.get(i)
             if nq:
-                c0, k = groups[cur_g]
+                g_cur = p.group_of(st["cpos"])
+                assert g_cur == begun, (g_cur, begun)
+                c0, k = groups[g_cur]
                 assert c0 <= st["cpos"] and st["cpos"] + nq <= c0 + k, "a k-step straddles a ring group"
+                if nm["cpos"] in gstart:
+                    # ---- the NEXT k-step opens ring group g: its barrier sits HERE, one k-step early -- this step's A fragments are in
+                    # registers already, so the slot of group g - 1 is free for group g + 1 once every wave is past the barrier, and the
+                    # first reads of group g (issued during this step's MFMAs) never wait behind a barrier
+                    g = gstart[nm["cpos"]]
+                    assert g == (begun + 1) % NG
+                    while pieces:                                # (normally empty: pieces are paced to finish in half a group)
+                        E("        " + pieces.pop(0))
+                    E("        GROUP_BEGIN();")
+                    self.group_pieces(g, groups, pieces, fetch_at)
+                    begun, since_begin = g, 0
             for s_ in bias_head.get(i, []):
                 E("        " + s_)
-            slot = cur_g & 1
-            if nq:
-                coff = (st["cpos"] - groups[cur_g][0]) * 1024 + slot * GROUP_BYTES
-                if not have_a:
-                    E(f"        a0 = LDA({coff});" + (f" a1 = LDA({coff + 1024});" if nq == 2 else ""))
             # ---- B operand of THIS step
             if blk.kind == NATURAL:
                 u = self.use_of(oi, st["ks"] // 16)
                 key = (oi, st["ks"] // 16, j // 4)
-                if have_bq != key:
-                    E(f"        bq = LDB({u['slot'] * 4096 + (j // 4) * 1024});")
-                    have_bq = key
-                E(f"        b = bq[{j % 4}];")
+                assert have_bq == key, ("natural quad not prefetched", key, have_bq)
+                E(f"        b{i % 2} = bq[{j % 4}];")
             elif not b_ready:
-                E(f"        b = {self.b_expr(st)};")
-            # ---- reads for the NEXT step: A fragments, B operand
-            nxt_a = nxt is not None and nq and nxt["nq"] and nxt["cpos"] not in gstart
-            if nxt_a:
-                noff = (nxt["cpos"] - groups[cur_g][0]) * 1024 + slot * GROUP_BYTES
-                E(f"        n0 = LDA({noff});" + (f" n1 = LDA({noff + 1024});" if nxt["nq"] == 2 else ""))
-            nxt_b = nxt is not None and nxt["blk"].kind == DLAYOUT and nxt["op"] is op      # (another op's registers are still accumulating)
+                E(f"        b{i % 2} = {self.b_expr(st)};")
+            # ---- reads for the NEXT step: A fragments (of the next MFMA step), B operand
+            if nq:
+                g_n = p.group_of(nm["cpos"])
+                noff = (nm["cpos"] - groups[g_n][0]) * 1024 + (g_n & 1) * GROUP_BYTES
+                E(f"        n0 = LDA({noff});" + (f" n1 = LDA({noff + 1024});" if nm["nq"] == 2 else ""))
+            nxt_b = nxt["blk"].kind == DLAYOUT and nxt["op"] is op and i + 1 < nsteps      # (another op's registers are still accumulating)
             if nxt_b:
-                E(f"        bn = {self.b_expr(nxt)};")
+                E(f"        b{(i + 1) % 2} = {self.b_expr(nxt)};")
             nxt_q = None
-            if nxt is not None and nxt["blk"].kind == NATURAL:
+            if nxt["blk"].kind == NATURAL:
                 key = (nxt["oi"], nxt["ks"] // 16, nxt["j"] // 4)
                 if have_bq != key:
                     un = self.use_of(nxt["oi"], nxt["ks"] // 16)
-                    # (legal one step ahead even on a group boundary: natural blocks are issued two groups before their first k-step)
+                    # (legal one step ahead even across a group boundary or the tile boundary: natural blocks are issued two groups before
+                    # their first k-step, and one GROUP_BEGIN in between has waited for them)
                     E(f"        bqn = LDB({un['slot'] * 4096 + (nxt['j'] // 4) * 1024});")
                     nxt_q = key
             # ---- thin head riding on this step
-            for th in op.thin:
+            for th in (op.thin if not (GEN_ABLATE & 4) or not op.tiles else []):
                 for row in range(th.nrows):
-                    nm = f"thin{oi}_{row}"
+                    nm_ = f"thin{oi}_{row}"
                     if st["ks"] % 4 == 0:
                         E(f"        hw{row} = AUX4({(self.lay[('thin_w', oi, row)] + st['ks']) * 4});")
-                    E(f"        {nm} = fmaf(b, hw{row}[{st['ks'] % 4}], {nm});")
-                    thin_decl.add(nm)
-            # ---- the MFMAs, one DMA piece between them
+                    E(f"        {nm_} = fmaf(b{i % 2}, hw{row}[{st['ks'] % 4}], {nm_});")
+                    thin_decl.add(nm_)
+            # ---- the MFMAs, LDS-DMA pieces between them: all pieces of a group are issued in its first half (the last one lands well
+            # before the next barrier asks for it)
             nt = len(op.tiles)
             npc = 0
             if pieces:
                 if nq:
-                    c0g, kg = groups[cur_g]
-                    left = sum(1 for s2 in steps[i:] if s2["nq"] and c0g <= s2["cpos"] < c0g + kg)       # k-steps left in this ring group
-                    npc = -(-len(pieces) // left)
+                    window = max(1, int(group_len[begun] * PIECE_WINDOW) - since_begin)
+                    npc = -(-len(pieces) // window)
                 else:
                     npc = 1
-            at = {((k + 1) * nt) // (npc + 1): 0 for k in range(npc)} if nt else {}
+            at = {}
             for k in range(npc if nt else 0):
-                at[((k + 1) * nt) // (npc + 1)] += 1
+                pos = ((k + 1) * nt) // (npc + 1)
+                at[pos] = at.get(pos, 0) + 1
             for t in range(nt):
                 for _ in range(at.get(t, 0)):
-                    E("        " + pieces.pop(0))
-                E(f"        MFMA({op.out}[{t}], a{t // 4}[{t % 4}], b);")
+                    pc = pieces.pop(0)
+                    if not (GEN_ABLATE & 1) or pc.startswith("NEXT"):
+                        E("        " + pc)
+                E(f"        MFMA({op.out}[{t}], a{t // 4}[{t % 4}], b{i % 2});")
             if nt == 0:
                 for _ in range(npc):
-                    E("        " + pieces.pop(0))
+                    pc = pieces.pop(0)
+                    if not (GEN_ABLATE & 1) or pc.startswith("NEXT"):
+                        E("        " + pc)
             for s_ in bias_in.get(i, []):
-                E("        " + s_)
+                if not (GEN_ABLATE & 2):
+                    E("        " + s_)
             if nt:
                 E("        PIN();")
-            if nxt_a:
-                E("        a0 = n0;" + (" a1 = n1;" if nxt["nq"] == 2 else ""))
-            have_a = bool(nxt_a)
-            if nxt_b:
-                E("        b = bn;")
+            if nq:
+                E("        a0 = n0;" + (" a1 = n1;" if nm["nq"] == 2 else ""))
+                since_begin += 1
             b_ready = bool(nxt_b)
             if nxt_q is not None:
                 E("        bq = bqn;")
                 have_bq = nxt_q
-        assert cur_g == NG - 1, (cur_g, NG)
+        assert begun == 0, begun
+        for oi2, op2 in enumerate(p.ops):
+            for th in op2.thin:
+                for row in range(th.nrows):
+                    thin_decl.add(f"thin{oi2}_{row}")
         while pieces:
             E("        " + pieces.pop(0))
+        assert have_bq == self.first_bq_key(steps)
         return sorted(thin_decl)
 
-    def group_pieces(self, g, groups, pieces, fetch_at):
+    @staticmethod
+    def first_bq_key(steps):
+        st = steps[0]
+        return (st["oi"], st["ks"] // 16, st["j"] // 4) if st["blk"].kind == NATURAL else None
+
+    def _fetch_at(self):
+        out = {}
+        for u in self.sched:
+            if u["fetch"]:
+                out.setdefault(u["issue_group"], []).append(u)
+        return out
+
+    def group_pieces(self, g, groups, pieces, fetch_at, prologue_cur=False):
         """queue the LDS-DMA pieces issued during ring group g: the weight-stream group after it (cyclically: the next tile's first),
         then the natural blocks scheduled here"""
         gn = (g + 1) % len(groups)
-        c0, k = groups[gn]
-        npw = k // WAVES                                      # pieces per wave
-        for i in range(npw):
-            pieces.append(f"dma_piece(stream + {c0 * 1024} + wave * {npw * 1024} + {i * 1024}, ring_base + {(gn & 1) * GROUP_BYTES} + wave * {npw * 1024} + {i * 1024}, lane16);")
+        pieces += self.ring_pieces(gn, groups)
         for u in fetch_at.get(g, []):
-            if u["prev_tile"] and not self._next_ptrs_emitted:
+            # group 0's barrier sits in the PREVIOUS tile's last k-step: what is issued behind it belongs to the next tile
+            nxt = (u["prev_tile"] or g == 0) and not prologue_cur
+            if nxt and not self._next_ptrs_emitted:
                 pieces.append("NEXT_TILE_POINTERS();")
                 self._next_ptrs_emitted = True
-            for q in range(4):
-                pieces.append(f"dma_piece_v({self.nat_piece_src(u, q, u['prev_tile'])}, nat_lds + {u['slot'] * 4096 + q * 1024});")
+            pieces += self.nat_pieces(u, nxt)
 
     # ---- the whole translation unit ----------------------------------------------------------------------
     def source(self):
@@ -294,14 +351,25 @@ class Gen:
         self.L = []
         thin = self.body()
         body = "\n".join(self.L)
-        first_fetch = [u for u in self.sched if u["fetch"] and u["prev_tile"]]
+        # prologue of the first tile = what the previous tile's tail does for every later one: the natural blocks issued "in the previous
+        # tile" and ring group 0, group 0's barrier, what is queued behind it (ring group 1, natural blocks of issue group 0), and the
+        # first k-step's operands
+        groups = p.groups()
         prologue = []
-        for u in first_fetch:
-            for q in range(4):
-                prologue.append(f"    dma_piece_v({self.nat_piece_src(u, q, False)}, nat_lds + {u['slot'] * 4096 + q * 1024});")
-        g0c, g0k = p.groups()[0]
-        for i in range(g0k // WAVES):
-            prologue.append(f"    dma_piece(stream + wave * {g0k // WAVES * 1024} + {i * 1024}, ring_base + wave * {g0k // WAVES * 1024} + {i * 1024}, lane16);")
+        for u in [u for u in self.sched if u["fetch"] and u["prev_tile"]]:
+            prologue += ["    " + x for x in self.nat_pieces(u, False)]
+        prologue += ["    " + x for x in self.ring_pieces(0, groups)]
+        prologue.append("    GROUP_BEGIN();")
+        q0 = []
+        keep = self._next_ptrs_emitted
+        self._next_ptrs_emitted = True           # (no next-tile pointers in the prologue: the first tile's own)
+        self.group_pieces(0, groups, q0, {g: [dict(u, prev_tile=False)] for g, us in self._fetch_at().items() for u in us if g == 0}, prologue_cur=True)
+        self._next_ptrs_emitted = keep
+        prologue += ["    " + x for x in q0]
+        st0 = self.steps()[0]
+        prologue.append(f"    a0 = LDA(0);" + (" a1 = LDA(1024);" if st0["nq"] == 2 else ""))
+        if st0["blk"].kind == NATURAL:
+            prologue.append(f"    bq = LDB({self.use_of(0, 0)['slot'] * 4096});")
         head_ops = [(oi, op) for oi, op in enumerate(p.ops) if op.thin]
         dens = [(oi, op) for oi, op in head_ops if op.kind == 1]
         col = [(oi, op) for oi, op in head_ops if op.kind == 2]
@@ -346,7 +414,9 @@ k_mlp_f32r(const char* __restrict__ stream_w, const float* __restrict__ aux, con
     const char* nat_lane = smem + kNatOff + wave * {NSLOT * 4096} + lane16;
     const unsigned ring_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem);
     const unsigned nat_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + kNatOff) + wave * {NSLOT * 4096};
-    const char* stream = stream_w;
+{chr(10).join(f"    const char* sw{n} = stream_w + wave * {n * 1024}; const unsigned lw{n} = ring_base + wave * {n * 1024};" for n in sorted({k // WAVES for _, k in p.groups()}))}
+    const char* gp = stream_w;
+    unsigned lp = 0, nl = 0;
     // this lane's sample of a tile, its encoding row and its ray's view encoding (clamped past the end: loads only)
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
@@ -364,11 +434,11 @@ k_mlp_f32r(const char* __restrict__ stream_w, const float* __restrict__ aux, con
         encp_nxt = enc + sc_ * kXyzDim + 16 * hi;                                                \\
         viewp_nxt = viewenc + (sc_ / num_samples) * 32 + 16 * hi;                                \\
     }} while (0)
-    // prologue: ring group 0 and the natural blocks the first groups read
-{chr(10).join(prologue)}
     f32x16 X[8], Y[8];
     f32x4 a0, a1, n0, n1, bq, bqn, hw0, hw1, hw2;
-    float b, bn;
+    float b0, b1;
+    // prologue: ring group 0 and the natural blocks the first groups read
+{chr(10).join(prologue)}
     for (; tile < ntiles; tile += gridDim.x) {{
         float {", ".join(f"{t} = 0.0f" for t in thin)};
 {body}
