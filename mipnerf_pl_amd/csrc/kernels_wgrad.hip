@@ -48,6 +48,22 @@ __device__ __forceinline__ void dma_block(const char* gbase, char* lbase, unsign
         : "v"(lane16), "s"(gbase), "s"(lds_addr)
         : "memory");
 }
+// Timing experiment ("natural-layout hand-off"): MLP_WGRAD_TR=1 reads every operand fragment with two transposing
+// ds_read_b64_tr_b16 instead of one ds_read_b128 -- the LDS traffic a weight-gradient kernel would have if the producers stored their
+// k-step registers as they are (lane = sample) and the transposition happened here.  Same bytes, same MFMAs; the RESULTS ARE WRONG
+// (the T-blocks in memory are still transposed): never the default.
+#if defined(MIP_WGRAD_TR) && MIP_WGRAD_TR
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_frag(const char* p) {
+    const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(size_t)(p));
+    const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16*)(size_t)(p + 8));
+    typedef short v8s16 __attribute__((ext_vector_type(8)));
+    const v8s16 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+}
+#else
+__device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+#endif
 }  // namespace
 
 __global__ void __launch_bounds__(512)
@@ -99,13 +115,13 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
             issue(lo + (nxt < nst ? nxt : nst - 1), nxt % kStages);
             if (active) {
                 const char* st = smem + (i % kStages) * kStageBytes + lane16;
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(st + 16384 + wave * 2048);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(st + 16384 + wave * 2048 + 1024);
+                const bf16x8 a0 = lds_frag(st + 16384 + wave * 2048);
+                const bf16x8 a1 = lds_frag(st + 16384 + wave * 2048 + 1024);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < nB) {
-                        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(st + j * 2048);
-                        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(st + j * 2048 + 1024);
+                        const bf16x8 b0 = lds_frag(st + j * 2048);
+                        const bf16x8 b1 = lds_frag(st + j * 2048 + 1024);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
                     }
