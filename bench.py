@@ -385,43 +385,43 @@ def run_train(args, e):
 
 def measure_one_rank_rccl_allreduce(numel, dev):
     """N = 1 only: what ONE gradient all-reduce costs on the launch stream before any byte crosses a link -- a 1-rank RCCL communicator
-    on this GPU (HIP events around all_reduce + wait, like GraphedTrainStep's collective form).  None when a process group exists already
-    or RCCL cannot be initialised."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    if not dist.is_available() or dist.is_initialized():
-        return None
+    on this GPU (HIP events around all_reduce + wait, like GraphedTrainStep's collective form).  Runs in a CHILD process with a hard
+    timeout: a communicator that cannot be created (or hangs) on some box must not take the bench line with it.  Returns the median ms,
+    or {"error": ...}."""
+    import subprocess
+    code = r"""
+import json, os, socket, sys
+import torch, torch.distributed as dist
+with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port); os.environ["NCCL_DEBUG"] = "WARN"
+torch.cuda.set_device(int(sys.argv[2]))
+dist.init_process_group("nccl", rank=0, world_size=1)
+buf = torch.zeros(int(sys.argv[1]), device="cuda")
+dist.all_reduce(buf); torch.cuda.synchronize()
+ms = []
+for _ in range(40):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True); w.wait(); b.record(); b.synchronize()
+    ms.append(a.elapsed_time(b))
+dist.destroy_process_group()
+ms.sort()
+open(sys.argv[3], "w").write(json.dumps({"ms": ms[len(ms) // 2]}))      # (stdout belongs to RCCL's banner / warnings)
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    import tempfile
+    res = os.path.join(tempfile.gettempdir(), f"mipnerf_rccl1_{os.getpid()}.json")
     try:
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ["MASTER_PORT"] = str(port)
-        os.environ["NCCL_DEBUG"] = "WARN"                 # no version banner on stdout (this 1-rank communicator only)
-        dist.init_process_group("nccl", rank=0, world_size=1)
-        buf = torch.zeros(numel, device=dev)
-        dist.all_reduce(buf)                      # creates the communicator (seconds)
-        torch.cuda.synchronize()
-        ms = []
-        for _ in range(40):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
-            w.wait()
-            b.record()
-            b.synchronize()
-            ms.append(a.elapsed_time(b))
-        dist.destroy_process_group()
-        ms.sort()
-        return ms[len(ms) // 2]
+        out = subprocess.run([sys.executable, "-c", code, str(int(numel)), str(dev.index or 0), res], capture_output=True, text=True, timeout=120, env=env)
+        if os.path.exists(res):
+            with open(res) as f:
+                return float(json.load(f)["ms"])
+        return {"error": f"rc {out.returncode}: " + (out.stderr or out.stdout)[-300:]}
     except Exception as ex:  # noqa: BLE001
-        try:
-            if dist.is_initialized():
-                dist.destroy_process_group()
-        except Exception:  # noqa: BLE001
-            pass
         return {"error": f"{type(ex).__name__}: {ex}"}
+    finally:
+        if os.path.exists(res):
+            os.remove(res)
 
 
 def scale_model(line, ar1_ms, grad_bytes):
