@@ -45,14 +45,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define BIAS(acc, off) acc = *reinterpret_cast<const f32x16*>(aux_lane + (off))
 #define MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), acc, 0, 0, 0)
 #define PIN() __builtin_amdgcn_sched_barrier(0)
-// the ring group and the natural blocks issued two groups ago have landed (this wave's pieces: vmcnt; everybody's: the barrier), and every
-// wave is done reading the slot the next group goes to
+// Ring-group barrier with a COUNTED wait: vmcnt retires in issue order, and this wave issued exactly K LDS-DMA pieces after the ones the
+// next group needs (the pieces queued at the previous barrier: the ring is RING_SLOTS deep, group g + RING_SLOTS - 1 is in flight while
+// g is read), so vmcnt(K) = "my share of the next group and of the natural blocks queued two barriers ago has landed"; lgkmcnt(0) = my
+// reads of the slot that is about to be refilled have returned; the barrier makes both true for every wave.
 #if defined(MLP_F32R_ABLATE) && MLP_F32R_ABLATE == 1          // timing experiments only (races): no barrier / no waits at all
-#define GROUP_BEGIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define GROUP_BEGIN(K) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K) : "memory")
 #elif defined(MLP_F32R_ABLATE) && MLP_F32R_ABLATE == 2
-#define GROUP_BEGIN() asm volatile("" ::: "memory")
+#define GROUP_BEGIN(K) asm volatile("" ::: "memory")
 #else
-#define GROUP_BEGIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define GROUP_BEGIN(K) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(K) : "memory")
 #endif
 
 __device__ __forceinline__ float relu1(float x) { return __builtin_fmaxf(x, 0.0f); }
@@ -104,7 +106,7 @@ class Gen:
         self.nat_off = self.aux_off + self.aux_bytes
         self.lds_bytes = self.nat_off + WAVES * NSLOT * 4096
         assert self.lds_bytes <= 160 * 1024, self.lds_bytes
-        assert plan.n_groups % RING_SLOTS == 0
+        assert plan.n_groups % RING_SLOTS == 0 and plan.n_groups >= 2 * RING_SLOTS
         self.sched = plan.natural_schedule()
         self.L = []
 
@@ -154,7 +156,7 @@ class Gen:
         for i in range(npw):
             pre = ""
             if i % 4 == 0:
-                pre = (f"gp = sw{npw}; OPAQUE_S(gp); gp += {c0 * 1024 + i * 1024}; lp = lw{npw}; OPAQUE_S(lp); lp += {(gn & 1) * GROUP_BYTES + i * 1024}; ")
+                pre = (f"gp = sw{npw}; OPAQUE_S(gp); gp += {c0 * 1024 + i * 1024}; lp = lw{npw}; OPAQUE_S(lp); lp += {(gn % RING_SLOTS) * GROUP_BYTES + i * 1024}; ")
             out.append(f"{pre}dma_piece<{(i % 4) * 1024}>(gp, lp, lane16);")
         return out
 
@@ -233,7 +235,7 @@ class Gen:
                     assert g == (begun + 1) % NG
                     while pieces:                                # (normally empty: pieces are paced to finish in half a group)
                         E("        " + pieces.pop(0))
-                    E("        GROUP_BEGIN();")
+                    E(f"        GROUP_BEGIN({self.wait_count(g, groups, fetch_at)});")
                     self.group_pieces(g, groups, pieces, fetch_at)
                     begun, since_begin = g, 0
             for s_ in bias_head.get(i, []):
@@ -249,7 +251,7 @@ class Gen:
             # ---- reads for the NEXT step: A fragments (of the next MFMA step), B operand
             if nq:
                 g_n = p.group_of(nm["cpos"])
-                noff = (nm["cpos"] - groups[g_n][0]) * 1024 + (g_n & 1) * GROUP_BYTES
+                noff = (nm["cpos"] - groups[g_n][0]) * 1024 + (g_n % RING_SLOTS) * GROUP_BYTES
                 E(f"        n0 = LDA({noff});" + (f" n1 = LDA({noff + 1024});" if nm["nq"] == 2 else ""))
             nxt_b = nxt["blk"].kind == DLAYOUT and nxt["op"] is op and i + 1 < nsteps      # (another op's registers are still accumulating)
             if nxt_b:
@@ -323,6 +325,18 @@ class Gen:
         st = steps[0]
         return (st["oi"], st["ks"] // 16, st["j"] // 4) if st["blk"].kind == NATURAL else None
 
+    def queue_ops(self, g, groups, fetch_at):
+        """number of LDS-DMA instructions queued at the barrier of group g"""
+        gn = (g + RING_SLOTS - 1) % len(groups)
+        return groups[gn][1] // WAVES + 4 * len(fetch_at.get(g, []))
+
+    def wait_count(self, g, groups, fetch_at):
+        """vmcnt operand of group g's barrier: the pieces queued at the barriers of groups g - RING_SLOTS + 2 .. g - 1 may stay in flight"""
+        NG = len(groups)
+        k = sum(self.queue_ops((g - d) % NG, groups, fetch_at) for d in range(1, RING_SLOTS - 1))
+        assert 0 <= k <= 63
+        return k
+
     def _fetch_at(self):
         out = {}
         for u in self.sched:
@@ -333,7 +347,7 @@ class Gen:
     def group_pieces(self, g, groups, pieces, fetch_at, prologue_cur=False):
         """queue the LDS-DMA pieces issued during ring group g: the weight-stream group after it (cyclically: the next tile's first),
         then the natural blocks scheduled here"""
-        gn = (g + 1) % len(groups)
+        gn = (g + RING_SLOTS - 1) % len(groups)             # its slot, (g - 1) % RING_SLOTS, has just been read for the last time
         pieces += self.ring_pieces(gn, groups)
         for u in fetch_at.get(g, []):
             # group 0's barrier sits in the PREVIOUS tile's last k-step: what is issued behind it belongs to the next tile
@@ -358,8 +372,9 @@ class Gen:
         prologue = []
         for u in [u for u in self.sched if u["fetch"] and u["prev_tile"]]:
             prologue += ["    " + x for x in self.nat_pieces(u, False)]
-        prologue += ["    " + x for x in self.ring_pieces(0, groups)]
-        prologue.append("    GROUP_BEGIN();")
+        for g0 in range(RING_SLOTS - 1):
+            prologue += ["    " + x for x in self.ring_pieces(g0, groups)]
+        prologue.append("    GROUP_BEGIN(0);")
         q0 = []
         keep = self._next_ptrs_emitted
         self._next_ptrs_emitted = True           # (no next-tile pointers in the prologue: the first tile's own)
@@ -367,7 +382,7 @@ class Gen:
         self._next_ptrs_emitted = keep
         prologue += ["    " + x for x in q0]
         st0 = self.steps()[0]
-        prologue.append(f"    a0 = LDA(0);" + (" a1 = LDA(1024);" if st0["nq"] == 2 else ""))
+        prologue.append(f"    a0 = LDA(0);" + (" a1 = LDA(1024);" if st0["nq"] == 2 else ""))      # group 0 sits in slot 0
         if st0["blk"].kind == NATURAL:
             prologue.append(f"    bq = LDB({self.use_of(0, 0)['slot'] * 4096});")
         head_ops = [(oi, op) for oi, op in enumerate(p.ops) if op.thin]

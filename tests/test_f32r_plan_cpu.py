@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import synthetic_inputs as syn
-from mipnerf_pl_amd.mlp_f32r_plan import GROUP_CHUNKS, MAGIC, NSLOT, F32RPlan, emulate_wave, supported
+from mipnerf_pl_amd.mlp_f32r_plan import GROUP_CHUNKS, MAGIC, NSLOT, RING_SLOTS, F32RPlan, emulate_wave, supported
 from mipnerf_pl_amd.mlp_plan import DLAYOUT, NATURAL
 from oracle import mipnerf_oracle as orc
 
@@ -86,7 +86,7 @@ def test_tables_cover_every_parameter_exactly_once(vi):
 def test_ring_groups_and_natural_block_schedule(vi):
     p = F32RPlan.build(VARIANTS[vi])
     groups = p.groups()
-    assert len(groups) % 2 == 0                                        # two ring slots, cyclic over tiles
+    assert len(groups) % RING_SLOTS == 0 and RING_SLOTS == 2           # group g lives in slot g % RING_SLOTS, cyclic over tiles
     assert groups[0][0] == 0 and sum(k for _, k in groups) == p.n_real_chunks
     assert all(c0 + k == groups[i + 1][0] for i, (c0, k) in enumerate(groups[:-1]))
     assert all(k <= GROUP_CHUNKS and k % 4 == 0 for _, k in groups)
