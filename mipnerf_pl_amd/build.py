@@ -90,7 +90,8 @@ def variant_units():
         elif re.fullmatch(r"mlp_bf16_dgrad_gen_v\d+\.hip", f):
             out.append((f, NO_IEEE))
         elif re.fullmatch(r"mlp_f32r_gen_v\d+\.hip", f):              # register-resident fp32 kernels (gen_mlp_f32r.py)
-            out.append((f, NO_IEEE + ["-ffp-contract=off"] + (["-DMLP_F32R_ABLATE=" + os.environ["MLP_F32R_ABLATE"]] if os.environ.get("MLP_F32R_ABLATE") else [])))
+            out.append((f, NO_IEEE + ["-ffp-contract=off"] + (["-DMLP_F32R_ABLATE=" + os.environ["MLP_F32R_ABLATE"]] if os.environ.get("MLP_F32R_ABLATE") else []) +
+                        ["-DMLP_F32R_NAT_NT=" + os.environ.get("MLP_F32R_NAT_NT", "1")]))
     return out
 
 

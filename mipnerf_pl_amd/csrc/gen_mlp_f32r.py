@@ -79,7 +79,13 @@ __device__ __forceinline__ void dma_piece(const char* gbase, unsigned lds_addr, 
         : "memory");
 }
 // One piece of a natural block: every lane brings 16 bytes of ITS sample's row: per-lane 64-bit row address + immediate; M0 is the LDS
-// target minus that immediate.
+// target minus that immediate.  The rows are read once per tile (MLP_F32R_NAT_NT=1: non-temporal, so that hundreds of MB of encodings do
+// not compete with the 2.33-MiB weight stream for the XCD's L2).
+#if defined(MLP_F32R_NAT_NT) && MLP_F32R_NAT_NT
+#define NAT_POLICY " nt"
+#else
+#define NAT_POLICY ""
+#endif
 template <int IMM>
 __device__ __forceinline__ void dma_piece_v(const float* row, unsigned m0_val) {
     unsigned keep;
@@ -87,7 +93,7 @@ __device__ __forceinline__ void dma_piece_v(const float* row, unsigned m0_val) {
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off offset:%3\n\t"
+        "global_load_lds_dwordx4 %1, off offset:%3" NAT_POLICY "\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(row), "s"(m0_val), "n"(IMM)
