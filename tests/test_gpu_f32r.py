@@ -4,7 +4,7 @@ k_mlp_f32 of rounds 1-3 (mipnerf_set_option(ctx, 5, 0)), which every fp32 golden
 * ragged / tiny sample counts: a launch of 1, 31, 33, 127, 129, ... samples (partial 128-sample tiles, partial 32-sample wave tiles,
   fewer tiles than workgroups, many tiles per workgroup) must equal the oracle's MLP (models/mip_nerf.py:75-111) and the other kernel;
 * every architecture variant the kernel is generated for, incl. the 672-wide unbounded-scene encoding (streamed natural blocks);
-* raw outputs and the density noise argument (mip_nerf.py:232-233) take the same route as in k_mlp_f32.
+* the outputs do not depend on how many persistent workgroups share the tiles.
 """
 import numpy as np
 import pytest
@@ -24,7 +24,7 @@ def G():
     return gpu_util
 
 
-def _run(model, enc, venc, resident, dnoise=None):
+def _run(model, enc, venc, resident):
     """mipnerf_mlp_forward in fp32 through the chosen kernel -> (raw [B,N,4], activated [B,N,4])"""
     from mipnerf_pl_amd import _lib as L
     from mipnerf_pl_amd import ops
@@ -36,9 +36,8 @@ def _run(model, enc, venc, resident, dnoise=None):
         v32[:, :venc.shape[-1]] = venc
     act = torch.empty(B, N, 4, device=enc.device)
     raw = torch.empty_like(act)
-    if dnoise is None:
-        L.check(L.lib().mipnerf_mlp_forward(ctx.handle, B * N, N, enc.contiguous().data_ptr(), v32.data_ptr(), L.PREC_FP32, act.data_ptr(),
-                                            raw.data_ptr(), ops._stream()), "mlp_forward")
+    L.check(L.lib().mipnerf_mlp_forward(ctx.handle, B * N, N, enc.contiguous().data_ptr(), v32.data_ptr(), L.PREC_FP32, act.data_ptr(),
+                                        raw.data_ptr(), ops._stream()), "mlp_forward")
     ctx.set_option(5, 1)
     return raw, act
 
