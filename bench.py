@@ -229,16 +229,7 @@ def run_inference(args, e):
     if nl > 0:
         launch_ms = tot_ms / nl
         tflops = FLOP_PER_SAMPLE * M / (launch_ms * 1e-3) / 1e12
-        traffic, tsrc = None, None
-        pmc = os.path.join(REPO, "profiles", "mlp_pmc.json")     # HBM bytes/launch from separate rocprofv3 --pmc passes (scripts/pmc_traffic.sh)
-        if os.path.exists(pmc):
-            pj = json.load(open(pmc))
-            if pj.get("round") != CURRENT_ROUND:
-                tsrc = f"profiles/mlp_pmc.json is from round {pj.get('round')}, this is round {CURRENT_ROUND}: refused (re-run scripts/pmc_traffic.sh)"
-            elif args.precision == "bf16" and pj.get("samples_per_launch") == M:
-                traffic, tsrc = pj.get("hbm_bytes_per_launch"), f"profiles/mlp_pmc.json (rocprofv3 --pmc passes of round {CURRENT_ROUND}, not this run)"
-            elif args.precision == "fp32" and pj.get("samples_per_launch") == M and "k_mlp_f32r" in pj.get("kernels", {}):
-                traffic, tsrc = pj["kernels"]["k_mlp_f32r"]["hbm_bytes_per_launch"], f"profiles/mlp_pmc.json (round {CURRENT_ROUND})"
+        traffic, tsrc = pmc_traffic("inference", args.precision, M)
         roofline = {"bound": "mfma", "kernel": kname, "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(tflops / peak, 4), "traffic": traffic, "traffic_source": tsrc,
                     "launch_ms": round(launch_ms, 4), "launches_timed": nl, "samples_per_launch": M,
@@ -350,15 +341,7 @@ def run_train(args, e):
     per_rank["allreduce_timed"] = ar_n
     peak = PEAK_TFLOPS[args.precision]
     tflops = FLOP_PER_SAMPLE_TRAIN * samples_per_step / (ms * 1e-3) / 1e12
-    traffic, tsrc = None, None
-    pmc = os.path.join(REPO, "profiles", "mlp_pmc.json")   # HBM bytes/step of the three MFMA kernels, separate --pmc passes (scripts/pmc_traffic.sh)
-    if args.precision == "bf16" and native and os.path.exists(pmc) and (B, N) == (4096, 128):
-        with open(pmc) as f:
-            pj = json.load(f)
-        if pj.get("round") != CURRENT_ROUND:
-            tsrc = f"profiles/mlp_pmc.json is from round {pj.get('round')}, this is round {CURRENT_ROUND}: refused"
-        else:
-            traffic, tsrc = pj.get("train_hbm_bytes_per_step"), f"profiles/mlp_pmc.json (rocprofv3 --pmc passes of round {CURRENT_ROUND}, not this run)"
+    traffic, tsrc = pmc_traffic("train", args.precision) if (native and (B, N) == (4096, 128)) else (None, None)
     roofline = {"bound": "mfma", "kernel": "whole step (forward-with-save + dgrad + wgrad MFMA kernels and everything around them)",
                 "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4), "traffic": traffic,
                 "traffic_source": tsrc,
@@ -381,6 +364,29 @@ def run_train(args, e):
                       "lr_schedule": "device" if graphed else "host",
                       "parallelism": f"data-parallel x{e.world}, one {4 * sum(p.numel() for p in model.parameters())} B all-reduce per step"}}
     return rec
+
+
+def pmc_traffic(kind, precision, samples_per_launch=None, path=None):
+    """HBM bytes from profiles/mlp_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scripts/pmc_traffic.sh) for the bench
+    line's roofline.traffic -> (bytes or None, source string or None).  A file written in another round is REFUSED (VERDICT r03 hygiene):
+    the number must come from this round's kernels.  kind: "inference" (bytes per MLP launch) | "train" (bytes per step)."""
+    path = path or os.path.join(REPO, "profiles", "mlp_pmc.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        pj = json.load(f)
+    if pj.get("round") != CURRENT_ROUND:
+        return None, f"profiles/mlp_pmc.json is from round {pj.get('round')}, this is round {CURRENT_ROUND}: refused (re-run scripts/pmc_traffic.sh)"
+    src = f"profiles/mlp_pmc.json (rocprofv3 --pmc passes of round {CURRENT_ROUND}, not this run)"
+    if kind == "train":
+        return (pj.get("train_hbm_bytes_per_step"), src) if precision == "bf16" else (None, None)
+    if pj.get("samples_per_launch") != samples_per_launch:
+        return None, None
+    if precision == "bf16":
+        return pj.get("hbm_bytes_per_launch"), src
+    if "k_mlp_f32r" in pj.get("kernels", {}):
+        return pj["kernels"]["k_mlp_f32r"]["hbm_bytes_per_launch"], src
+    return None, None
 
 
 def measure_one_rank_rccl_allreduce(numel, dev):

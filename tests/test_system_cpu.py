@@ -178,3 +178,37 @@ def test_same_seed_initialisation_equals_reference():
             a = v.numpy().ravel()
             assert np.array_equal(a[:8], g[f"{tag}_head_{k}"]), (tag, k)
             assert float(a.astype(np.float64).sum()) == float(g[f"{tag}_sum_{k}"]), (tag, k)
+
+
+def test_bench_scale_model_and_pmc_round_rule(tmp_path):
+    """bench.py helpers that need no GPU: the stated 1 / 2 / 4 / 8 expectation (VERDICT r03 #5a) and the rule that roofline.traffic only
+    comes from THIS round's PMC passes (VERDICT r03 hygiene)."""
+    import importlib.util
+    import json
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    line = {"ms_per_step": 0.94, "train": {"ms_per_step": 4.2}, "render": {"ms_per_step": 144.0}}
+    sm = bench.scale_model(line, 0.03, 4 * 612740)
+    assert sm["predicted"]["1"] == {"train_ms_per_step": 4.2, "train_allreduce_ms": 0.0, "train_weak_efficiency": 1.0, "render_ms_per_frame": 144.0,
+                                    "render_strong_efficiency": 1.0, "inference_weak_efficiency": 1.0}
+    # ring all-reduce of 2.45 MB over 153 GB/s links + 3 us per hop + the measured launch: 8 GPUs = 30 + 28 + 42 us
+    assert abs(sm["predicted"]["8"]["train_allreduce_ms"] - (0.03 + 2 * 7 / 8 * 2450960 / 153e9 * 1e3 + 14 * 3e-3)) < 1e-3
+    assert sm["predicted"]["2"]["train_allreduce_ms"] < sm["predicted"]["4"]["train_allreduce_ms"] < sm["predicted"]["8"]["train_allreduce_ms"]
+    assert 0.97 < sm["predicted"]["8"]["train_weak_efficiency"] < 1 and 0.99 < sm["predicted"]["8"]["render_strong_efficiency"] < 1
+    assert bench.scale_model(line, {"error": "no rccl"}, 4 * 612740)["measured_inputs"]["allreduce_1rank_error"] == "no rccl"
+    # PMC file of another round: refused, with the reason in the source string
+    p = tmp_path / "mlp_pmc.json"
+    p.write_text(json.dumps({"round": bench.CURRENT_ROUND - 1, "samples_per_launch": 524288, "hbm_bytes_per_launch": 1, "train_hbm_bytes_per_step": 2}))
+    t, src = bench.pmc_traffic("inference", "bf16", 524288, path=str(p))
+    assert t is None and "refused" in src
+    p.write_text(json.dumps({"round": bench.CURRENT_ROUND, "samples_per_launch": 524288, "hbm_bytes_per_launch": 11, "train_hbm_bytes_per_step": 22,
+                             "kernels": {"k_mlp_f32r": {"hbm_bytes_per_launch": 33}}}))
+    assert bench.pmc_traffic("inference", "bf16", 524288, path=str(p))[0] == 11
+    assert bench.pmc_traffic("inference", "fp32", 524288, path=str(p))[0] == 33
+    assert bench.pmc_traffic("inference", "bf16", 1000, path=str(p)) == (None, None)
+    assert bench.pmc_traffic("train", "bf16", path=str(p))[0] == 22
+    # the committed file is this round's
+    t, src = bench.pmc_traffic("inference", "bf16", 524288)
+    assert t and t > 12124160 and "round" in src
