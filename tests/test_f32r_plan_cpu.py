@@ -125,3 +125,95 @@ def test_blob_header():
     # the VALU, the view encoding's 27 -> 32 zero padding adds 5 x 128 = 640 to the view layer
     mfmas = sum(len(op.tiles) * op.nk for op in p.ops)
     assert mfmas == 9536 and mfmas * 2048 // 32 == 610304
+
+
+# ---- replay of the GENERATED tile body (no GPU): register hazards, accumulator images, LDS-DMA bookkeeping ------------------------
+import re  # noqa: E402
+
+sys.path.insert(0, os.path.join(REPO, "mipnerf_pl_amd", "csrc"))
+import gen_mlp_f32r as gen  # noqa: E402
+
+
+def _tile_body(vi):
+    g = gen.Gen(F32RPlan.build(VARIANTS[vi]), vi)
+    src = g.source()
+    body = src[src.index("// ---- generated tile body ----"):src.index("// ---- thin heads:")]
+    prologue = src[src.index("// prologue:"):src.index("for (; tile < ntiles;")]
+    return g, body.splitlines(), prologue.splitlines()
+
+
+@pytest.mark.parametrize("vi", SUPPORTED)
+def test_generated_body_replays_without_hazards(vi):
+    """Walk the generated statements in program order, as one wave executes them:
+    * every MFMA accumulates into its op's output set, with the A fragment register its k-step's chunk was read into and the B register
+      its k-step's operand was written to; every chunk of the stream is read exactly once per tile, from the ring slot its group lives in;
+    * a register of a D tile is read as B operand only AFTER the last MFMA of the op that produced it, and an accumulator image (BIAS)
+      overwrites a tile only after its last read and before the first MFMA of the op that accumulates into it next;
+    * between two ring barriers exactly the LDS-DMA pieces of one ring group (+ 4 per natural block fetched) are issued, every piece
+      behind the barrier that frees its slot."""
+    g, lines, prologue = _tile_body(vi)
+    p = g.p
+    groups = p.groups()
+    NG = len(groups)
+    cur_op, op_of_name = None, {op.name: (oi, op) for oi, op in enumerate(p.ops)}
+    last_mfma_into = {}          # (set, tile) -> line number of the last MFMA writing it (current value)
+    value_op = {}                # (set, tile) -> op index that produced / is producing the value
+    last_read = {}               # (set, tile) -> line number of the last B-operand read
+    reads_lda = []
+    breg_src = {}                # b0 / b1 -> ("reg", set, tile, r) | ("nat",)
+    n_mfma = 0
+    dma_ring, dma_nat, begins = 0, 0, 0
+    per_interval = []
+    for ln, s_ in enumerate(lines):
+        s_ = s_.strip()
+        m = re.match(r"// (\w+) k-step (\d+) ", s_)
+        if m:
+            cur_op = op_of_name[m.group(1)]
+            continue
+        if s_.startswith("GROUP_BEGIN("):
+            per_interval.append([0, 0])
+            begins += 1
+        for m in re.finditer(r"LDA\((\d+)\)", s_):
+            reads_lda.append(int(m.group(1)))
+        for m in re.finditer(r"(b[01]) = (relu1\()?([XY])\[(\d+)\]\[(\d+)\]", s_):
+            key = (m.group(3), int(m.group(4)))
+            # the value must be complete: produced by an EARLIER op than the one that reads it
+            assert key in value_op and value_op[key] < cur_op[0], (ln, s_)
+            assert bool(m.group(2)) == p.ops[value_op[key]].relu, (ln, s_)
+            last_read[key] = ln
+            breg_src[m.group(1)] = ("reg",) + key
+        for m in re.finditer(r"(b[01]) = bq\[", s_):
+            breg_src[m.group(1)] = ("nat",)
+        m = re.match(r"BIAS\(([XY])\[(\d+)\], (\d+)\);", s_)
+        if m:
+            key = (m.group(1), int(m.group(2)))
+            # nothing may still need the old value: every reader of it lies behind us
+            assert last_read.get(key, -1) < ln
+            value_op[key] = "bias"
+            last_mfma_into[key] = None
+        m = re.match(r"MFMA\(([XY])\[(\d+)\], a([01])\[(\d)\], (b[01])\);", s_)
+        if m:
+            n_mfma += 1
+            oi, op = cur_op
+            key = (m.group(1), int(m.group(2)))
+            assert m.group(1) == op.out and int(m.group(2)) == 4 * int(m.group(3)) + int(m.group(4))
+            if value_op.get(key) != oi:
+                assert value_op.get(key) == "bias", ("first MFMA of an op into a tile that holds no accumulator image", ln, s_)
+                value_op[key] = oi
+            last_mfma_into[key] = ln
+        if "dma_piece<" in s_:
+            dma_ring += 1
+            per_interval[-1][0] += 1
+        if "dma_piece_v<" in s_:
+            dma_nat += 1
+            per_interval[-1][1] += 1
+    assert n_mfma == sum(len(op.tiles) * op.nk for op in p.ops)
+    assert begins == NG
+    # every chunk of the stream read exactly once per tile (offsets inside a slot), the first k-step's by the prologue / the previous tile
+    want = []
+    for gi, (c0, k) in enumerate(groups):
+        want += [(gi % RING_SLOTS) * GROUP_CHUNKS * 1024 + i * 1024 for i in range(k)]
+    assert sorted(reads_lda) == sorted(want)
+    # LDS-DMA bookkeeping: one ring group per barrier interval (cyclically), four pieces per natural block fetched
+    assert dma_ring == sum(k // 4 for _, k in groups) and dma_nat == 4 * sum(u["fetch"] for u in p.natural_schedule())
+    assert any("GROUP_BEGIN(0);" in x for x in prologue)
