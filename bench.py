@@ -23,6 +23,7 @@ rank 0, N=1 only (the numpy port when nothing is staged).
 """
 import argparse
 import json
+import math
 import os
 import socket
 import sys
@@ -597,6 +598,33 @@ def run_fp32_c4(args, e):
         unb = {"ms_per_step": round(udt / steps * 1e3, 4), "value": round(B * N * 2 * e.world * steps / udt, 1), "launch_ms": round(ulaunch, 4),
                "flop_per_sample": flop_u, "achieved": round(utf, 2), "frac": round(utf / peak, 4), "finite": bool(torch.isfinite(uout[-1][0]).all()),
                "model": "MipNerf(unbounded=True): 672-wide encoding, fp32 only"}
+        # ... and in bf16 (round 4: k_pre_gemm + trunk kernel, csrc/gen_pre_gemm.py): same rays, same weights, agreement with the fp32 frame
+        try:
+            bm = MipNerf(num_samples=N, precision="bf16", unbounded=True)
+            bm.load_state_dict(um.state_dict())
+            bm = bm.to(e.dev)
+
+            def bstep():
+                with torch.no_grad():
+                    return bm(R, False, True)
+            bstep()
+            bctx = bm.mlp.native(e.dev)
+            bstep()
+            bctx.set_option(2, 1)
+            bsteps = max(5, args.steps // 4)
+            bdt, bout = timed(e, bstep, 0, bsteps)
+            btot, bnl = launch_stats(bctx)
+            bctx.set_option(2, 0)
+            blaunch = btot / max(bnl, 1)
+            btf = flop_u * M / (blaunch * 1e-3) / 1e12
+            mse = float(torch.mean((bout[-1][0] - uout[-1][0]) ** 2))
+            unb["bf16"] = {"ms_per_step": round(bdt / bsteps * 1e3, 4), "value": round(B * N * 2 * e.world * bsteps / bdt, 1), "steps": bsteps,
+                           "mlp_ms_per_level": round(blaunch, 4), "achieved": round(btf, 2), "peak": PEAK_TFLOPS["bf16"],
+                           "frac": round(btf / PEAK_TFLOPS["bf16"], 4), "kernels": "k_pre_gemm + k_mlp_bf16 (trunk), timed together per level",
+                           "psnr_vs_fp32_frame_db": round(float(-10 * math.log10(max(mse, 1e-20))), 2),
+                           "finite": bool(torch.isfinite(bout[-1][0]).all())}
+        except Exception as ex:  # noqa: BLE001
+            unb["bf16"] = {"error": f"{type(ex).__name__}: {ex}"}
     except Exception as ex:  # noqa: BLE001  (an extra must not take the record down)
         unb = {"error": f"{type(ex).__name__}: {ex}"}
     return {"unbounded": unb, "value": round(B * N * 2 * e.world * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warm,

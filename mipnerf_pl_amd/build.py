@@ -73,11 +73,13 @@ def generate() -> None:
     variants that no longer exist are removed first, so adding / removing a shape is an edit of VARIANTS and a rebuild."""
     import re
     for f in os.listdir(CSRC):
-        if re.fullmatch(r"(mlp_bf16(_trainfwd|_dgrad)?_gen_v\d+\.(hip|o)|_gen_train_tables(_v\d+)?\.bin|mlp_f32r_gen_v\d+\.(hip|o)|_gen_f32r_tables_v\d+\.bin)", f):
+        if re.fullmatch(r"(mlp_bf16(_trainfwd|_dgrad)?_gen_v\d+\.(hip|o)|_gen_train_tables(_v\d+)?\.bin|mlp_f32r_gen_v\d+\.(hip|o)|_gen_f32r_tables_v\d+\.bin|"
+                        r"pre_gemm_gen_v\d+\.(hip|o)|mlp_bf16_pre_gen_v\d+\.(hip|o)|_gen_pre_tables_v\d+\.bin)", f):
             os.remove(os.path.join(CSRC, f))
     subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_mlp_bf16.py"), CSRC])
     subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_mlp_train.py"), CSRC])
     subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_mlp_f32r.py"), CSRC])
+    subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_pre_gemm.py"), CSRC])
 
 
 def variant_units():
@@ -86,6 +88,8 @@ def variant_units():
     out = []
     for f in sorted(os.listdir(CSRC)):
         if re.fullmatch(r"mlp_bf16_gen_v\d+\.hip", f) or re.fullmatch(r"mlp_bf16_trainfwd_gen_v\d+\.hip", f):
+            out.append((f, NO_IEEE + ["-ffp-contract=off"]))
+        elif re.fullmatch(r"(pre_gemm_gen|mlp_bf16_pre_gen)_v\d+\.hip", f):      # two-kernel bf16 form of wide encodings (gen_pre_gemm.py)
             out.append((f, NO_IEEE + ["-ffp-contract=off"]))
         elif re.fullmatch(r"mlp_bf16_dgrad_gen_v\d+\.hip", f):
             out.append((f, NO_IEEE))
@@ -112,6 +116,10 @@ def tables_object() -> str:
             sfx = name[len("_gen_f32r_tables"):-len(".bin")]
             f.write('__asm__(".section .rodata\\n.global mip_f32r_tables%s\\n.balign 16\\n'
                     'mip_f32r_tables%s:\\n.incbin \\"%s\\"\\n.previous\\n");\n' % (sfx, sfx, os.path.join(CSRC, name)))
+        for name in sorted(n for n in os.listdir(CSRC) if re.fullmatch(r"_gen_pre_tables_v\d+\.bin", n)):
+            sfx = name[len("_gen_pre_tables"):-len(".bin")]
+            f.write('__asm__(".section .rodata\\n.global mip_pre_tables%s\\n.balign 16\\n'
+                    'mip_pre_tables%s:\\n.incbin \\"%s\\"\\n.previous\\n");\n' % (sfx, sfx, os.path.join(CSRC, name)))
     subprocess.check_call(["gcc", "-c", "-fPIC", src, "-o", obj])
     return obj
 

@@ -14,6 +14,7 @@
 #include "mlp_variants_gen.hpp"
 #include "mlp_train_variants_gen.hpp"
 #include "mlp_f32r_variants_gen.hpp"
+#include "mlp_pre_variants_gen.hpp"
 #include "mlp_plan_gen.hpp"
 
 // binary tables of the training kernels (mlp_train_plan.TrainPlan.blob()), linked in through train_tables.c (.incbin)
@@ -227,6 +228,26 @@ bool f32r_tables(F32RTables& T, int variant, int nparams) {
     return true;
 }
 
+// ---- two-kernel bf16 form of wide encodings: blob produced by mlp_pre_plan.PrePlan.blob(), linked in by train_tables.c ------
+struct PreTables {
+    int n_gemm_chunks = 0, n_gemm_bias = 0, n_trunk_chunks = 0, n_trunk_tiles = 0, nk = 0;
+    const int32_t* gemm_pack = nullptr;    // [n_gemm_chunks * 512] flat parameter index or -1
+    const int32_t* gemm_bias = nullptr;    // [n_gemm_bias]
+    const int32_t* trunk_pack = nullptr;   // [n_trunk_chunks * 512]
+    const int32_t* trunk_bias = nullptr;   // [n_trunk_tiles * 32]
+};
+bool pre_tables(PreTables& T, int variant, int nparams) {
+    if (variant < 0 || variant >= mip::plan::kNumVariants || !mip::kPreTableBlobs[variant]) return false;
+    const int32_t* h = reinterpret_cast<const int32_t*>(mip::kPreTableBlobs[variant]);
+    if (h[0] != 0x50524731 || h[7] != nparams || h[1] != h[2]) return false;
+    T.n_gemm_chunks = h[1]; T.n_gemm_bias = h[3]; T.n_trunk_chunks = h[4]; T.n_trunk_tiles = h[6]; T.nk = h[8];
+    T.gemm_pack = h + 16;
+    T.gemm_bias = T.gemm_pack + (size_t)h[1] * 512;
+    T.trunk_pack = T.gemm_bias + h[3];
+    T.trunk_bias = T.trunk_pack + (size_t)h[4] * 512;
+    return true;
+}
+
 }  // namespace
 
 struct mipnerf_ctx {
@@ -246,6 +267,16 @@ struct mipnerf_ctx {
     float* d_stream_f32r = nullptr;
     float* d_aux_f32r = nullptr;
     int f32_resident = 1;            // option 5: 1 = k_mlp_f32r where generated (inference), 0 = the LDS-resident k_mlp_f32
+    // two-kernel bf16 inference of the variants whose encoding does not fit k_mlp_bf16's wave-private LDS area (gen_pre_gemm.py):
+    // k_pre_gemm's weight stream + accumulator images, the trunk kernel's stream + bias table, and scratch for the per-stage entry point
+    PreTables pre;
+    int32_t* d_pre_idx[4] = {nullptr, nullptr, nullptr, nullptr};     // index tables: gemm pack, gemm bias, trunk pack, trunk bias
+    void* d_pre_gemm_stream = nullptr;
+    float* d_pre_gemm_bias = nullptr;
+    void* d_pre_trunk_stream = nullptr;
+    float* d_pre_trunk_bias = nullptr;
+    void* d_pre_scratch = nullptr;   // pre_x | pre_acc of mipnerf_mlp_forward (mipnerf_forward carves them out of the caller's workspace)
+    size_t pre_scratch_bytes = 0;
     // training (bf16): W^T stream of the dgrad kernel, wgrad job tables
     TrainTables tt;
     int32_t* d_pack_dgrad = nullptr;
@@ -284,7 +315,19 @@ hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* view
 
 // ... and its training kernels (variants whose row of the generated kLaunchTrainFwd table is not null)
 static inline bool has_bf16_train(const PlanDesc* P) { return mip::kLaunchTrainFwd[P->variant] != nullptr; }
-static inline bool has_bf16(const PlanDesc* P) { return mip::kLaunchBf16[P->variant] != nullptr; }
+static inline bool has_bf16_pre(const PlanDesc* P) { return mip::kLaunchPreGemm[P->variant] != nullptr; }      // the two-kernel form
+static inline bool has_bf16(const PlanDesc* P) { return mip::kLaunchBf16[P->variant] != nullptr || has_bf16_pre(P); }
+// bytes of k_pre_gemm's two outputs for M samples: 16 KiB (X fragments) + 32 KiB (accumulator images) per wave tile, whole 256-sample tiles
+static inline size_t pre_x_bytes(int64_t M) { return (size_t)((M + 255) / 256) * 8 * 16384; }
+static inline size_t pre_acc_bytes(int64_t M) { return (size_t)((M + 255) / 256) * 8 * 32768; }
+// k_pre_gemm + the trunk kernel.  enc: bf16, row-major [M, xyz_dim] (frag = 0) or the fragment layout launch_cast_ipe_360 writes
+hipError_t launch_bf16_pre(mipnerf_ctx* c, const void* enc, int frag, const void* viewenc, float* rgb_sigma, float* raw, int64_t M, int N,
+                           void* pre_x, void* pre_acc, const float* dnoise, hipStream_t st) {
+    hipError_t er = mip::kLaunchPreGemm[c->P->variant](c->d_pre_gemm_stream, c->d_pre_gemm_bias, enc, frag, pre_x, pre_acc, M, c->grid_limit, st);
+    if (er != hipSuccess) return er;
+    return mip::kLaunchBf16Pre[c->P->variant](c->d_pre_trunk_stream, c->d_pre_trunk_bias, pre_x, pre_acc, viewenc, rgb_sigma, raw, M, N,
+                                              c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, dnoise, c->cfg.density_noise, st);
+}
 hipError_t launch_trainfwd_variant(mipnerf_ctx* c, const void* enc, const void* viewenc, float* rgb_sigma, float* raw, void* act,
                                    void* masks, int64_t M, int N, const mip::RayInputs* rays, const float* dnoise, hipStream_t st) {
     const mip::LaunchTrainFwdFn fn = mip::kLaunchTrainFwd[c->P->variant];
@@ -387,7 +430,7 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
             char b[160];
             snprintf(b, sizeof b, "%s[depth %d width %d cond %dx%d skip %d xyz %d (%d per degree) view %d viewdirs %d%s]", v ? ", " : "", kPlans[v].net_depth,
                      kPlans[v].net_width, kPlans[v].net_depth_cond, kPlans[v].net_width_cond, kPlans[v].skip_index, kPlans[v].xyz_dim,
-                     kPlans[v].feat_per_deg, kPlans[v].view_dim, kPlans[v].use_viewdirs, mip::kLaunchBf16[v] ? "" : ", fp32 only");
+                     kPlans[v].feat_per_deg, kPlans[v].view_dim, kPlans[v].use_viewdirs, has_bf16(&kPlans[v]) ? "" : ", fp32 only");
             have += b;
         }
         return fail(MIPNERF_E_UNSUPPORTED, "no kernels / tables were generated for this MLP shape; generated: %s.  Add the shape to "
@@ -439,6 +482,28 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         if (er != hipSuccess) {
             mipnerf_destroy(c);
             return fail(MIPNERF_E_HIP, "mipnerf_create (fp32 register-resident tables): %s", hipGetErrorString(er));
+        }
+    }
+    if (has_bf16_pre(P)) {
+        if (!pre_tables(c->pre, P->variant, off_total(c->tab))) {
+            mipnerf_destroy(c);
+            return fail(MIPNERF_E_INVALID, "mipnerf_create: embedded tables of the two-kernel bf16 form are inconsistent with the compiled plan");
+        }
+        const PreTables& pt = c->pre;
+        const int32_t* src[4] = {pt.gemm_pack, pt.gemm_bias, pt.trunk_pack, pt.trunk_bias};
+        const size_t cnt[4] = {(size_t)pt.n_gemm_chunks * 512, (size_t)pt.n_gemm_bias, (size_t)pt.n_trunk_chunks * 512, (size_t)pt.n_trunk_tiles * 32};
+        for (int i = 0; i < 4; ++i) {
+            const std::vector<int32_t> enc_i = encode(std::vector<int32_t>(src[i], src[i] + cnt[i]), c->tab.tensor_off);
+            chk(hipMalloc(&c->d_pre_idx[i], cnt[i] * 4));
+            if (er == hipSuccess) chk(hipMemcpy(c->d_pre_idx[i], enc_i.data(), cnt[i] * 4, hipMemcpyHostToDevice));
+        }
+        chk(hipMalloc(&c->d_pre_gemm_stream, cnt[0] * 2));
+        chk(hipMalloc(&c->d_pre_gemm_bias, cnt[1] * 4));
+        chk(hipMalloc(&c->d_pre_trunk_stream, cnt[2] * 2));
+        chk(hipMalloc(&c->d_pre_trunk_bias, cnt[3] * 4));
+        if (er != hipSuccess) {
+            mipnerf_destroy(c);
+            return fail(MIPNERF_E_HIP, "mipnerf_create (tables of the two-kernel bf16 form): %s", hipGetErrorString(er));
         }
     }
     int dev = 0, cus = 0;
@@ -493,6 +558,9 @@ int mipnerf_destroy(mipnerf_ctx* c) {
     (void)hipFree(c->d_wgtab); (void)hipFree(c->d_jobslots); (void)hipFree(c->d_scratch); (void)hipFree(c->d_extra_wT);
     (void)hipFree(c->d_pack_extraT);
     (void)hipFree(c->d_pack_f32r); (void)hipFree(c->d_aux_idx_f32r); (void)hipFree(c->d_stream_f32r); (void)hipFree(c->d_aux_f32r);
+    for (int i = 0; i < 4; ++i) (void)hipFree(c->d_pre_idx[i]);
+    (void)hipFree(c->d_pre_gemm_stream); (void)hipFree(c->d_pre_gemm_bias); (void)hipFree(c->d_pre_trunk_stream); (void)hipFree(c->d_pre_trunk_bias);
+    (void)hipFree(c->d_pre_scratch);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
     return MIPNERF_OK;
@@ -543,6 +611,13 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
         add(c->d_pack_f32r, (int64_t)c->f32r.n_chunks * 256, c->d_stream_f32r, false);
         add(c->d_aux_idx_f32r, (int64_t)c->f32r.n_aux, c->d_aux_f32r, false);
     }
+    if (c->d_pre_gemm_stream) {
+        add(c->d_pre_idx[0], (int64_t)c->pre.n_gemm_chunks * 512, c->d_pre_gemm_stream, true);
+        add(c->d_pre_idx[1], (int64_t)c->pre.n_gemm_bias, c->d_pre_gemm_bias, false);
+        add(c->d_pre_idx[2], (int64_t)c->pre.n_trunk_chunks * 512, c->d_pre_trunk_stream, true);
+        add(c->d_pre_idx[3], (int64_t)c->pre.n_trunk_tiles * 32, c->d_pre_trunk_bias, false);
+    }
+    if (sg.n > mip::kMaxPackSegments) return fail(MIPNERF_E_INVALID, "set_params: %d pack segments, the library handles %d", sg.n, mip::kMaxPackSegments);
     HIP_TRY(mip::launch_pack_multi(sg, pp, S(stream)));
     c->pp = pp;
     c->params_set = true;
@@ -603,6 +678,20 @@ static int mlp_forward_noise(mipnerf_ctx* c, int64_t M, int32_t N, const void* e
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward: mipnerf_set_params has not been called");
     if (precision == MIPNERF_PREC_BF16) {
         if (!has_bf16(c->P)) return fail(MIPNERF_E_UNSUPPORTED, "this architecture variant (xyz_dim %d) has fp32 kernels only", c->P->xyz_dim);
+        if (has_bf16_pre(c->P)) {
+            // the two-kernel form needs 1.5 KiB of scratch per sample between its kernels; this per-stage entry point has no workspace
+            // argument, so the context keeps a buffer that grows on demand (hipMalloc: not capturable -- mipnerf_forward uses the caller's)
+            const size_t need = pre_x_bytes(M) + pre_acc_bytes(M);
+            if (need > c->pre_scratch_bytes) {
+                HIP_TRY(hipStreamSynchronize(S(stream)));
+                (void)hipFree(c->d_pre_scratch);
+                c->d_pre_scratch = nullptr; c->pre_scratch_bytes = 0;
+                HIP_TRY(hipMalloc(&c->d_pre_scratch, need));
+                c->pre_scratch_bytes = need;
+            }
+            HIP_TRY(launch_bf16_pre(c, enc, 0, viewenc, rgb_sigma, raw, M, N, c->d_pre_scratch, (char*)c->d_pre_scratch + pre_x_bytes(M), dnoise, S(stream)));
+            return MIPNERF_OK;
+        }
         HIP_TRY(launch_bf16_variant(c, enc, viewenc, rgb_sigma, raw, M, N, c->mlp_dma != 0, nullptr, dnoise, S(stream)));
     } else if (precision == MIPNERF_PREC_FP32 && c->f32_resident && c->d_stream_f32r) {
         // register-resident kernel (generated per variant, gen_mlp_f32r.py): activations in registers, weights through an LDS ring
@@ -1210,11 +1299,18 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
 }
 
 // ---- the level loop ---------------------------------------------------------------------------------
+// encoding buffer of one level: [M, xyz_dim] fp32 (or bf16), or -- two-kernel bf16 form -- bf16 fragments of whole 256-sample tiles
+static size_t enc_region_bytes(const mipnerf_ctx* c, size_t M) {
+    const size_t rowmajor = M * c->P->xyz_dim * 4;
+    const size_t frag = has_bf16_pre(c->P) ? ((M + 255) / 256) * 256 * (size_t)c->P->xyz_dim * 2 : 0;
+    return rowmajor > frag ? rowmajor : frag;
+}
 size_t mipnerf_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
     if (!c || B < 1) return 0;
     const size_t M = (size_t)B * (size_t)c->cfg.num_samples;
-    return align256(M * c->P->xyz_dim * 4) + align256((size_t)B * 32 * 4) + align256(M * 16) + 256 +
-           (c->cfg.unbounded ? 2 * align256((size_t)B * (c->cfg.num_samples + 1) * 4) : 0);       // inverse-depth fence posts of two levels
+    return align256(enc_region_bytes(c, M)) + align256((size_t)B * 32 * 4) + align256(M * 16) + 256 +
+           (c->cfg.unbounded ? 2 * align256((size_t)B * (c->cfg.num_samples + 1) * 4) : 0) +       // inverse-depth fence posts of two levels
+           (has_bf16_pre(c->P) ? align256(pre_x_bytes((int64_t)M)) + align256(pre_acc_bytes((int64_t)M)) : 0);   // between k_pre_gemm and the trunk kernel
 }
 
 int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* t_rand, const float* u_rand,
@@ -1236,16 +1332,20 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
     const size_t M = (size_t)B * N;
     char* ws = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
     void* enc = ws;
-    void* viewenc = ws + align256(M * c->P->xyz_dim * 4);
-    float* rgb_sigma = reinterpret_cast<float*>(ws + align256(M * c->P->xyz_dim * 4) + align256((size_t)B * 32 * 4));
+    const size_t enc_b = align256(enc_region_bytes(c, M));
+    void* viewenc = ws + enc_b;
+    float* rgb_sigma = reinterpret_cast<float*>(ws + enc_b + align256((size_t)B * 32 * 4));
     float* t_inv[2] = {nullptr, nullptr};
+    char* ws_tail = reinterpret_cast<char*>(rgb_sigma) + align256(M * 16);
     if (cfg.unbounded) {
-        if (precision != MIPNERF_PREC_FP32)
-            return fail(MIPNERF_E_UNSUPPORTED, "the unbounded-scene path runs in fp32 precision (its 42-features-per-degree encoding has no bf16 kernels)");
-        char* q = reinterpret_cast<char*>(rgb_sigma) + align256(M * 16);
-        t_inv[0] = reinterpret_cast<float*>(q);
-        t_inv[1] = reinterpret_cast<float*>(q + align256((size_t)B * (N + 1) * 4));
+        t_inv[0] = reinterpret_cast<float*>(ws_tail);
+        t_inv[1] = reinterpret_cast<float*>(ws_tail + align256((size_t)B * (N + 1) * 4));
+        ws_tail += 2 * align256((size_t)B * (N + 1) * 4);
     }
+    // bf16 on a variant whose encoding is too wide for k_mlp_bf16 (the unbounded-scene model): k_pre_gemm + trunk kernel (gen_pre_gemm.py)
+    const bool pre_form = precision == MIPNERF_PREC_BF16 && has_bf16_pre(c->P);
+    void* pre_x = pre_form ? ws_tail : nullptr;
+    void* pre_acc = pre_form ? ws_tail + align256(pre_x_bytes((int64_t)M)) : nullptr;
     const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
     const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
     int rc;
@@ -1281,7 +1381,7 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
                 HIP_TRY(mip::launch_reciprocal((int64_t)B * (N + 1), t_inv[lvl], o.t_samples, S(stream)));
             }
             HIP_TRY(mip::launch_cast_ipe_360(B, N, cfg.min_deg_point, cfg.max_deg_point, 1, o.t_samples, rays->origins, rays->directions,
-                                             rays->radii, enc, false, nullptr, nullptr, S(stream)));
+                                             rays->radii, enc, pre_form, nullptr, nullptr, S(stream), pre_form));
         } else if (lvl == 0) {
             if (!have_t0 && (rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, o.t_samples, stream))) return rc;
         } else if (!have_resampled) {
@@ -1306,6 +1406,8 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
             const mip::RayInputs ri = {o.t_samples, rays->origins, rays->directions, rays->radii, cfg.min_deg_point,
                                        cfg.disable_integration};
             HIP_TRY(launch_bf16_variant(c, nullptr, viewenc, rgb_sigma, nullptr, (int64_t)M, N, true, &ri, dnoise, S(stream)));
+        } else if (pre_form) {
+            HIP_TRY(launch_bf16_pre(c, enc, 1, viewenc, rgb_sigma, nullptr, (int64_t)M, N, pre_x, pre_acc, dnoise, S(stream)));
         } else if ((rc = mlp_forward_noise(c, (int64_t)M, N, enc, viewenc, precision, rgb_sigma, nullptr, dnoise, stream))) {
             return rc;
         }

@@ -139,6 +139,7 @@ def build_schedule(plan: Plan):
     slot c: MFMA of chunk c with accumulator `acc` and B operand `b`; b is either a literal
     register ('reg', 'X[3]') or ('lds', byte offset in the wave-private area)."""
     a = plan.arch
+    nenc_lds = 0 if plan.pre_gemm else a.xyz_dim // 16
     panels, slots = [], []
     for op in plan.ops:
         for (t0, t1) in plan.panels(op):
@@ -152,7 +153,7 @@ def build_schedule(plan: Plan):
                     return ("reg", f"{seg.regset}[{seg.reg0 + ksl}]")
                 if seg.regset == "enc":
                     return ("lds", ksl * 1024)
-                return ("lds", (a.xyz_dim // 16) * 1024 + ksl * 1024)   # view: after the encoding k-steps
+                return ("lds", nenc_lds * 1024 + ksl * 1024)   # view: after the encoding k-steps
             if CHAIN:
                 for w in range(spk):
                     for ks in range(op.nk):
@@ -174,7 +175,7 @@ def _check_hazards(plan, panels, slots, b_expr, side):
     last by the previous op that writes activation registers at all (same discipline as gen_mlp_train.check_hazards).  Without
     this, a view layer or trunk narrower than two panels generated a kernel whose consumer read the registers before the
     producer's epilogue had written them (found with an ad-hoc 8 x 192 / 64 shape: bf16 rgb off by 0.2, fp32 fine)."""
-    last = {}
+    last = {f"X[{k}]": -1 for k in range(16)} if plan.pre_gemm else {}     # trunk plans: X arrives preloaded ("op -1")
     for c, sl in enumerate(slots):
         b = b_expr[c]
         if b and b[0] in "XY":
@@ -211,6 +212,11 @@ def epilogue_pieces(plan, pn):
 
 def bias_pieces(plan, pn):
     op, pair = pn["op"], pn["pair"]
+    if op.pre:      # accumulator images written by k_pre_gemm (gen_pre_gemm.py): 4 KiB per tile and wave, four lane-linear 1-KiB loads
+        out = [f"pre_load(acc{pair}0, pre_lane + {pn['t0'] * 4096});"]
+        if pn["t1"] is not None:
+            out.append(f"pre_load(acc{pair}1, pre_lane + {pn['t1'] * 4096});")
+        return out
     out = [f"BIAS(acc{pair}0, {op.first_tile + pn['t0']});"]
     if pn["t1"] is not None:
         out.append(f"BIAS(acc{pair}1, {op.first_tile + pn['t1']});")
@@ -241,6 +247,17 @@ __device__ __forceinline__ void epilogue_half(const f32x16& acc, bf16x8& o) {
     for (int r = 0; r < 8; ++r) {
         const float v = RELU ? relu1(acc[R0 + r]) : acc[R0 + r];
         o[r] = (__bf16)v;
+    }
+}
+
+// Trunk kernels of the two-kernel form (mlp_pre_plan.py): one accumulator tile as k_pre_gemm stored it -- registers 4q .. 4q+3 of every
+// lane form one lane-linear 1-KiB row, four rows per tile.
+typedef __attribute__((ext_vector_type(4))) float f32x4_;
+__device__ __forceinline__ void pre_load(f32x16& acc, const char* p) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4_ v = *reinterpret_cast<const f32x4_*>(p + q * 1024);
+        acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
     }
 }
 
@@ -420,13 +437,14 @@ def _shadow_fits(plan: Plan) -> bool:
 
 
 def gen_kernel(plan: Plan, variant: int = 0) -> str:
-    sfx = "" if variant == 0 else f"_v{variant}"
+    pre = plan.pre_gemm        # trunk of the two-kernel form (mlp_pre_plan.py): X preloaded, skip-layer accumulators from k_pre_gemm
+    sfx = f"_pre_v{variant}" if pre else ("" if variant == 0 else f"_v{variant}")
     nchunks = len(plan.chunks)
     assert nchunks % GROUP == 0, "stream must be a whole number of ring groups"
     ngroups = nchunks // GROUP
     assert ngroups % SLOTS == 0, "tile-to-tile ring phase must be stable"
     a = plan.arch
-    nenc = a.xyz_dim // 16
+    nenc = 0 if pre else a.xyz_dim // 16
     assert (nenc + 2) * 1024 <= ENC_WAVE_BYTES
     nbias_bytes = plan.n_tiles * 128
     ring_bytes = SLOTS * GROUP * CHUNK_BYTES
@@ -435,7 +453,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     assert lds_bytes <= 160 * 1024
     panels, slots = build_schedule(plan)
     nreal = len(slots)
-    assert nreal == plan.n_real_chunks and nchunks - nreal < GROUP, "padding must stay inside the last ring group"
+    # padding: inside the last ring group, or (trunk plans) exactly one whole group of zeros, begun by an extra GROUP_BEGIN at the tile end
+    assert nreal == plan.n_real_chunks and (nchunks - nreal < GROUP or (pre and nchunks - nreal == GROUP and nreal % GROUP == 0))
     lines = []
     e = lines.append
     e("// AUTO-GENERATED by gen_mlp_bf16.py from mlp_plan.py -- do not edit by hand.")
@@ -448,8 +467,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     if variant:
         a_ = plan.arch
         e(f"// architecture variant {variant}: depth {a_.net_depth} width {a_.net_width} cond {a_.net_depth_condition}x{a_.net_width_condition} "
-          f"use_viewdirs={int(a_.use_viewdirs)}")
-        e(f"namespace v{variant} {{")
+          f"use_viewdirs={int(a_.use_viewdirs)}" + (" -- TRUNK of the two-kernel form (layers 1.., mlp_pre_plan.py)" if pre else ""))
+        e(f"namespace v{variant}{'pre' if pre else ''} {{")
     e("typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;")
     e("typedef __attribute__((ext_vector_type(16))) float f32x16;")
     e(f"constexpr int kRingBytes = {ring_bytes};")
@@ -465,6 +484,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e("template <bool DMA, bool IPE>")
     e(f"__global__ void __launch_bounds__({WAVES * 64}, 2)")
     e("k_mlp_bf16(const char* __restrict__ stream, const float* __restrict__ bias_tab,")
+    if pre:
+        e("           const char* __restrict__ pre_x, const char* __restrict__ pre_acc,")
     e("           const __bf16* __restrict__ enc, const __bf16* __restrict__ viewenc, float4* __restrict__ rgb_sigma,")
     e("           float4* __restrict__ raw_out, int64_t M, int num_samples, int ntiles, float density_bias,")
     e("           float rgb_padding, RayIn rin, const float* __restrict__ dnoise, float dnoise_scale) {")
@@ -501,14 +522,24 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         e("        IpeNext ipn;")
         e("        float ipe_y = 0.0f, ipe_d = 0.0f;")
         e("        bf16x8 ipe_fs, ipe_fc;")
-    e("        if (IPE) {")
-    e(f"            issue_encodings<DMA, {nenc}, {nenc}>(nullptr, viewenc + ray * 32 + hi * 8, encw, lane16);")
-    if not shadow:
-        e(f"            ipe_to_lds<{nenc}>(rin, sc, num_samples, hi, encw + lane16);")
-    e("        } else {")
-    e(f"            issue_encodings<DMA, {nenc}, 0>(enc + sc * {a.xyz_dim} + hi * 8, viewenc + ray * 32 + hi * 8, encw, lane16);")
-    e("        }")
+    if pre:
+        e("        issue_encodings<DMA, 0, 0>(nullptr, viewenc + ray * 32 + hi * 8, encw, lane16);")
+    else:
+        e("        if (IPE) {")
+        e(f"            issue_encodings<DMA, {nenc}, {nenc}>(nullptr, viewenc + ray * 32 + hi * 8, encw, lane16);")
+        if not shadow:
+            e(f"            ipe_to_lds<{nenc}>(rin, sc, num_samples, hi, encw + lane16);")
+        e("        } else {")
+        e(f"            issue_encodings<DMA, {nenc}, 0>(enc + sc * {a.xyz_dim} + hi * 8, viewenc + ray * 32 + hi * 8, encw, lane16);")
+        e("        }")
     e("        bf16x8 X[16], Y[16], " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ", E0, E1, E2;")
+    if pre:
+        e("        // what k_pre_gemm left for this wave tile: X = bf16(relu(layer 0)) as 16 lane-linear fragments, the skip layer's accumulator images")
+        e(f"        const int64_t wt = (int64_t)tile * {WAVES} + wave;")
+        e("        const char* prex_lane = pre_x + wt * 16384 + lane16;")
+        e("        const char* pre_lane = pre_acc + wt * 32768 + lane16;")
+        for k in range(16):
+            e(f"        X[{k}] = *reinterpret_cast<const bf16x8*>(prex_lane + {k * 1024});")
     e("        f32x16 acc00, acc01, acc10, acc11;")
     e("        float raw_density = 0.0f, raw_r = 0.0f, raw_g = 0.0f, raw_b = 0.0f;")
 
@@ -630,6 +661,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         for stmt in side[c]:
             e(f"        {stmt}")
         e("        PIN();")
+    for g in range((nreal + GROUP - 1) // GROUP, ngroups):
+        e(f"        GROUP_BEGIN({g}, {(g + 1) % SLOTS});      // a whole group of zero padding: nothing reads it, but its barrier issues the next tile's group 0")
     for stmt in epilogue_pieces(plan, panels[-1]):
         e(f"        {stmt}")
     e("        if (hi == 0 && s < M) {")
@@ -643,11 +676,35 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e("}")
     e("")
     if variant:
-        e(f"}}  // namespace v{variant}")
-        e(f"using namespace v{variant};")
+        e(f"}}  // namespace v{variant}{'pre' if pre else ''}")
+        e(f"using namespace v{variant}{'pre' if pre else ''};")
     else:
         e("int mlp_bf16_lds_bytes() { return kLdsBytes; }")
     e("")
+    if pre:
+        e("// pre_x / pre_acc: the two outputs of launch_pre_gemm for the same M (16 KiB + 32 KiB per wave tile of 32 samples)")
+        e(f"hipError_t launch_mlp_bf16{sfx}(const void* stream_w, const float* bias_tab, const void* pre_x, const void* pre_acc, const void* viewenc,")
+        e("                           float* rgb_sigma, float* raw_out, int64_t M, int num_samples, float density_bias,")
+        e("                           float rgb_padding, int grid_limit, const float* dnoise, float dnoise_scale, hipStream_t st) {")
+        e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
+        e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
+        e("    if (grid < 1) grid = 1;")
+        e("    static int attr_done[64] = {};")
+        e("    int dev = 0;")
+        e("    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;")
+        e("    if (!attr_done[dev]) {")
+        e("        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_bf16<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
+        e("        if (er != hipSuccess) return er;")
+        e("        attr_done[dev] = 1;")
+        e("    }")
+        e("    const RayIn rin = {nullptr, nullptr, nullptr, nullptr, 0, 0};")
+        e("    hipLaunchKernelGGL((k_mlp_bf16<true, false>), dim3(grid), dim3(%d), kLdsBytes, st, (const char*)stream_w, bias_tab," % (WAVES * 64))
+        e("                       (const char*)pre_x, (const char*)pre_acc, (const __bf16*)nullptr, (const __bf16*)viewenc, (float4*)rgb_sigma,")
+        e("                       (float4*)raw_out, M, num_samples, ntiles, density_bias, rgb_padding, rin, dnoise, dnoise_scale);")
+        e("    return hipGetLastError();")
+        e("}")
+        e("}  // namespace mip")
+        return "\n".join(lines) + "\n"
     e(f"hipError_t launch_mlp_bf16{sfx}(const void* stream_w, const float* bias_tab, const void* enc, const void* viewenc,")
     e("                           float* rgb_sigma, float* raw_out, int64_t M, int num_samples, float density_bias,")
     e("                           float rgb_padding, int grid_limit, bool dma, const RayInputs* rays, const float* dnoise,")

@@ -51,7 +51,7 @@ hipError_t launch_sample_along_rays_360(int64_t B, int N, const float* nearp, co
                                         float* t_inv, float* t, hipStream_t st);
 hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int contracted, const float* t, const float* origins,
                                const float* dirs, const float* radii, void* enc, bool bf16, float* means, float* covs,
-                               hipStream_t st);
+                               hipStream_t st, bool frag = false);   // frag: the MFMA B-operand fragment layout k_pre_gemm reads (bf16 only)
 
 hipError_t launch_gauss_360(int64_t M, int min_deg, int max_deg, int contracted, const float* means, const float* covs, void* enc,
                             bool bf16, float* means_out, float* covs_out, hipStream_t st);
@@ -196,7 +196,7 @@ struct ParamPtrs {
 };
 // table entry: -1 => 0, else (tensor << 20) | element offset
 hipError_t launch_pack(const int32_t* table, int64_t n, const ParamPtrs& ptrs, void* out, bool bf16, hipStream_t st);
-constexpr int kMaxPackSegments = 8;
+constexpr int kMaxPackSegments = 12;
 struct PackSegments {              // several (table -> stream) packs as one launch
     int n;
     int64_t start[kMaxPackSegments + 1];

@@ -34,11 +34,19 @@ k_sample_along_rays_360(int64_t B, int N, const float* __restrict__ nearp, const
     t_out[gid] = 1.0f / ti;
 }
 
+// Where feature f of sample s goes.  Row-major [M, F], or (frag != 0, bf16 only) the MFMA B-operand fragments k_pre_gemm reads
+// (gen_pre_gemm.py): [wave tile of 32 samples][k-step of 16 features][lane (f / 8 % 2, s % 32)][f % 8] -- one lane-linear 1-KiB
+// fragment per wave tile and k-step.
+__device__ __forceinline__ int64_t enc360_index(int64_t s, int f, int F, int frag) {
+    if (!frag) return s * F + f;
+    return ((s >> 5) * (F >> 4) + (f >> 4)) * 512 + ((f >> 3) & 1) * 256 + (s & 31) * 8 + (f & 7);
+}
+
 template <typename OutT>
 __global__ void __launch_bounds__(256)
 k_cast_ipe_360(int64_t B, int N, int min_deg, int L, int contracted, const float* __restrict__ t,
                const float* __restrict__ origins, const float* __restrict__ dirs, const float* __restrict__ radii,
-               OutT* __restrict__ enc, float* __restrict__ means_out, float* __restrict__ covs_out) {
+               OutT* __restrict__ enc, float* __restrict__ means_out, float* __restrict__ covs_out, int frag) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t s = gid / kBasis360N;
     const int j = (int)(gid - s * kBasis360N);
@@ -58,10 +66,10 @@ k_cast_ipe_360(int64_t B, int N, int min_deg, int L, int contracted, const float
     if (!enc) return;
     float y, var;
     project_360(g, j, y, var);
-    OutT* row = enc + s * (int64_t)(2 * kBasis360N * L);
+    const int F = 2 * kBasis360N * L;
     for (int l = 0; l < L; ++l) {
-        row[l * kBasis360N + j] = (OutT)ipe360_feature(y, var, 0, l, min_deg);
-        row[(L + l) * kBasis360N + j] = (OutT)ipe360_feature(y, var, 1, l, min_deg);
+        enc[enc360_index(s, l * kBasis360N + j, F, frag)] = (OutT)ipe360_feature(y, var, 0, l, min_deg);
+        enc[enc360_index(s, (L + l) * kBasis360N + j, F, frag)] = (OutT)ipe360_feature(y, var, 1, l, min_deg);
     }
 }
 
@@ -131,18 +139,20 @@ hipError_t launch_sample_along_rays_360(int64_t B, int N, const float* nearp, co
     return hipGetLastError();
 }
 
+// frag: bf16 only, (2 * 21 * L) % 16 == 0 -- the fragment layout of enc360_index (the buffer must cover whole wave tiles: ceil(M / 32) * 32 rows)
 hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int contracted, const float* t, const float* origins,
                                const float* dirs, const float* radii, void* enc, bool bf16, float* means, float* covs,
-                               hipStream_t st) {
+                               hipStream_t st, bool frag) {
     const int64_t n = B * (int64_t)N * kBasis360N;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     const int L = max_deg - min_deg;
+    if (frag && (!bf16 || (2 * kBasis360N * L) % 16 != 0)) return hipErrorInvalidValue;
     if (bf16)
         hipLaunchKernelGGL((k_cast_ipe_360<__bf16>), grid, block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii,
-                           (__bf16*)enc, means, covs);
+                           (__bf16*)enc, means, covs, frag ? 1 : 0);
     else
         hipLaunchKernelGGL((k_cast_ipe_360<float>), grid, block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii,
-                           (float*)enc, means, covs);
+                           (float*)enc, means, covs, 0);
     return hipGetLastError();
 }
 

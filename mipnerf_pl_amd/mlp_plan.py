@@ -75,6 +75,7 @@ class Op:
     relu: bool
     out: str           # register set written: 'X' | 'Y' | 'head' | 'rgb'
     first_tile: int = 0   # global tile index of tiles[0] (bias table row)
+    pre: bool = False     # accumulators start from pre-activations computed by the pre-GEMM kernel (mlp_pre_plan.py), not from the bias
 
     @property
     def nk(self):
@@ -135,12 +136,17 @@ class Plan:
     chunks: List[Tuple[int, int, int]] = field(default_factory=list)   # (op, tile_in_op, ks); op = -1: zero padding
     n_tiles: int = 0
     n_real_chunks: int = 0
+    pre_gemm: bool = False     # trunk of the two-kernel bf16 form (mlp_pre_plan.py): no encoding segments, layer 0 done elsewhere
 
     # ---- construction -----------------------------------------------------------------
     @staticmethod
-    def build(arch: Arch = None) -> "Plan":
+    def build(arch: Arch = None, pre_gemm: bool = False) -> "Plan":
+        """pre_gemm: the TRUNK of the two-kernel bf16 form used for encodings too wide for the wave-private LDS area (mlp_pre_plan.py):
+        layer 0 and the encoding part of the skip layer are a separate k-step-major GEMM kernel; this plan starts at layer 1 with the
+        register set X preloaded from memory (bf16(relu(layer 0))) and the skip layer's accumulators initialised from the GEMM's fp32
+        partial sums (Op.pre) instead of the bias."""
         a = arch or Arch()
-        wmax = 256 if a.bf16_kernels else 512      # the bf16 kernels keep a whole layer in registers; the fp32 kernel in LDS
+        wmax = 256 if (a.bf16_kernels or pre_gemm) else 512      # the bf16 kernels keep a whole layer in registers; the fp32 kernel in LDS
         if a.net_width % TILE or a.net_width_condition % TILE or a.net_width > wmax or a.net_width_condition > wmax:
             raise NotImplementedError("MFMA kernels need widths that are multiples of 32 and <= 256 (<= 512 for fp32-only variants)")
         if a.xyz_dim % KSTEP or a.view_dim > 32 or a.num_rgb > 4 or a.num_density != 1:
@@ -150,25 +156,30 @@ class Plan:
         if not a.use_viewdirs and a.net_width_condition != a.net_width:
             raise NotImplementedError("use_viewdirs=False feeds the trunk output (net_width) to color_layer "
                                       "(net_width_condition inputs): the reference fails unless the two widths are equal")
-        p = Plan(a)
+        p = Plan(a, pre_gemm=pre_gemm)
         names = [n for n, _ in a.param_shapes()]
         pid = {n: i for i, n in enumerate(names)}
         W, E = a.net_width, a.xyz_dim
         cur, other = None, "X"
         for i in range(a.net_depth):
             segs = []
+            is_skip = (i - 1) % a.skip_index == 0 and i > 1
             if i == 0:
+                if pre_gemm:                       # X = bf16(relu(layer 0)) arrives from the pre-GEMM kernel
+                    cur, other = "X", "Y"
+                    continue
                 segs.append(Seg("enc", NATURAL, E // KSTEP, 0, E))
                 ld = E
             else:
                 segs.append(Seg(cur, DLAYOUT, W // KSTEP, 0, W))
                 ld = W
-                if (i - 1) % a.skip_index == 0 and i > 1:
-                    segs.append(Seg("enc", NATURAL, E // KSTEP, W, E))
+                if is_skip:
+                    if not pre_gemm:
+                        segs.append(Seg("enc", NATURAL, E // KSTEP, W, E))
                     ld = W + E
             tiles = [TileSrc(pid[f"layers.{i}.0.weight"], pid[f"layers.{i}.0.bias"], t * TILE, TILE, ld)
                      for t in range(W // TILE)]
-            p.ops.append(Op(f"layer{i}", segs, tiles, True, other))
+            p.ops.append(Op(f"layer{i}", segs, tiles, True, other, pre=pre_gemm and is_skip))
             cur, other = other, ("Y" if other == "X" else "X")
         # head: bottleneck (no activation) + density row as an extra tile; without view directions only the density row
         # (extra_layer and view_layers stay unused parameters, mip_nerf.py:99-110)
@@ -281,6 +292,8 @@ class Plan:
         offs, _ = self.param_offsets()
         tab = np.full((self.n_tiles, 2, 16), -1, dtype=np.int32)
         for op in self.ops:
+            if op.pre:                  # the bias is part of the pre-activations the accumulators start from
+                continue
             for ti, tile in enumerate(op.tiles):
                 for hi in range(2):
                     for r in range(16):
@@ -351,10 +364,12 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
 
 
 def emulate_wave(plan: Plan, flat_params: np.ndarray, enc: np.ndarray, view: np.ndarray,
-                 round_bf16: bool = False):
+                 round_bf16: bool = False, pre_x: np.ndarray = None, pre_acc: np.ndarray = None):
     """Run the register-level dataflow of one wavefront (32 samples) exactly as the generated
     kernel does: stream chunks in plan order, MFMA 32x32x16 semantics, D -> B repacking.
-    enc [32, xyz_dim], view [32, 32] (already padded).  Returns raw (rgb[32,3], density[32])."""
+    enc [32, xyz_dim], view [32, 32] (already padded).  Returns raw (rgb[32,3], density[32]).
+    Trunk plans (Plan.pre_gemm): pre_x [16, 64, 8] = the preloaded register set X, pre_acc [tiles, 64, 16] = the accumulator images
+    of the skip layer, both as the pre-GEMM kernel leaves them (mlp_pre_plan.emulate_pre_gemm); enc is not read."""
     rnd = bf16_round if round_bf16 else (lambda z: z.astype(np.float32))
     ptab = plan.pack_table()
     btab = plan.bias_table()
@@ -371,7 +386,10 @@ def emulate_wave(plan: Plan, flat_params: np.ndarray, enc: np.ndarray, view: np.
             for j in range(8):
                 out[ks, :, j] = src[lanes_n, ks * 16 + lanes_hi * 8 + j]
         return rnd(out)
-    regs["enc"] = natural(enc, plan.arch.xyz_dim // 16)
+    if plan.pre_gemm:
+        regs["X"] = pre_x
+    else:
+        regs["enc"] = natural(enc, plan.arch.xyz_dim // 16)
     regs["view"] = natural(view, 2)
     ci = 0
     result = {}
@@ -379,7 +397,7 @@ def emulate_wave(plan: Plan, flat_params: np.ndarray, enc: np.ndarray, view: np.
         nt = len(op.tiles)
         acc = np.zeros((nt, 64, 16), np.float32)
         for ti in range(nt):
-            acc[ti] = bias[op.first_tile + ti][lanes_hi]          # accumulator initialised with bias
+            acc[ti] = pre_acc[ti] if op.pre else bias[op.first_tile + ti][lanes_hi]      # accumulator initialised with bias
         for (t0, t1) in plan.panels(op):
             for ks in range(op.nk):
                 seg, ksl = plan.seg_of(op, ks)

@@ -479,9 +479,9 @@ class MipNerf(torch.nn.Module):
                 raise NotImplementedError("unbounded=True samples in inverse depth and always integrates (disparity / disable_integration do not apply)")
             if not stop_resample_grad:
                 raise NotImplementedError("unbounded=True implements the shipped stop-gradient resampler")
-            if (precision or os.environ.get("MIPNERF_PRECISION", "fp32")) not in ("fp32", "float32"):
-                raise NotImplementedError("unbounded=True runs in precision='fp32' (the 42-features-per-degree encoding has no bf16 kernels)")
-            precision = "fp32"
+            # fp32 unless asked otherwise.  precision='bf16' is INFERENCE only: the 672-wide encoding runs as k_pre_gemm + a trunk kernel
+            # (csrc/gen_pre_gemm.py); there are no bf16 training kernels for this shape (forward under autograd raises)
+            precision = precision or os.environ.get("MIPNERF_PRECISION", "fp32")
         mlp_view_dim = deg_view * 3 * 2
         mlp_view_dim = mlp_view_dim + 3 if append_identity else mlp_view_dim
         if not append_identity:
@@ -530,6 +530,9 @@ class MipNerf(torch.nn.Module):
             if o.shape[0] == 0:
                 return self._forward_empty(o.device)
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                if self.unbounded and self.precision == L.PREC_BF16:
+                    raise NotImplementedError("MipNerf(unbounded=True, precision='bf16') is inference only (k_pre_gemm + trunk kernel); "
+                                              "train this model with precision='fp32', or call forward under torch.no_grad()")
                 from .autograd import mipnerf_forward_train
                 return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
             return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
@@ -562,6 +565,8 @@ class MipNerf(torch.nn.Module):
         distloss_c, distloss_f, psnr_fine, outputs or None).  bf16 precision only."""
         if self.precision != L.PREC_BF16:
             raise NotImplementedError("train_step_native is the bf16 path; fp32 parity mode trains through autograd")
+        if self.unbounded:
+            raise NotImplementedError("the unbounded-scene model has bf16 INFERENCE kernels only; it trains through autograd in fp32 precision")
         if not self.stop_resample_grad:
             raise NotImplementedError("stop_resample_grad=False trains through autograd in fp32 precision (the one-call native step "
                                       "implements the shipped stop-gradient resampler)")

@@ -1,0 +1,160 @@
+"""CPU: the plan of the two-kernel bf16 MLP of the unbounded-scene model (mipnerf_pl_amd/mlp_pre_plan.py, csrc/gen_pre_gemm.py).
+
+k_pre_gemm (layer 0 + the encoding half of the skip layer, k-step-major) and the trunk kernel (k_mlp_bf16 generated from
+Plan.build(arch, pre_gemm=True)) are generated from this plan and their weight streams / bias tables packed through its index
+tables.  Checked here, short of the hardware: the numpy emulation of one wavefront through BOTH kernels reproduces the oracle's MLP
+(models/mip_nerf.py:75-111); every parameter lands in exactly one table slot; the generated straight-line bodies issue the MFMAs, ring
+barriers and B-operand loads the counted waits assume."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+import synthetic_inputs as syn
+from mipnerf_pl_amd.mlp_plan import Plan, bf16_round
+from mipnerf_pl_amd.mlp_pre_plan import GROUP, MAGIC, RING_SLOTS, PrePlan, emulate_pre_gemm, emulate_pre_wave, supported
+from oracle import mipnerf_oracle as orc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "mipnerf_pl_amd", "csrc"))
+import gen_mlp_bf16 as gb  # noqa: E402
+import gen_pre_gemm as gp  # noqa: E402
+
+VIS = [vi for vi, a in enumerate(gb.VARIANTS) if supported(a)]
+
+
+def _params(arch, seed=3):
+    params = syn.make_params(seed=seed, density_gain=5.0, xyz_dim=arch.xyz_dim)
+    return params, np.concatenate([params[n].ravel() for n, _ in arch.param_shapes()])
+
+
+def test_which_variants_get_the_two_kernel_form():
+    """exactly the fp32-only variants with an encoding too wide for k_mlp_bf16 (today: the 672 off-axis features of MipNerf(unbounded=True))"""
+    assert VIS == [vi for vi, a in enumerate(gb.VARIANTS) if a.xyz_dim > 96]
+    assert len(VIS) == 1 and gb.VARIANTS[VIS[0]].xyz_dim == 672
+    with pytest.raises(NotImplementedError):
+        PrePlan.build(gb.VARIANTS[0])
+
+
+@pytest.mark.parametrize("vi", VIS)
+def test_emulated_wave_through_both_kernels_equals_oracle(vi):
+    arch = gb.VARIANTS[vi]
+    p = PrePlan.build(arch)
+    params, flat = _params(arch)
+    rng = np.random.default_rng(vi)
+    enc = rng.uniform(-1, 1, (32, arch.xyz_dim)).astype(np.float32)
+    v27 = rng.uniform(-1, 1, (32, 27)).astype(np.float32)
+    view = np.zeros((32, 32), np.float32)
+    view[:, :27] = v27
+    rr, dd = orc.mlp_forward(params, enc[:, None, :], v27)
+    # exact arithmetic of the dataflow (no bf16 rounding): the oracle to fp32 round-off
+    rgb, dens = emulate_pre_wave(p, flat, enc, view)
+    np.testing.assert_allclose(rgb, rr[:, 0], atol=3e-6)
+    np.testing.assert_allclose(dens, dd[:, 0, 0], atol=2e-5)
+    # with the kernels' bf16 operand rounding: the bf16 tolerance of the standard model's tests (|raw| up to ~5 here)
+    rgb16, dens16 = emulate_pre_wave(p, flat, enc, view, round_bf16=True)
+    assert np.max(np.abs(rgb16 - rr[:, 0])) < 2e-2 and np.max(np.abs(dens16 - dd[:, 0, 0])) < 6e-2
+    # what the first kernel hands over: X = bf16(relu(W0 enc + b0)), images = W5[:, 256:] enc + b5 in fp32
+    x, images = emulate_pre_gemm(p, flat, enc)
+    a1 = np.maximum(enc @ params["layers.0.0.weight"].T + params["layers.0.0.bias"], 0)
+    p5 = enc @ params[f"layers.{p.skip_layer}.0.weight"][:, arch.net_width:].T + params[f"layers.{p.skip_layer}.0.bias"]
+    for n in (0, 7, 31):
+        for f in (0, 5, 100, 255):
+            t, r_ = f // 32, None
+            # feature f of sample n sits in fragment k = kmap^-1: search the dlayout
+            hits = [(k, hi, j) for k in range(16) for hi in range(2) for j in range(8) if Plan.kmap(1, k, hi, j) == f]
+            assert len(hits) == 1
+            k, hi, j = hits[0]
+            assert abs(x[k, hi * 32 + n, j] - a1[n, f]) < 2e-5
+            regs = [(hi2, r) for hi2 in range(2) for r in range(16) if Plan.drow(hi2, r) == f % 32]
+            hi2, r = regs[0]
+            assert abs(images[t, hi2 * 32 + n, r] - p5[n, f]) < 2e-5
+
+
+@pytest.mark.parametrize("vi", VIS)
+def test_tables_cover_every_parameter_exactly_once(vi):
+    p = PrePlan.build(gb.VARIANTS[vi])
+    _, total = p.trunk.param_offsets()
+    seen = np.zeros(total, np.int32)
+    for tab in (p.pack_table(), p.bias_table(), p.trunk.pack_table(), p.trunk.bias_table()):
+        t = tab.ravel()
+        np.add.at(seen, t[t >= 0], 1)
+    assert np.all(seen == 1)
+
+
+@pytest.mark.parametrize("vi", VIS)
+def test_streams_and_blob(vi):
+    p = PrePlan.build(gb.VARIANTS[vi])
+    # pre-GEMM stream: whole revolutions of the three-slot ring, no padding, k-step-major
+    assert p.n_real_chunks == len(p.chunks) == 2 * p.nk * p.ntiles == 672 and len(p.chunks) % (GROUP * RING_SLOTS) == 0
+    assert p.chunks[:9] == [(0, 0, t) for t in range(8)] + [(0, 1, 0)] and p.chunks[336] == (1, 0, 0)
+    # trunk: the standard stream minus layer 0 (8 x 42) and the skip layer's encoding k-steps (8 x 42), one whole group of zero padding
+    std = Plan.build(gb.VARIANTS[vi])
+    assert p.trunk.n_real_chunks == std.n_real_chunks - 2 * 8 * 42 == 1120 and len(p.trunk.chunks) == 1152
+    assert [op.name for op in p.trunk.ops][0] == "layer1" and [op.pre for op in p.trunk.ops].count(True) == 1
+    assert p.trunk.ops[p.skip_layer - 1].pre and p.trunk.ops[p.skip_layer - 1].nk == 16
+    blob = np.frombuffer(p.blob(), np.int32)
+    assert blob[0] == MAGIC and blob[1] == blob[2] == 672 and blob[4] == 1152 and blob[5] == 1120 and blob[6] == p.trunk.n_tiles == 70
+    assert blob[7] == p.trunk.param_offsets()[1] and blob[8] == 42 and blob[9] == 8
+    assert blob.size == 16 + 672 * 512 + blob[3] + 1152 * 512 + 70 * 32
+
+
+@pytest.mark.parametrize("vi", VIS)
+def test_generated_gemm_body(vi):
+    """program order of the generated k_pre_gemm tile body: 672 MFMAs in stream order on the accumulator of their tile, with the B
+    register of their k-step; one B-operand load per k-step, into the register the PREVIOUS k-step read; 21 ring barriers, each with
+    exactly four loads since its predecessor (what the counted vmcnt relies on)"""
+    p = PrePlan.build(gb.VARIANTS[vi])
+    src = gp.gen_gemm(p, vi)
+    body = src[src.index("    for (;;) {"):src.index("        if (!has_next) break;")].splitlines()
+    mf = [re.match(r"\s+MFMA\(acc(\d), A(\d), EB(\d+)\);", ln) for ln in body]
+    mf = [m for m in mf if m]
+    assert len(mf) == 672
+    for c, m in enumerate(mf):
+        ps, ks, t = p.chunks[c]
+        assert int(m.group(1)) == t and int(m.group(2)) == c % gp.PREFETCH and int(m.group(3)) == (ps * p.nk + ks) % gp.DEPTH
+    events = []
+    for ln in body:
+        if "RING_BARRIER(" in ln:
+            events.append("gb")
+        elif "LOAD_B(" in ln:
+            events.append(int(re.search(r"LOAD_B\(EB(\d+)\)", ln).group(1)))
+        elif re.match(r"\s+MFMA\(acc7", ln):
+            events.append("k")
+    assert events.count("gb") == len(p.chunks) // GROUP == 21 and events.count("k") == 2 * p.nk
+    # loads between consecutive barriers
+    gaps, n = [], 0
+    for ev in events:
+        if ev == "gb":
+            gaps.append(n)
+            n = 0
+        elif ev != "k":
+            n += 1
+    assert gaps[1:] == [4] * 20 and gaps[0] in (3, 4)
+    # the load behind k-step s goes to register (s - 1) mod DEPTH, i.e. the operand of k-step s + DEPTH - 1
+    step = -1
+    for i, ev in enumerate(events):
+        if ev == "k":
+            step += 1
+        elif ev != "gb":
+            assert ev == (step - 1) % gp.DEPTH
+    # counted waits: never more than the 4 + 8 vector-memory operations known to be younger than the awaited group's DMA
+    ks_ = [int(x) for x in re.findall(r"RING_BARRIER\((\d+)\);", src)]
+    assert ks_ and max(ks_) <= 12 - gp.VM_MARGIN and min(ks_) >= 4
+
+
+@pytest.mark.parametrize("vi", VIS)
+def test_generated_trunk(vi):
+    """the trunk kernel text: X preloaded from 16 fragments, the skip layer's eight accumulators from k_pre_gemm's images (no BIAS for
+    them), one extra ring barrier for the zero-padding group, and the register hazard replay of gen_mlp_bf16 passed (it asserts)"""
+    p = PrePlan.build(gb.VARIANTS[vi])
+    src = gb.gen_kernel(p.trunk, vi)
+    assert len(re.findall(r"X\[\d+\] = \*reinterpret_cast<const bf16x8\*>\(prex_lane", src)) == 16
+    assert sorted(int(x) for x in re.findall(r"pre_load\(acc\d\d, pre_lane \+ (\d+)\);", src)) == [t * 4096 for t in range(8)]
+    skip_first = p.trunk.ops[p.skip_layer - 1].first_tile
+    bias_tiles = {int(x) for x in re.findall(r"BIAS\(acc\d\d, (\d+)\);", src)}
+    assert bias_tiles == set(range(p.trunk.n_tiles)) - set(range(skip_first, skip_first + 8))
+    assert src.count("GROUP_BEGIN(35, 0);") == 1 and len(re.findall(r"\n\s+MFMA\(", src)) == 1120
+    assert "ipe_to_lds<" not in src[src.index("k_mlp_bf16("):]
