@@ -78,7 +78,9 @@ typedef struct mipnerf_config {
                                  /* density_randn tensor is given (mip_nerf.py:232-233)     */
     int32_t unbounded;           /* 0 ; 1 => the unbounded-scene (mip-NeRF 360) path: fence posts uniform in inverse depth,  */
                                  /* contracted full-covariance Gaussians, off-axis IPE with 42 features per degree (what     */
-                                 /* models/mip.py:106-124, 292-319, 424-447 aim at); fp32 precision only (ABI 4)             */
+                                 /* models/mip.py:106-124, 292-319, 424-447 aim at).  fp32 (forward + training) or bf16      */
+                                 /* INFERENCE (mipnerf_forward / mipnerf_mlp_forward: the 672-wide encoding runs as          */
+                                 /* k_pre_gemm + a trunk kernel, csrc/gen_pre_gemm.py); no bf16 training kernels             */
 } mipnerf_config;
 
 #define MIPNERF_MAX_SAMPLES 512
@@ -182,9 +184,12 @@ int mipnerf_integrated_pos_enc(int64_t num_points, int32_t min_deg, int32_t max_
 int mipnerf_pos_enc(int64_t num_rays, int32_t deg_view, const float* viewdirs, void* out,
                     int32_t ld, int out_dtype, void* stream);
 /* MLP.forward (mip_nerf.py:75-111) + activations (mip_nerf.py:236-238):
- * enc [M,96] (dtype = precision), viewenc [B,32] (dtype = precision, ld 32),
- * sample m belongs to ray m / num_samples.  rgb_sigma [M,4] = (r,g,b,sigma) after
- * sigmoid/padding and softplus(raw+bias); raw [M,4] = (raw_rgb, raw_density) or NULL. */
+ * enc [M,xyz_dim] row-major (dtype = precision; xyz_dim = 96, or 672 for the unbounded-scene variant), viewenc [B,32]
+ * (dtype = precision, ld 32), sample m belongs to ray m / num_samples.  rgb_sigma [M,4] = (r,g,b,sigma) after
+ * sigmoid/padding and softplus(raw+bias); raw [M,4] = (raw_rgb, raw_density) or NULL.
+ * bf16 on the unbounded-scene variant runs two kernels with 1.5 KiB of scratch per sample between them; this entry point has no
+ * workspace argument, so the context keeps that buffer and GROWS it with hipMalloc when num_points exceeds every earlier call
+ * (synchronises the stream, not capturable into a hipGraph at that moment) -- mipnerf_forward uses the caller's workspace. */
 int mipnerf_mlp_forward(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples,
                         const void* enc, const void* viewenc, int precision, float* rgb_sigma,
                         float* raw, void* stream);

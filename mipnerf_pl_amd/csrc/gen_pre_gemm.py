@@ -32,7 +32,9 @@ from mipnerf_pl_amd.mlp_pre_plan import GROUP, RING_SLOTS, PrePlan, supported  #
 WAVES = 8
 CHUNK = 1024
 PREFETCH = 4                                              # A fragments in flight (registers A0..A3)
-DEPTH = int(os.environ.get("PRE_GEMM_DEPTH", "13"))       # rotating B-operand registers EB0..: DEPTH - 1 k-steps in flight
+# rotating B-operand registers EB0..: DEPTH - 1 k-steps in flight.  Must divide the 84 k-steps of a tile (12 or 14), so that the register of
+# k-step s is the same in every tile (the loads run ahead across the tile boundary)
+DEPTH = int(os.environ.get("PRE_GEMM_DEPTH", "12"))
 VM_MARGIN = 4                                             # see the counted vmcnt below
 
 
@@ -47,7 +49,7 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     lds_bytes = ring_bytes + bias_bytes
     per_pass = nk * nt
     nsteps = 2 * nk                      # k-steps per tile (both passes)
-    assert DEPTH < nk and GROUP % nt == 0
+    assert DEPTH < nk and GROUP % nt == 0 and nsteps % DEPTH == 0, "the B-register rotation must be tile-periodic"
 
     def lda(c):
         slot = (c // GROUP) % RING_SLOTS

@@ -42,6 +42,78 @@ __device__ __forceinline__ int64_t enc360_index(int64_t s, int f, int F, int fra
     return ((s >> 5) * (F >> 4) + (f >> 4)) * 512 + ((f >> 3) & 1) * 256 + (s & 31) * 8 + (f & 7);
 }
 
+// Accuracy policy per output type, as in kernels_ray.hip: float rows feed the exact-fp32 MLP (parity mode) and use the accurate libm
+// sin / exp; bf16 rows are rounded to 8 bits anyway and use the fast pair -- in BOTH layouts, so the fragment route of mipnerf_forward
+// and the row-major route of the per-stage API hand the MLP the same bits.
+template <typename OutT> struct Ipe360Math;
+template <> struct Ipe360Math<float> {
+    __device__ static float sin(float x) { return sin_accurate(x); }
+    __device__ static float exp(float x) { return exp_accurate(x); }
+};
+template <> struct Ipe360Math<__bf16> {
+    __device__ static float sin(float x) { return sin_fast(x); }
+    __device__ static float exp(float x) { return exp_fast(x); }
+};
+// off-axis IPE feature pair (l, basis j) from the projection (y, var): exp(-0.5 * 4^l var) * (sin(2^l y), sin(2^l y + pi/2));
+// the expressions of raymath360.hpp:ipe360_feature
+template <typename OutT>
+__device__ __forceinline__ void ipe360_pair(float y, float var, int l, int min_deg, OutT& fs, OutT& fc) {
+    const float scale = (float)(1u << (l + min_deg));
+    const float ys = y * scale;
+    const float vs = var * (scale * scale);
+    const float damp = Ipe360Math<OutT>::exp(-0.5f * vs);
+    fs = (OutT)(damp * Ipe360Math<OutT>::sin(ys));
+    fc = (OutT)(damp * Ipe360Math<OutT>::sin(ys + kHalfPiF));
+}
+
+// The bf16 fragment layout as its own kernel: one workgroup per wave tile of 32 samples.  The Gaussian of a sample is formed ONCE (the
+// row-major kernel below recomputes it in each of its 21 threads), its 21 projections go through LDS, and every thread then writes
+// whole 16-byte fragment vectors -- lane n of a vector = sample n, so a wave's stores are lane-linear -- pairing the "sin" vector of
+// eight (degree, direction) features with its "cos" vector 21 k-steps later (same damping factor).  Needs 21 * L to be a multiple of 8.
+__global__ void __launch_bounds__(256)
+k_cast_ipe_360_frag(int64_t B, int N, int min_deg, int L, int contracted, const float* __restrict__ t, const float* __restrict__ origins,
+                    const float* __restrict__ dirs, const float* __restrict__ radii, __bf16* __restrict__ enc) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+    __shared__ GaussFull sg[32];
+    __shared__ float sy[32][kBasis360N], sv[32][kBasis360N];
+    const int tid = threadIdx.x;
+    const int64_t wt = blockIdx.x, M = B * (int64_t)N;
+    if (tid < 32) {
+        const int64_t s = wt * 32 + tid, sc = s < M ? s : M - 1;       // past the end: a valid sample, its fragments are never consumed
+        const int64_t b = sc / N;
+        const int i = (int)(sc - b * N);
+        const float d[3] = {dirs[b * 3], dirs[b * 3 + 1], dirs[b * 3 + 2]};
+        const float o[3] = {origins[b * 3], origins[b * 3 + 1], origins[b * 3 + 2]};
+        sg[tid] = conical_frustum_to_gaussian_full(t[b * (N + 1) + i], t[b * (N + 1) + i + 1], d, o, radii[b], contracted != 0);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 32 * kBasis360N; idx += 256) {
+        const int n = idx / kBasis360N, j = idx - n * kBasis360N;
+        float y, var;
+        project_360(sg[n], j, y, var);
+        sy[n][j] = y;
+        sv[n][j] = var;
+    }
+    __syncthreads();
+    const int nq = kBasis360N * L / 8;          // vectors per half (42 for 16 degrees); k-steps per sample = nq
+    bf16x8* out = reinterpret_cast<bf16x8*>(enc) + wt * (int64_t)(nq * 64);
+    for (int w = tid; w < 32 * nq; w += 256) {
+        const int n = w & 31, q = w >> 5;
+        bf16x8 fs, fc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = q * 8 + i, l = f / kBasis360N, j = f - l * kBasis360N;
+            __bf16 a, c;
+            ipe360_pair<__bf16>(sy[n][j], sv[n][j], l, min_deg, a, c);
+            fs[i] = a;
+            fc[i] = c;
+        }
+        // feature f = 8 q + i: k-step q / 2, lane half q % 2; the "cos" half starts 21 L features = nq vectors later
+        out[(q >> 1) * 64 + (q & 1) * 32 + n] = fs;
+        out[((q + nq) >> 1) * 64 + ((q + nq) & 1) * 32 + n] = fc;
+    }
+}
+
 template <typename OutT>
 __global__ void __launch_bounds__(256)
 k_cast_ipe_360(int64_t B, int N, int min_deg, int L, int contracted, const float* __restrict__ t,
@@ -68,8 +140,10 @@ k_cast_ipe_360(int64_t B, int N, int min_deg, int L, int contracted, const float
     project_360(g, j, y, var);
     const int F = 2 * kBasis360N * L;
     for (int l = 0; l < L; ++l) {
-        enc[enc360_index(s, l * kBasis360N + j, F, frag)] = (OutT)ipe360_feature(y, var, 0, l, min_deg);
-        enc[enc360_index(s, (L + l) * kBasis360N + j, F, frag)] = (OutT)ipe360_feature(y, var, 1, l, min_deg);
+        OutT fs, fc;
+        ipe360_pair<OutT>(y, var, l, min_deg, fs, fc);
+        enc[enc360_index(s, l * kBasis360N + j, F, frag)] = fs;
+        enc[enc360_index(s, (L + l) * kBasis360N + j, F, frag)] = fc;
     }
 }
 
@@ -103,10 +177,8 @@ k_gauss_360(int64_t M, int min_deg, int L, int contracted, const float* __restri
     float y, var;
     project_360(g, j, y, var);
     OutT* row = enc + s * (int64_t)(2 * kBasis360N * L);
-    for (int l = 0; l < L; ++l) {
-        row[l * kBasis360N + j] = (OutT)ipe360_feature(y, var, 0, l, min_deg);
-        row[(L + l) * kBasis360N + j] = (OutT)ipe360_feature(y, var, 1, l, min_deg);
-    }
+    for (int l = 0; l < L; ++l)
+        ipe360_pair<OutT>(y, var, l, min_deg, row[l * kBasis360N + j], row[(L + l) * kBasis360N + j]);
 }
 
 // t = 1 / t_inv for the resampled inverse-depth fence posts of the fine level
@@ -147,6 +219,12 @@ hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int c
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     const int L = max_deg - min_deg;
     if (frag && (!bf16 || (2 * kBasis360N * L) % 16 != 0)) return hipErrorInvalidValue;
+    if (frag && enc && !means && (kBasis360N * L) % 8 == 0) {
+        const int64_t wts = (B * (int64_t)N + 31) / 32;
+        if (wts > 0x7fffffff) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_cast_ipe_360_frag, dim3((unsigned)wts), block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii, (__bf16*)enc);
+        return hipGetLastError();
+    }
     if (bf16)
         hipLaunchKernelGGL((k_cast_ipe_360<__bf16>), grid, block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii,
                            (__bf16*)enc, means, covs, frag ? 1 : 0);

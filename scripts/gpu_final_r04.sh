@@ -19,7 +19,7 @@ l = json.loads(lines[-1])
 open(f"gpurun_out/{T}_bench.json", "w").write(lines[-1] + "\n")
 print("headline", l["value"], l["ms_per_step"], l["roofline"]["frac"], l["roofline"]["launch_ms"], "sustained", l["sustained"]["ms_per_step"])
 print("train", l["train"]["ms_per_step"], "render", l["render"]["ms_per_step"], "fp32", l["fp32"]["ms_per_step"], l["fp32"]["roofline"]["frac"],
-      "unbounded", l["fp32"]["unbounded"]["ms_per_step"], l["fp32"]["unbounded"]["frac"])
+      "unbounded", l["fp32"]["unbounded"]["ms_per_step"], l["fp32"]["unbounded"]["frac"], "unbounded bf16", l["fp32"]["unbounded"].get("bf16"))
 print("ceiling", l["ceiling"]["register_fed"], l["ceiling"]["lds_fed"], l["ceiling"]["lds_and_dma_fed"], l["ceiling"]["fp32_register_fed"]["frac_of_peak"],
       "cpu", l["cpu_baseline"]["value"], l["cpu_baseline"]["cores"], "train cpu", l["train"]["cpu_baseline"]["value"])
 print("scale_model", l["scale_model"]["measured_inputs"], l["scale_model"]["predicted"]["8"])

@@ -86,10 +86,7 @@ def test_unbounded_model_forward_vs_oracle(G, randomized, white):
     assert errs["l1_t_samples"] <= 5e-5 * far                  # measured 2.4e-5 * far = 1e-6 of the inverse depth
     assert errs["l1_rgb"] <= 2e-4 and errs["l1_acc"] <= 2e-4
     assert errs["l1_distance"] <= 2e-4 * far
-    # bf16 precision is refused loudly for this architecture
-    from mipnerf_pl_amd import MipNerf
-    with pytest.raises(NotImplementedError):
-        MipNerf(num_samples=N, unbounded=True, precision="bf16")
+    # (bf16 inference of this architecture: tests/test_gpu_unbounded_bf16.py; bf16 TRAINING is refused loudly there)
 
 
 def _torch_volumetric_rendering(rgb, density, t_samples, dirs, white_bkgd):

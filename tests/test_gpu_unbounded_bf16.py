@@ -65,7 +65,7 @@ def test_mlp_does_not_depend_on_the_grid(G):
     rng = np.random.default_rng(3)
     enc = torch.from_numpy(rng.uniform(-1, 1, (70, 64, 672)).astype(np.float32)).to(DEV)      # 4480 samples = 17.5 tiles
     v = torch.from_numpy(rng.uniform(-1, 1, (70, 27)).astype(np.float32)).to(DEV)
-    ctx = model.mlp.native(DEV)
+    ctx = model.mlp.native(enc.device)
     outs = []
     with torch.no_grad():
         for grid in (256, 5, 1, 256):
