@@ -437,8 +437,9 @@ class MipNerf(torch.nn.Module):
     (mip.py:106-124 sample_along_rays_360, :292-319 integrated_pos_enc_360, :424-447 contract / parameterization): fence posts
     uniform in inverse depth, fine-level resampling over the inverse-depth fence posts, conical frustums lifted to
     FULL-covariance Gaussians, contracted into the radius-2 ball, encoded with the off-axis IPE on 21 directions -- 42 features
-    per degree, so the MLP's first layer / skip concat are 42 * (max_deg_point - min_deg_point) wide (672 for 16 degrees).  fp32
-    precision only (forward, rendering and training through autograd); `disparity` / `disable_integration` do not apply."""
+    per degree, so the MLP's first layer / skip concat are 42 * (max_deg_point - min_deg_point) wide (672 for 16 degrees).  Default
+    precision fp32 (forward, rendering and training through autograd); precision='bf16' is INFERENCE only (two MLP kernels,
+    csrc/gen_pre_gemm.py; about six times faster).  `disparity` / `disable_integration` do not apply."""
 
     def __init__(self, num_samples: int = 128, num_levels: int = 2, resample_padding: float = 0.01,
                  stop_resample_grad: bool = True, use_viewdirs: bool = True, disparity: bool = False,
