@@ -34,8 +34,13 @@ CHUNK = 1024
 PREFETCH = 4                                              # A fragments in flight (registers A0..A3)
 # rotating B-operand registers EB0..: DEPTH - 1 k-steps in flight.  Must divide the 84 k-steps of a tile (12 or 14), so that the register of
 # k-step s is the same in every tile (the loads run ahead across the tile boundary)
-DEPTH = int(os.environ.get("PRE_GEMM_DEPTH", "12"))
+DEPTH = int(os.environ.get("MLP_PRE_DEPTH", "12"))
 VM_MARGIN = 4                                             # see the counted vmcnt below
+# cache policy: non-temporal stores of the two outputs (written once, read by the NEXT kernel) and a non-temporal second read of the encoding
+# (pass 1 is its last use).  Alternating A/B on one box, whole 8192 x (256 + 256) forward: 8.78 / 8.83 ms without, 8.72 / 8.74 with the stores,
+# 8.68 / 8.72 with both (profiles/r04y_pre_gemm_policy_ab.txt); 13 instead of 11 operands in flight: no difference.  Both on by default.
+NT_STORES = os.environ.get("MLP_PRE_NT_STORES", "1") == "1"
+NT_PASS1 = os.environ.get("MLP_PRE_NT_PASS1", "1") == "1"
 
 
 def gen_gemm(p: PrePlan, vi: int) -> str:
@@ -129,14 +134,18 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e("// (the DMA of group g + 1 and the B-operand loads issued since), so the prefetched operands are never waited for here")
     e('#define RING_BARRIER(K) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\\n\\ts_barrier" ::"n"(K) : "memory")')
     e("// stores: wave-uniform base + literal offset (SGPRs) + the 32-bit lane offset, so no 64-bit VGPR address per 4 KiB of output stays live")
-    e("#define STORE_X(k, v) *reinterpret_cast<bf16x8*>(xo_base + (k) * 1024 + lane16) = (v)")
+    if NT_STORES:
+        e("#define ST16(p, v) __builtin_nontemporal_store((v), (p))")
+    else:
+        e("#define ST16(p, v) *(p) = (v)")
+    e("#define STORE_X(k, v) ST16(reinterpret_cast<bf16x8*>(xo_base + (k) * 1024 + lane16), (v))")
     e("// sub-vectors of the accumulator, not element-wise copies: the stores read the accumulator registers themselves")
     e("#define STORE_ACC(t, acc)                                                                                                  \\")
     e("    do {                                                                                                                   \\")
-    e("        *reinterpret_cast<f32x4_*>(ao_base + (t) * 4096 + lane16) = __builtin_shufflevector(acc, acc, 0, 1, 2, 3);                  \\")
-    e("        *reinterpret_cast<f32x4_*>(ao_base + ((t) * 4096 + 1024) + lane16) = __builtin_shufflevector(acc, acc, 4, 5, 6, 7);           \\")
-    e("        *reinterpret_cast<f32x4_*>(ao_base + ((t) * 4096 + 2048) + lane16) = __builtin_shufflevector(acc, acc, 8, 9, 10, 11);         \\")
-    e("        *reinterpret_cast<f32x4_*>(ao_base + ((t) * 4096 + 3072) + lane16) = __builtin_shufflevector(acc, acc, 12, 13, 14, 15);       \\")
+    e("        ST16(reinterpret_cast<f32x4_*>(ao_base + (t) * 4096 + lane16), __builtin_shufflevector(acc, acc, 0, 1, 2, 3));                  \\")
+    e("        ST16(reinterpret_cast<f32x4_*>(ao_base + ((t) * 4096 + 1024) + lane16), __builtin_shufflevector(acc, acc, 4, 5, 6, 7));           \\")
+    e("        ST16(reinterpret_cast<f32x4_*>(ao_base + ((t) * 4096 + 2048) + lane16), __builtin_shufflevector(acc, acc, 8, 9, 10, 11));         \\")
+    e("        ST16(reinterpret_cast<f32x4_*>(ao_base + ((t) * 4096 + 3072) + lane16), __builtin_shufflevector(acc, acc, 12, 13, 14, 15));       \\")
     e("    } while (0)")
     e("// FRAG: enc is the fragment layout [wave tile][k-step][lane][8] (k_cast_ipe_360 writes it); else row-major [M, xyz_dim] bf16")
     e("// B-operand source of a wave tile = a wave-uniform base (SGPRs, so the loads take the saddr form) + a 32-bit lane offset; 16 bytes per")
@@ -189,6 +198,7 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e("    const char* bp = bsrc;")
     e("    unsigned bo = boff0;")
     e('#define LOAD_B(reg) do { reg = *reinterpret_cast<const bf16x8*>(bp + bo); bo += kBStep; asm volatile("" : "+v"(bo)); } while (0)')
+    e('#define LOAD_B_NT(reg) do { reg = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(bp + bo)); bo += kBStep; asm volatile("" : "+v"(bo)); } while (0)')
     for d in range(DEPTH - 1):
         e(f"    LOAD_B(EB{d});")
     e(f"    RING_BARRIER({vmk[0]});")
@@ -211,7 +221,8 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
                 e("        bo = boff0;                // pass 1 reads the same operands again")
             elif step == nsteps:
                 e("        bp = bnext; bo = boff0_next;    // ... and from here on the next tile's")
-            e(f"        LOAD_B(EB{step % DEPTH});")
+            last_use = NT_PASS1 and nk <= step < nsteps          # pass 1's reads of the current tile
+            e(f"        {'LOAD_B_NT' if last_use else 'LOAD_B'}(EB{step % DEPTH});")
         else:
             g = x
             e(f"        RING_BARRIER({vmk[g]});      // group {g} readable, the slot of group {(g - 1) % ngroups} free")
@@ -227,6 +238,7 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e("    }")
     e('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may land after the workgroup has released its LDS')
     e("#undef LOAD_B")
+    e("#undef LOAD_B_NT")
     e("}")
     e(f"}}  // namespace pre_v{vi}")
     e("")

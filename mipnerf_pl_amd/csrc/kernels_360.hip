@@ -47,11 +47,21 @@ __device__ __forceinline__ int64_t enc360_index(int64_t s, int f, int F, int fra
 // and the row-major route of the per-stage API hand the MLP the same bits.
 template <typename OutT> struct Ipe360Math;
 template <> struct Ipe360Math<float> {
-    __device__ static float sin(float x) { return sin_accurate(x); }
+    // sin(x) and "cos" = sin(fl32(x + fl32(pi/2))), the reference's form (mip.py:349-350)
+    __device__ static void sincos(float x, float& s, float& c) { s = sin_accurate(x); c = sin_accurate(x + kHalfPiF); }
     __device__ static float exp(float x) { return exp_accurate(x); }
 };
 template <> struct Ipe360Math<__bf16> {
-    __device__ static float sin(float x) { return sin_fast(x); }
+    // ONE range reduction for the pair (in fp64: x is up to 2^16 rad at the top degree): r = frac(x / 2 pi) in [-0.5, 0.5] turns, then the
+    // hardware sine of r and of r + 1/4 turn.  The "cos" here is the true cosine of x; the reference's fl32(x + pi/2) differs from it by
+    // at most half an fp32 ulp of x (4e-3 rad at 2^16 rad: one bf16 ulp of a feature, and only where the damping has not removed it).
+    __device__ static void sincos(float x, float& s, float& c) {
+        double r = (double)x * 0.15915494309189535;
+        r -= rint(r);
+        const float rf = (float)r;
+        s = __builtin_amdgcn_sinf(rf);
+        c = __builtin_amdgcn_sinf(rf + 0.25f);
+    }
     __device__ static float exp(float x) { return exp_fast(x); }
 };
 // off-axis IPE feature pair (l, basis j) from the projection (y, var): exp(-0.5 * 4^l var) * (sin(2^l y), sin(2^l y + pi/2));
@@ -62,8 +72,10 @@ __device__ __forceinline__ void ipe360_pair(float y, float var, int l, int min_d
     const float ys = y * scale;
     const float vs = var * (scale * scale);
     const float damp = Ipe360Math<OutT>::exp(-0.5f * vs);
-    fs = (OutT)(damp * Ipe360Math<OutT>::sin(ys));
-    fc = (OutT)(damp * Ipe360Math<OutT>::sin(ys + kHalfPiF));
+    float sn, cs;
+    Ipe360Math<OutT>::sincos(ys, sn, cs);
+    fs = (OutT)(damp * sn);
+    fc = (OutT)(damp * cs);
 }
 
 // The bf16 fragment layout as its own kernel: one workgroup per wave tile of 32 samples.  The Gaussian of a sample is formed ONCE (the

@@ -119,8 +119,8 @@ def test_generated_gemm_body(vi):
     for ln in body:
         if "RING_BARRIER(" in ln:
             events.append("gb")
-        elif "LOAD_B(" in ln:
-            events.append(int(re.search(r"LOAD_B\(EB(\d+)\)", ln).group(1)))
+        elif re.search(r"LOAD_B(_NT)?\(EB", ln):           # (_NT: pass 1's reads, the last use of a tile's operands)
+            events.append(int(re.search(r"LOAD_B(?:_NT)?\(EB(\d+)\)", ln).group(1)))
         elif re.match(r"\s+MFMA\(acc7", ln):
             events.append("k")
     assert events.count("gb") == len(p.chunks) // GROUP == 21 and events.count("k") == 2 * p.nk
