@@ -158,3 +158,35 @@ def test_generated_trunk(vi):
     assert bias_tiles == set(range(p.trunk.n_tiles)) - set(range(skip_first, skip_first + 8))
     assert src.count("GROUP_BEGIN(35, 0);") == 1 and len(re.findall(r"\n\s+MFMA\(", src)) == 1120
     assert "ipe_to_lds<" not in src[src.index("k_mlp_bf16("):]
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.mark.parametrize("vi", VIS)
+def test_compiled_gemm_kernel_keeps_the_counted_waits_honest(vi, tmp_path):
+    """The ring barriers of k_pre_gemm wait `vmcnt(8)`: correct as long as at least 8 vector-memory operations are younger than the wave's
+    DMA of the awaited group.  The B-operand loads are ordinary C++ loads the compiler schedules, so this looks at what it actually
+    emitted -- the shipped object, disassembled: between any two consecutive barriers of the steady state there are exactly 4 B-operand
+    loads and 4 LDS-DMA chunks (=> 4 + 8 younger operations, 4 of margin), nothing went to scratch, and no call is left in the kernel."""
+    import shutil
+    import subprocess
+    obj = os.path.join(REPO, "mipnerf_pl_amd", "csrc", f"pre_gemm_gen_v{vi}.o")
+    if not (os.path.exists(obj) and os.path.exists(OBJDUMP)):
+        pytest.skip("needs the built library (python -m mipnerf_pl_amd.build) and llvm-objdump")
+    shutil.copy(obj, tmp_path / "x.o")
+    subprocess.run([OBJDUMP, "--offloading", "x.o"], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(co) == 1
+    dis = subprocess.run([OBJDUMP, "-d", co[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+    kernels = re.split(r"\n[0-9a-f]+ <[^>]*k_pre_gemm[^>]*>:\n", dis)[1:]
+    assert len(kernels) == 2                                   # fragment / row-major encodings
+    for body in kernels:
+        assert "scratch_" not in body and "s_swappc" not in body
+        iv = body.split("s_barrier")
+        assert len(iv) == 24                                   # bias fill + prologue + 21 per tile + tail
+        loads = [len(re.findall(r"global_load_dwordx4", x)) for x in iv]
+        dma = [len(re.findall(r"global_load_lds_dwordx4", x)) for x in iv]
+        assert loads[2:23] == [4] * 21 and dma[2:24] == [4] * 22 and loads[1] == gp.DEPTH - 1 and dma[1] == 8
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", body)
+        assert len(waits) >= 22 and set(waits) == {"8"}          # (the loop rotation may duplicate one)
