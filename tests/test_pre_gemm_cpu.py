@@ -188,5 +188,5 @@ def test_compiled_gemm_kernel_keeps_the_counted_waits_honest(vi, tmp_path):
         loads = [len(re.findall(r"global_load_dwordx4", x)) for x in iv]
         dma = [len(re.findall(r"global_load_lds_dwordx4", x)) for x in iv]
         assert loads[2:23] == [4] * 21 and dma[2:24] == [4] * 22 and loads[1] == gp.DEPTH - 1 and dma[1] == 8
-        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)", body)
-        assert len(waits) >= 22 and set(waits) == {"8"}          # (the loop rotation may duplicate one)
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)[^\n]*\n[^\n]*s_barrier", body)      # the wait in front of every ring barrier
+        assert len(waits) == 22 and set(waits) == {"8"}
