@@ -82,52 +82,57 @@ __device__ __forceinline__ void ipe360_pair(float y, float var, int l, int min_d
     fc = (OutT)(damp * cs);
 }
 
-// The bf16 fragment layout as its own kernel: one workgroup per wave tile of 32 samples.  The Gaussian of a sample is formed ONCE (the
-// row-major kernel below recomputes it in each of its 21 threads), its 21 projections go through LDS, and every thread then writes
-// whole 16-byte fragment vectors -- lane n of a vector = sample n, so a wave's stores are lane-linear -- pairing the "sin" vector of
-// eight (degree, direction) features with its "cos" vector 21 k-steps later (same damping factor).  Needs 21 * L to be a multiple of 8.
+// The bf16 fragment layout as its own kernel: one workgroup per TWO wave tiles (64 samples).  The Gaussian of a sample is formed ONCE (the
+// row-major kernel below recomputes it in each of its 21 threads) by one full wave -- which wave rotates with the workgroup index, so that the
+// serial part does not always land on the same SIMD --, its 21 projections go through LDS, and every thread then writes whole 16-byte
+// fragment vectors -- lane n of a vector = sample n, so a wave's stores are lane-linear -- pairing the "sin" vector of eight
+// (degree, direction) features with its "cos" vector 21 k-steps later (same damping factor).  Needs 21 * L to be a multiple of 8; the buffer
+// covers whole 256-sample tiles (an even number of wave tiles), samples past the end repeat the last one.
+constexpr int kFragSamples = 64;
 __global__ void __launch_bounds__(256)
 k_cast_ipe_360_frag(int64_t B, int N, int min_deg, int L, int contracted, const float* __restrict__ t, const float* __restrict__ origins,
                     const float* __restrict__ dirs, const float* __restrict__ radii, __bf16* __restrict__ enc) {
     typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-    __shared__ GaussFull sg[32];
-    __shared__ float sy[32][kBasis360N], sv[32][kBasis360N];
+    __shared__ GaussFull sg[kFragSamples];
+    __shared__ float sy[kFragSamples][kBasis360N], sv[kFragSamples][kBasis360N];
     const int tid = threadIdx.x;
-    const int64_t wt = blockIdx.x, M = B * (int64_t)N;
-    if (tid < 32) {
-        const int64_t s = wt * 32 + tid, sc = s < M ? s : M - 1;       // past the end: a valid sample, its fragments are never consumed
+    const int64_t s0 = (int64_t)blockIdx.x * kFragSamples, M = B * (int64_t)N;
+    if ((tid >> 6) == (int)(blockIdx.x & 3)) {
+        const int m = tid & 63;
+        const int64_t s = s0 + m, sc = s < M ? s : M - 1;
         const int64_t b = sc / N;
         const int i = (int)(sc - b * N);
         const float d[3] = {dirs[b * 3], dirs[b * 3 + 1], dirs[b * 3 + 2]};
         const float o[3] = {origins[b * 3], origins[b * 3 + 1], origins[b * 3 + 2]};
-        sg[tid] = conical_frustum_to_gaussian_full(t[b * (N + 1) + i], t[b * (N + 1) + i + 1], d, o, radii[b], contracted != 0);
+        sg[m] = conical_frustum_to_gaussian_full(t[b * (N + 1) + i], t[b * (N + 1) + i + 1], d, o, radii[b], contracted != 0);
     }
     __syncthreads();
-    for (int idx = tid; idx < 32 * kBasis360N; idx += 256) {
-        const int n = idx / kBasis360N, j = idx - n * kBasis360N;
+    for (int idx = tid; idx < kFragSamples * kBasis360N; idx += 256) {
+        const int m = idx / kBasis360N, j = idx - m * kBasis360N;
         float y, var;
-        project_360(sg[n], j, y, var);
-        sy[n][j] = y;
-        sv[n][j] = var;
+        project_360(sg[m], j, y, var);
+        sy[m][j] = y;
+        sv[m][j] = var;
     }
     __syncthreads();
     const int nq = kBasis360N * L / 8;          // vectors per half (42 for 16 degrees); k-steps per sample = nq
-    bf16x8* out = reinterpret_cast<bf16x8*>(enc) + wt * (int64_t)(nq * 64);
-    for (int w = tid; w < 32 * nq; w += 256) {
-        const int n = w & 31, q = w >> 5;
+    bf16x8* out = reinterpret_cast<bf16x8*>(enc) + (s0 >> 5) * (int64_t)(nq * 64);
+    for (int w = tid; w < kFragSamples * nq; w += 256) {
+        const int m = w & 63, q = w >> 6;       // consecutive threads = consecutive samples of the same vector index
         bf16x8 fs, fc;
         int l = (q * 8) / kBasis360N, j = q * 8 - l * kBasis360N;       // (degree, direction) of the vector's first feature, then stepped
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             __bf16 a, c;
-            ipe360_pair<__bf16>(sy[n][j], sv[n][j], l, min_deg, a, c);
+            ipe360_pair<__bf16>(sy[m][j], sv[m][j], l, min_deg, a, c);
             fs[i] = a;
             fc[i] = c;
             if (++j == kBasis360N) { j = 0; ++l; }
         }
-        // feature f = 8 q + i: k-step q / 2, lane half q % 2; the "cos" half starts 21 L features = nq vectors later
-        out[(q >> 1) * 64 + (q & 1) * 32 + n] = fs;
-        out[((q + nq) >> 1) * 64 + ((q + nq) & 1) * 32 + n] = fc;
+        // feature f = 8 q + i of sample m: wave tile m / 32, k-step q / 2, lane half q % 2, lane m % 32; the "cos" half starts nq vectors later
+        bf16x8* o = out + (m >> 5) * (nq * 64) + (m & 31);
+        o[(q >> 1) * 64 + (q & 1) * 32] = fs;
+        o[((q + nq) >> 1) * 64 + ((q + nq) & 1) * 32] = fc;
     }
 }
 
@@ -237,7 +242,7 @@ hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int c
     const int L = max_deg - min_deg;
     if (frag && (!bf16 || (2 * kBasis360N * L) % 16 != 0)) return hipErrorInvalidValue;
     if (frag && enc && !means && (kBasis360N * L) % 8 == 0) {
-        const int64_t wts = (B * (int64_t)N + 31) / 32;
+        const int64_t wts = (B * (int64_t)N + kFragSamples - 1) / kFragSamples;
         if (wts > 0x7fffffff) return hipErrorInvalidValue;
         hipLaunchKernelGGL(k_cast_ipe_360_frag, dim3((unsigned)wts), block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii, (__bf16*)enc);
         return hipGetLastError();
