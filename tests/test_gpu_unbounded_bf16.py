@@ -77,10 +77,11 @@ def test_mlp_does_not_depend_on_the_grid(G):
 
 
 @pytest.mark.parametrize("randomized", [False, True])
-def test_forward_bf16_vs_fp32_and_vs_per_stage_route(G, randomized):
+@pytest.mark.parametrize("B", [1, 5, 300])
+def test_forward_bf16_vs_fp32_and_vs_per_stage_route(G, randomized, B):
     from mipnerf_pl_amd import _lib as L
     from mipnerf_pl_amd import ops
-    B, N = 300, 64            # 19,200 samples = 75 tiles of 256
+    N = 64                    # 64 / 320 / 19,200 samples: a quarter of a tile, 1.25 tiles, 75 tiles of 256
     rays = syn.synthetic_rays(B, seed=71, unbounded=True)
     params = syn.make_params(seed=17, density_gain=40.0, xyz_dim=672)
     rng = np.random.default_rng(6)
@@ -98,11 +99,11 @@ def test_forward_bf16_vs_fp32_and_vs_per_stage_route(G, randomized):
             errs[f"l{lvl}_{nm}"] = G.maxdiff(a, b)
     mse = float(torch.mean((got[1][0] - ref[1][0]) ** 2))
     errs["psnr_fine_rgb_db"] = float(-10 * np.log10(max(mse, 1e-20)))
-    G.record(f"unbounded bf16 forward vs fp32 randomized={randomized}", **errs)
+    G.record(f"unbounded bf16 forward vs fp32 B={B} randomized={randomized}", **errs)
     # the coarse level sees the same fence posts: colours within the bf16 tolerance of the standard model's full-size test (3e-2 max,
     # PSNR >= 55 dB); the fine level's fence posts move with the coarse weights, so it is held by PSNR only
     assert errs["l0_rgb"] <= 3e-2 and errs["l0_acc"] <= 3e-2
-    assert errs["psnr_fine_rgb_db"] >= 45.0
+    assert errs["psnr_fine_rgb_db"] >= 50.0                  # measured 55-66 dB
     for lvl in range(2):
         assert all(bool(torch.isfinite(t).all()) for t in got[lvl])
     # per-stage route of the coarse level: row-major bf16 encodings -> mipnerf_mlp_forward -> compositing; the forward call wrote the same
