@@ -35,6 +35,7 @@ PREFETCH = 4                                              # A fragments in fligh
 # rotating B-operand registers EB0..: DEPTH - 1 k-steps in flight.  Must divide the 84 k-steps of a tile (12 or 14), so that the register of
 # k-step s is the same in every tile (the loads run ahead across the tile boundary)
 DEPTH = int(os.environ.get("MLP_PRE_DEPTH", "12"))
+DEPTH_SPLIT = int(os.environ.get("MLP_PRE_DEPTH_SPLIT", "14"))   # split form: must divide the 42 k-steps of a tile (6, 7, 14, 21)
 VM_MARGIN = 4                                             # see the counted vmcnt below
 # cache policy: non-temporal stores of the two outputs (written once, read by the NEXT kernel) and a non-temporal second read of the encoding
 # (pass 1 is its last use).  Alternating A/B on one box, whole 8192 x (256 + 256) forward: 8.78 / 8.83 ms without, 8.72 / 8.74 with the stores,
@@ -53,12 +54,25 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     bias_bytes = 2 * nt * 128
     lds_bytes = ring_bytes + bias_bytes
     per_pass = nk * nt
-    nsteps = 2 * nk                      # k-steps per tile (both passes)
-    assert DEPTH < nk and GROUP % nt == 0 and nsteps % DEPTH == 0, "the B-register rotation must be tile-periodic"
+    split = p.split
+    depth = DEPTH_SPLIT if split else DEPTH
+    nsteps = nk if split else 2 * nk     # k-steps per tile and wave
+    assert depth < nk and GROUP % nt == 0 and nsteps % depth == 0, "the B-register rotation must be tile-periodic"
+    tile_waves = 4 if split else WAVES   # wave tiles (32 samples) per workgroup tile
+    nslots = nsteps * nt                 # MFMAs per wave and tile
 
     def lda(c):
-        slot = (c // GROUP) % RING_SLOTS
-        return f"A{c % PREFETCH} = LDA({slot * GROUP * CHUNK + (c % GROUP) * CHUNK});"
+        """A fragment of wave-local slot c.  Split form: the stream is [k-step][matrix][tile]; the matrix (= the wave's half of the workgroup)
+        is a wave-uniform 8-KiB offset folded into ring_lane"""
+        if split:
+            ks, t = divmod(c, nt)
+            gc = ks * 2 * nt + t
+        else:
+            gc = c
+        slot = (gc // GROUP) % RING_SLOTS
+        return f"A{c % PREFETCH} = LDA({slot * GROUP * CHUNK + (gc % GROUP) * CHUNK});"
+
+    slots_per_group = GROUP // 2 if split else GROUP      # wave-local MFMA slots between two ring barriers
 
     # ---- program-order event list of one tile body: ("gb", g) ring barrier of group g (issues group g + 2), ("ld", step) B-operand load
     body = []                            # (kind, payload) in emission order; "stmt" entries carry C++ text
@@ -66,28 +80,42 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     for t in range(nt):
         E("stmt", f"BIAS(acc{t}, {t});")
     E("stmt", "PIN();")
-    for c in range(nchunks):
-        ps, ks, t = p.chunks[c]
-        step = ps * nk + ks
-        if ps == 1 and ks == 0:
+    for c in range(nslots):
+        step, t = divmod(c, nt)
+        ps = 0 if split else step // nk
+        if not split and ps == 1 and step == nk:
             # pass 0's epilogue tile by tile in front of pass 1's first k-step: X fragments 2t, 2t+1, then the accumulator restarts from b_skip
             E("stmt", f"epilogue_half<true, 0>(acc{t}, xo);  STORE_X({2 * t}, xo);")
             E("stmt", f"epilogue_half<true, 8>(acc{t}, xo);  STORE_X({2 * t + 1}, xo);")
             E("stmt", f"BIAS(acc{t}, {nt + t});")
-        E("stmt", f"MFMA(acc{t}, A{c % PREFETCH}, EB{step % DEPTH});")
+        E("stmt", f"MFMA(acc{t}, A{c % PREFETCH}, EB{step % depth});")
         lc = c + PREFETCH
-        if lc % GROUP == 0:
-            E("gb", (lc // GROUP) % ngroups)           # lc == nchunks: group 0 of the NEXT tile (its first A loads follow below)
-        E("stmt", lda(lc % nchunks))                    # past the end: the next tile's first fragments (harmless after the last tile)
+        if lc % slots_per_group == 0:
+            E("gb", (lc // slots_per_group) % ngroups)  # lc == nslots: group 0 of the NEXT tile (its first A loads follow below)
+        E("stmt", lda(lc % nslots))                     # past the end: the next tile's first fragments (harmless after the last tile)
         if t == nt - 1:
-            # load the operand DEPTH - 1 k-steps ahead (wrapping into the next pass / the next tile) into the register the PREVIOUS
+            # load the operand depth - 1 k-steps ahead (wrapping into the next pass / the next tile) into the register the PREVIOUS
             # k-step read, so the youngest MFMA that used it is 8 slots back
-            E("ld", step + DEPTH - 1)
+            E("ld", step + depth - 1)
         E("stmt", "PIN();")
-    # pass 1's epilogue: plain stores of the 8 accumulator tiles
-    for t in range(nt):
-        E("stmt", f"STORE_ACC({t}, acc{t});")
-        E("stmt", "PIN();")
+    if split:
+        # the tile's epilogue, by half of the workgroup (a wave-uniform branch): W0 half -> ReLU, bf16, the trunk's X fragments;
+        # skip-layer half -> the accumulator tiles as they are
+        E("stmt", "if (role == 0) {")
+        for t in range(nt):
+            E("stmt", f"    epilogue_half<true, 0>(acc{t}, xo);  STORE_X({2 * t}, xo);")
+            E("stmt", f"    epilogue_half<true, 8>(acc{t}, xo);  STORE_X({2 * t + 1}, xo);")
+            E("stmt", "    PIN();")
+        E("stmt", "} else {")
+        for t in range(nt):
+            E("stmt", f"    STORE_ACC({t}, acc{t});")
+            E("stmt", "    PIN();")
+        E("stmt", "}")
+    else:
+        # pass 1's epilogue: plain stores of the 8 accumulator tiles
+        for t in range(nt):
+            E("stmt", f"STORE_ACC({t}, acc{t});")
+            E("stmt", "PIN();")
 
     # ---- counted vmcnt of every ring barrier: vm operations known to be younger than the DMA of the group it waits for ----------
     # DMA(g) is issued inside barrier (g - 2) mod ngroups; steady state = the tile body repeated.  The first tile's prologue issues
@@ -104,7 +132,7 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
         younger = sum(1 for j in range(j2 + 1, i) if seq[j][0] == "ld") + 4       # + DMA(g + 1): four chunks per wave
         vmk[g] = min(vmk.get(g, 63), younger)
     assert len(vmk) == ngroups and all(4 <= k <= 63 for k in vmk.values()), vmk
-    prologue_younger = 4 + DEPTH - 1
+    prologue_younger = 4 + depth - 1
     vmk[0] = min(vmk[0], prologue_younger)
     # margin: the B-operand loads are ordinary C++ loads; should the compiler move a few of them across a barrier, the count stays a
     # lower bound (tests/test_pre_gemm_cpu.py counts the vector-memory instructions between the barriers of the compiled kernel)
@@ -126,7 +154,7 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e(f"constexpr int kLdsBytes = {lds_bytes};")
     e(f"constexpr int kGroupBytes = {GROUP * CHUNK};")
     e(f"constexpr int kNumGroups = {ngroups};")
-    e(f"constexpr int kTileSamples = {WAVES * 32};")
+    e(f"constexpr int kTileSamples = {tile_waves * 32};")
     e(f"constexpr int kXyzDim = {a.xyz_dim};")
     e(f"constexpr int kNk = {nk};")
     e(gb.KERNEL_PREAMBLE.replace("BARRIER_INSN", "s_barrier").replace("WAIT_INSN", "s_waitcnt vmcnt(0) lgkmcnt(0)"))
@@ -151,16 +179,15 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e("// B-operand source of a wave tile = a wave-uniform base (SGPRs, so the loads take the saddr form) + a 32-bit lane offset; 16 bytes per")
     e("// lane and k-step.  Row-major: rows past M are clamped to the last one (their results are never stored).")
     e("template <bool FRAG>")
-    e("__device__ __forceinline__ const char* bbase_of(const char* enc, int tile, int wave, int64_t M) {")
-    e(f"    const int64_t wt = (int64_t)tile * {WAVES} + wave;")
+    e("__device__ __forceinline__ const char* bbase_of(const char* enc, int64_t wt, int64_t M) {")
     e("    if (FRAG) return enc + wt * (int64_t)(kNk * 1024);")
     e("    const int64_t s0 = wt * 32;")
     e("    return enc + (s0 < M ? s0 : M - 1) * (int64_t)(kXyzDim * 2);")
     e("}")
     e("template <bool FRAG>")
-    e("__device__ __forceinline__ unsigned boff_of(int tile, int wave, int lane, int64_t M) {")
+    e("__device__ __forceinline__ unsigned boff_of(int64_t wt, int lane, int64_t M) {")
     e("    if (FRAG) return (unsigned)lane * 16u;")
-    e(f"    const int64_t s0 = ((int64_t)tile * {WAVES} + wave) * 32, s = s0 + (lane & 31);")
+    e("    const int64_t s0 = wt * 32, s = s0 + (lane & 31);")
     e("    const int64_t r0 = s0 < M ? s0 : M - 1, r = s < M ? s : M - 1;")
     e("    return (unsigned)((r - r0) * (kXyzDim * 2) + (lane >> 5) * 16);")
     e("}")
@@ -176,8 +203,17 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e("    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);")
     e("    const int hi = lane >> 5, n = lane & 31;")
     e("    const unsigned lane16 = (unsigned)lane * 16u;")
-    e("    const char* ring_lane = smem + lane16;")
-    e("    const char* bias_lane = smem + kRingBytes + hi * 64;")
+    if split:
+        e("    // waves 0-3: W0 (role 0), waves 4-7: the skip layer's encoding half (role 1), on the SAME four wave tiles -- the second reader of a")
+        e("    // fragment finds it in L1 / L2.  The role is a wave-uniform offset into the ring (8 chunks per k-step each) and the bias table")
+        e("    const int role = wave >> 2, wsub = wave & 3;")
+        e(f"    const char* ring_lane = smem + lane16 + role * {nt * CHUNK};")
+        e(f"    const char* bias_lane = smem + kRingBytes + hi * 64 + role * {nt * 128};")
+        e("#define WT_OF(tl) ((int64_t)(tl) * 4 + wsub)")
+    else:
+        e("    const char* ring_lane = smem + lane16;")
+        e("    const char* bias_lane = smem + kRingBytes + hi * 64;")
+        e(f"#define WT_OF(tl) ((int64_t)(tl) * {WAVES} + wave)")
     e(f"    for (int i = tid; i < kBiasBytes / 16; i += {WAVES * 64})")
     e("        reinterpret_cast<float4*>(smem + kRingBytes)[i] = reinterpret_cast<const float4*>(bias_tab)[i];")
     e("    __syncthreads();")
@@ -185,10 +221,10 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e("    int tile = (int)__builtin_amdgcn_workgroup_id_x();")
     e("    if (tile >= ntiles) return;")
     e("    constexpr int kBStep = FRAG ? 1024 : 32;          // bytes between consecutive k-steps of a lane")
-    e("    const char* bsrc = bbase_of<FRAG>(enc, tile, wave, M);          // uniform")
+    e("    const char* bsrc = bbase_of<FRAG>(enc, WT_OF(tile), M);          // uniform")
     e("    const char* bnext = bsrc;")
-    e("    unsigned boff0 = boff_of<FRAG>(tile, wave, lane, M), boff0_next = boff0;")
-    e("    bf16x8 " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ", " + ", ".join(f"EB{i}" for i in range(DEPTH)) + ", xo;")
+    e("    unsigned boff0 = boff_of<FRAG>(WT_OF(tile), lane, M), boff0_next = boff0;")
+    e("    bf16x8 " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ", " + ", ".join(f"EB{i}" for i in range(depth)) + ", xo;")
     e("    f32x16 " + ", ".join(f"acc{t}" for t in range(nt)) + ";")
     e("    // prologue: ring groups 0 and 1, the first B operands, the first A fragments")
     e("    issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
@@ -199,7 +235,7 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e("    unsigned bo = boff0;")
     e('#define LOAD_B(reg) do { reg = *reinterpret_cast<const bf16x8*>(bp + bo); bo += kBStep; asm volatile("" : "+v"(bo)); } while (0)')
     e('#define LOAD_B_NT(reg) do { reg = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(bp + bo)); bo += kBStep; asm volatile("" : "+v"(bo)); } while (0)')
-    for d in range(DEPTH - 1):
+    for d in range(depth - 1):
         e(f"    LOAD_B(EB{d});")
     e(f"    RING_BARRIER({vmk[0]});")
     e("    issue_group<DMA>(stream, smem, 2, 2, wave, lane16);")
@@ -208,21 +244,21 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e("    for (;;) {")
     e("        const int tnext = tile + nwg;")
     e("        const bool has_next = tnext < ntiles;")
-    e("        bnext = has_next ? bbase_of<FRAG>(enc, tnext, wave, M) : bsrc;")
-    e("        boff0_next = has_next ? boff_of<FRAG>(tnext, wave, lane, M) : boff0;")
-    e(f"        char* xo_base = pre_x + ((int64_t)tile * {WAVES} + wave) * 16384;       // uniform")
-    e(f"        char* ao_base = pre_acc + ((int64_t)tile * {WAVES} + wave) * 32768;")
+    e("        bnext = has_next ? bbase_of<FRAG>(enc, WT_OF(tnext), M) : bsrc;")
+    e("        boff0_next = has_next ? boff_of<FRAG>(WT_OF(tnext), lane, M) : boff0;")
+    e("        char* xo_base = pre_x + WT_OF(tile) * 16384;       // uniform")
+    e("        char* ao_base = pre_acc + WT_OF(tile) * 32768;")
     for kind, x in body:
         if kind == "stmt":
             e(f"        {x}")
         elif kind == "ld":
             step = x
-            if step == nk:
+            if not split and step == nk:
                 e("        bo = boff0;                // pass 1 reads the same operands again")
             elif step == nsteps:
                 e("        bp = bnext; bo = boff0_next;    // ... and from here on the next tile's")
-            last_use = NT_PASS1 and nk <= step < nsteps          # pass 1's reads of the current tile
-            e(f"        {'LOAD_B_NT' if last_use else 'LOAD_B'}(EB{step % DEPTH});")
+            last_use = NT_PASS1 and not split and nk <= step < nsteps          # pass 1's reads of the current tile
+            e(f"        {'LOAD_B_NT' if last_use else 'LOAD_B'}(EB{step % depth});")
         else:
             g = x
             e(f"        RING_BARRIER({vmk[g]});      // group {g} readable, the slot of group {(g - 1) % ngroups} free")
@@ -239,6 +275,7 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA may land after the workgroup has released its LDS')
     e("#undef LOAD_B")
     e("#undef LOAD_B_NT")
+    e("#undef WT_OF")
     e("}")
     e(f"}}  // namespace pre_v{vi}")
     e("")

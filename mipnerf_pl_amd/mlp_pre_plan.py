@@ -30,6 +30,14 @@ GROUP = 32           # chunks per ring slot (8 waves x 4), as in gen_mlp_bf16.py
 RING_SLOTS = 3       # k_pre_gemm has the LDS for a three-slot ring (two groups in flight)
 RING_MULTIPLE = GROUP * RING_SLOTS   # the stream is a whole number of ring revolutions, so the ring phase is the same for every tile
 MAGIC = 0x50524731   # 'PRG1'
+# k_pre_gemm's work split.  0 [default]: one matrix after the other over a 256-sample tile (the encoding is read twice: the kernel sits on the
+# HBM roof, 9.1 GB per level); stream order [matrix][k-step][tile].  1: the two matrices go to the two HALVES of a workgroup -- waves 0-3 contract
+# a 128-sample tile with W0, waves 4-7 the same samples with W_skip[:, 256:], so a tile's encoding comes from HBM once (the second wave finds it
+# in L1 / L2); stream order [k-step][matrix][tile].  Built, parity-green, and SLOWER: 8.56-8.57 ms per forward against 8.27-8.31 (three alternating
+# pairs, profiles/r04y_pre_gemm_split_ab.txt) -- every wave uses half of each ring group, so there is a ring barrier per 16 instead of 32 of its MFMAs
+# and twice the L2 -> LDS weight traffic per sample, which costs more than the second HBM read of the encoding.  Kept as a knob (both forms are
+# generated and checked by tests/test_pre_gemm_cpu.py).
+SPLIT = __import__("os").environ.get("MLP_PRE_SPLIT", "0") == "1"
 
 
 def supported(a: Arch) -> bool:
@@ -45,20 +53,22 @@ class PrePlan:
     trunk: Plan = None
     skip_layer: int = 0
     nk: int = 0                                             # encoding k-steps
-    chunks: List[Tuple[int, int, int]] = field(default_factory=list)      # (pass, ks, tile); pass -1: zero padding
+    chunks: List[Tuple[int, int, int]] = field(default_factory=list)      # (pass = matrix, ks, tile); pass -1: zero padding
     n_real_chunks: int = 0
+    split: bool = True
 
     @staticmethod
-    def build(arch: Arch) -> "PrePlan":
+    def build(arch: Arch, split: bool = None) -> "PrePlan":
         if not supported(arch):
             raise NotImplementedError("the pre-GEMM form is generated for fp32-only variants with a wide encoding, a 256-wide trunk and one skip layer")
-        p = PrePlan(arch, trunk=Plan.build(arch, pre_gemm=True))
+        p = PrePlan(arch, trunk=Plan.build(arch, pre_gemm=True), split=SPLIT if split is None else bool(split))
         p.skip_layer = [i for i in range(arch.net_depth) if (i - 1) % arch.skip_index == 0 and i > 1][0]
         p.nk = arch.xyz_dim // KSTEP
-        for ps in range(2):
-            for ks in range(p.nk):
-                for t in range(arch.net_width // TILE):
-                    p.chunks.append((ps, ks, t))
+        nt = arch.net_width // TILE
+        if p.split:
+            p.chunks = [(ps, ks, t) for ks in range(p.nk) for ps in range(2) for t in range(nt)]
+        else:
+            p.chunks = [(ps, ks, t) for ps in range(2) for ks in range(p.nk) for t in range(nt)]
         p.n_real_chunks = len(p.chunks)
         while len(p.chunks) % RING_MULTIPLE:
             p.chunks.append((-1, 0, 0))

@@ -87,9 +87,14 @@ def test_tables_cover_every_parameter_exactly_once(vi):
 @pytest.mark.parametrize("vi", VIS)
 def test_streams_and_blob(vi):
     p = PrePlan.build(gb.VARIANTS[vi])
-    # pre-GEMM stream: whole revolutions of the three-slot ring, no padding, k-step-major
+    # pre-GEMM stream: whole revolutions of the three-slot ring, no padding, k-step-major; split form: both matrices per k-step
     assert p.n_real_chunks == len(p.chunks) == 2 * p.nk * p.ntiles == 672 and len(p.chunks) % (GROUP * RING_SLOTS) == 0
-    assert p.chunks[:9] == [(0, 0, t) for t in range(8)] + [(0, 1, 0)] and p.chunks[336] == (1, 0, 0)
+    if p.split:
+        assert p.chunks[:17] == [(0, 0, t) for t in range(8)] + [(1, 0, t) for t in range(8)] + [(0, 1, 0)]
+    else:
+        assert p.chunks[:9] == [(0, 0, t) for t in range(8)] + [(0, 1, 0)] and p.chunks[336] == (1, 0, 0)
+    two = PrePlan.build(gb.VARIANTS[vi], split=not p.split)          # the other work split: the same chunks in another order
+    assert sorted(two.chunks) == sorted(p.chunks) and two.chunks != p.chunks
     # trunk: the standard stream minus layer 0 (8 x 42) and the skip layer's encoding k-steps (8 x 42), one whole group of zero padding
     std = Plan.build(gb.VARIANTS[vi])
     assert p.trunk.n_real_chunks == std.n_real_chunks - 2 * 8 * 42 == 1120 and len(p.trunk.chunks) == 1152
@@ -101,30 +106,42 @@ def test_streams_and_blob(vi):
     assert blob.size == 16 + 672 * 512 + blob[3] + 1152 * 512 + 70 * 32
 
 
+@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("vi", VIS)
-def test_generated_gemm_body(vi):
-    """program order of the generated k_pre_gemm tile body: 672 MFMAs in stream order on the accumulator of their tile, with the B
-    register of their k-step; one B-operand load per k-step, into the register the PREVIOUS k-step read; 21 ring barriers, each with
-    exactly four loads since its predecessor (what the counted vmcnt relies on)"""
-    p = PrePlan.build(gb.VARIANTS[vi])
+def test_generated_gemm_body(vi, split):
+    """program order of the generated k_pre_gemm tile body, for both work splits (mlp_pre_plan.SPLIT): the MFMAs of a wave in stream order
+    on the accumulator of their tile, with the A register of their slot and the B register of their k-step; the A fragment of every slot
+    read from the ring position its chunk lives at; one B-operand load per k-step, into the register the PREVIOUS k-step read, the
+    rotation tile-periodic; 21 ring barriers, each with the same number of loads since its predecessor (what the counted vmcnt relies on)"""
+    p = PrePlan.build(gb.VARIANTS[vi], split=split)
     src = gp.gen_gemm(p, vi)
+    depth = gp.DEPTH_SPLIT if split else gp.DEPTH
+    per_wave = [c for c in p.chunks if c[0] == 0] if split else p.chunks          # split: a wave sees one matrix (role 0 here; role 1 = + 8 chunks)
     body = src[src.index("    for (;;) {"):src.index("        if (!has_next) break;")].splitlines()
     mf = [re.match(r"\s+MFMA\(acc(\d), A(\d), EB(\d+)\);", ln) for ln in body]
     mf = [m for m in mf if m]
-    assert len(mf) == 672
+    assert len(mf) == len(per_wave) == (336 if split else 672)
+    steps_per_tile = p.nk if split else 2 * p.nk
+    assert steps_per_tile % depth == 0
     for c, m in enumerate(mf):
-        ps, ks, t = p.chunks[c]
-        assert int(m.group(1)) == t and int(m.group(2)) == c % gp.PREFETCH and int(m.group(3)) == (ps * p.nk + ks) % gp.DEPTH
+        ps, ks, t = per_wave[c]
+        assert int(m.group(1)) == t and int(m.group(2)) == c % gp.PREFETCH and int(m.group(3)) == (ps * p.nk + ks) % depth
+    # every A fragment is read from where its chunk sits in the three-slot ring (the role offset of the split form is in ring_lane)
+    ldas = [int(x) for x in re.findall(r"A\d = LDA\((\d+)\);", "\n".join(body))]
+    want = []
+    for c in range(len(per_wave)):
+        gc = p.chunks.index(per_wave[(c + gp.PREFETCH) % len(per_wave)])
+        want.append(((gc // GROUP) % RING_SLOTS) * GROUP * 1024 + (gc % GROUP) * 1024)
+    assert ldas == want
     events = []
     for ln in body:
         if "RING_BARRIER(" in ln:
             events.append("gb")
-        elif re.search(r"LOAD_B(_NT)?\(EB", ln):           # (_NT: pass 1's reads, the last use of a tile's operands)
+        elif re.search(r"LOAD_B(_NT)?\(EB", ln):           # (_NT: pass 1's reads of the two-pass form, the last use of a tile's operands)
             events.append(int(re.search(r"LOAD_B(?:_NT)?\(EB(\d+)\)", ln).group(1)))
         elif re.match(r"\s+MFMA\(acc7", ln):
             events.append("k")
-    assert events.count("gb") == len(p.chunks) // GROUP == 21 and events.count("k") == 2 * p.nk
-    # loads between consecutive barriers
+    assert events.count("gb") == len(p.chunks) // GROUP == 21 and events.count("k") == steps_per_tile
     gaps, n = [], 0
     for ev in events:
         if ev == "gb":
@@ -132,17 +149,18 @@ def test_generated_gemm_body(vi):
             n = 0
         elif ev != "k":
             n += 1
-    assert gaps[1:] == [4] * 20 and gaps[0] in (3, 4)
-    # the load behind k-step s goes to register (s - 1) mod DEPTH, i.e. the operand of k-step s + DEPTH - 1
+    per_gap = 2 if split else 4
+    assert gaps[1:] == [per_gap] * 20 and gaps[0] in (per_gap - 1, per_gap)
     step = -1
-    for i, ev in enumerate(events):
+    for ev in events:
         if ev == "k":
             step += 1
         elif ev != "gb":
-            assert ev == (step - 1) % gp.DEPTH
-    # counted waits: never more than the 4 + 8 vector-memory operations known to be younger than the awaited group's DMA
+            assert ev == (step - 1) % depth
+    # counted waits: never more than the vector-memory operations known to be younger than the awaited group's DMA (its successor's four
+    # chunks + the loads of two barrier intervals), minus the margin
     ks_ = [int(x) for x in re.findall(r"RING_BARRIER\((\d+)\);", src)]
-    assert ks_ and max(ks_) <= 12 - gp.VM_MARGIN and min(ks_) >= 4
+    assert ks_ and max(ks_) <= 4 + 2 * per_gap - gp.VM_MARGIN and min(ks_) >= 4 - (0 if split else 0)
 
 
 @pytest.mark.parametrize("vi", VIS)
@@ -187,6 +205,8 @@ def test_compiled_gemm_kernel_keeps_the_counted_waits_honest(vi, tmp_path):
         assert len(iv) == 24                                   # bias fill + prologue + 21 per tile + tail
         loads = [len(re.findall(r"global_load_dwordx4", x)) for x in iv]
         dma = [len(re.findall(r"global_load_lds_dwordx4", x)) for x in iv]
-        assert loads[2:23] == [4] * 21 and dma[2:24] == [4] * 22 and loads[1] == gp.DEPTH - 1 and dma[1] == 8
+        split = PrePlan.build(gb.VARIANTS[vi]).split
+        per_gap, depth = (2, gp.DEPTH_SPLIT) if split else (4, gp.DEPTH)
+        assert loads[3:23] == [per_gap] * 20 and loads[2] in (per_gap - 1, per_gap) and dma[2:24] == [4] * 22 and loads[1] == depth - 1 and dma[1] == 8
         waits = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)[^\n]*\n[^\n]*s_barrier", body)      # the wait in front of every ring barrier
-        assert len(waits) == 22 and set(waits) == {"8"}
+        assert len(waits) == 22 and set(waits) == {str(4 + 2 * per_gap - gp.VM_MARGIN)}
