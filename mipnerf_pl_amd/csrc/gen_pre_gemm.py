@@ -18,6 +18,9 @@ k_pre_gemm, per workgroup of 8 waves (2 per SIMD) and tile of 256 samples, strai
   * pass 0 ends in bias-free ReLU + bf16 packing (the accumulators started from the bias image) and 16 fragment stores = the trunk's
     register set X; pass 1 stores its 8 accumulator tiles as fp32 images the trunk's skip layer starts from.
 
+A second form of k_pre_gemm (mlp_pre_plan.SPLIT = MLP_PRE_SPLIT=1) gives the two matrices to the two halves of a workgroup on the same 128 samples (one HBM
+read of the encoding); it is generated and tested too, and measured 3.6 % slower -- see mlp_pre_plan.py.
+
 Usage: python gen_pre_gemm.py [outdir]
 """
 import os

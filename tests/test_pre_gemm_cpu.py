@@ -183,10 +183,11 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 @pytest.mark.parametrize("vi", VIS)
 def test_compiled_gemm_kernel_keeps_the_counted_waits_honest(vi, tmp_path):
-    """The ring barriers of k_pre_gemm wait `vmcnt(8)`: correct as long as at least 8 vector-memory operations are younger than the wave's
-    DMA of the awaited group.  The B-operand loads are ordinary C++ loads the compiler schedules, so this looks at what it actually
-    emitted -- the shipped object, disassembled: between any two consecutive barriers of the steady state there are exactly 4 B-operand
-    loads and 4 LDS-DMA chunks (=> 4 + 8 younger operations, 4 of margin), nothing went to scratch, and no call is left in the kernel."""
+    """The ring barriers of k_pre_gemm wait with a counted `vmcnt(K)`: correct as long as at least K vector-memory operations are younger than
+    the wave's DMA of the awaited group.  The B-operand loads are ordinary C++ loads the compiler schedules, so this looks at what it actually
+    emitted -- the shipped object, disassembled: between any two consecutive barriers of the steady state there are exactly 4 (split form: 2)
+    B-operand loads and 4 LDS-DMA chunks (=> 4 + 2 x that many younger operations; K leaves 4 of margin), nothing went to scratch, and no
+    call is left in the kernel."""
     import shutil
     import subprocess
     obj = os.path.join(REPO, "mipnerf_pl_amd", "csrc", f"pre_gemm_gen_v{vi}.o")
