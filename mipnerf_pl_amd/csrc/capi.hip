@@ -1299,18 +1299,19 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
 }
 
 // ---- the level loop ---------------------------------------------------------------------------------
-// encoding buffer of one level: [M, xyz_dim] fp32 (or bf16), or -- two-kernel bf16 form -- bf16 fragments of whole 256-sample tiles
+// encoding region of one level: [M, xyz_dim] fp32 (or bf16) -- or, two-kernel bf16 form, the bf16 fragments of whole 256-sample tiles followed by
+// k_pre_gemm's two outputs (1,344 + 1,536 B per sample: 7 % more than the fp32 encodings they replace, so one region serves either precision)
+static size_t pre_frag_bytes(const mipnerf_ctx* c, size_t M) { return ((M + 255) / 256) * 256 * (size_t)c->P->xyz_dim * 2; }
 static size_t enc_region_bytes(const mipnerf_ctx* c, size_t M) {
     const size_t rowmajor = M * c->P->xyz_dim * 4;
-    const size_t frag = has_bf16_pre(c->P) ? ((M + 255) / 256) * 256 * (size_t)c->P->xyz_dim * 2 : 0;
-    return rowmajor > frag ? rowmajor : frag;
+    const size_t pre = has_bf16_pre(c->P) ? align256(pre_frag_bytes(c, M)) + align256(pre_x_bytes((int64_t)M)) + align256(pre_acc_bytes((int64_t)M)) : 0;
+    return rowmajor > pre ? rowmajor : pre;
 }
 size_t mipnerf_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
     if (!c || B < 1) return 0;
     const size_t M = (size_t)B * (size_t)c->cfg.num_samples;
     return align256(enc_region_bytes(c, M)) + align256((size_t)B * 32 * 4) + align256(M * 16) + 256 +
-           (c->cfg.unbounded ? 2 * align256((size_t)B * (c->cfg.num_samples + 1) * 4) : 0) +       // inverse-depth fence posts of two levels
-           (has_bf16_pre(c->P) ? align256(pre_x_bytes((int64_t)M)) + align256(pre_acc_bytes((int64_t)M)) : 0);   // between k_pre_gemm and the trunk kernel
+           (c->cfg.unbounded ? 2 * align256((size_t)B * (c->cfg.num_samples + 1) * 4) : 0);       // inverse-depth fence posts of two levels
 }
 
 int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* t_rand, const float* u_rand,
@@ -1336,16 +1337,16 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
     void* viewenc = ws + enc_b;
     float* rgb_sigma = reinterpret_cast<float*>(ws + enc_b + align256((size_t)B * 32 * 4));
     float* t_inv[2] = {nullptr, nullptr};
-    char* ws_tail = reinterpret_cast<char*>(rgb_sigma) + align256(M * 16);
     if (cfg.unbounded) {
-        t_inv[0] = reinterpret_cast<float*>(ws_tail);
-        t_inv[1] = reinterpret_cast<float*>(ws_tail + align256((size_t)B * (N + 1) * 4));
-        ws_tail += 2 * align256((size_t)B * (N + 1) * 4);
+        char* q = reinterpret_cast<char*>(rgb_sigma) + align256(M * 16);
+        t_inv[0] = reinterpret_cast<float*>(q);
+        t_inv[1] = reinterpret_cast<float*>(q + align256((size_t)B * (N + 1) * 4));
     }
-    // bf16 on a variant whose encoding is too wide for k_mlp_bf16 (the unbounded-scene model): k_pre_gemm + trunk kernel (gen_pre_gemm.py)
+    // bf16 on a variant whose encoding is too wide for k_mlp_bf16 (the unbounded-scene model): k_pre_gemm + trunk kernel (gen_pre_gemm.py);
+    // its fragments and the two buffers between the kernels share the encoding region
     const bool pre_form = precision == MIPNERF_PREC_BF16 && has_bf16_pre(c->P);
-    void* pre_x = pre_form ? ws_tail : nullptr;
-    void* pre_acc = pre_form ? ws_tail + align256(pre_x_bytes((int64_t)M)) : nullptr;
+    char* pre_x = pre_form ? ws + align256(pre_frag_bytes(c, M)) : nullptr;
+    char* pre_acc = pre_form ? pre_x + align256(pre_x_bytes((int64_t)M)) : nullptr;
     const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
     const int white = (flags & MIPNERF_FLAG_WHITE_BKGD) ? 1 : 0;
     int rc;

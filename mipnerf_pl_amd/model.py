@@ -519,6 +519,16 @@ class MipNerf(torch.nn.Module):
             raise ValueError("density_randn must have num_levels x B x num_samples elements")
         return z
 
+    def set_precision(self, precision: str) -> "MipNerf":
+        """Switch the arithmetic of all later calls: 'bf16' | 'fp32'.  The native context packs the weight streams of both precisions, so
+        nothing is rebuilt.  Typical use: `MipNerf(unbounded=True)` trains in fp32 (it has no bf16 training kernels) and renders in bf16
+        (`model.eval(); model.set_precision('bf16')` -- about six times faster)."""
+        if precision not in _PREC:
+            raise ValueError(f"precision must be one of {sorted(_PREC)}")
+        self.precision = _PREC[precision]
+        self.mlp.precision = self.precision
+        return self
+
     def forward(self, rays: Rays, randomized: bool, white_bkgd: bool, t_rand=None, u_rand=None, density_randn=None):
         """rays: Rays of [B,k] float32 HIP tensors.  Returns [(comp_rgb [B,3], distance [B], acc [B],
         weights [B,N], t_samples [B,N+1])] * num_levels (mip_nerf.py:246).  `t_rand` / `u_rand` / `density_randn`

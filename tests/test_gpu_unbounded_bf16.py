@@ -117,6 +117,27 @@ def test_forward_bf16_vs_fp32_and_vs_per_stage_route(G, randomized, B):
     assert torch.equal(comp[0], got[0][0]) and torch.equal(comp[3], got[0][3])
 
 
+def test_train_in_fp32_render_in_bf16(G):
+    """set_precision switches the arithmetic of a live model: an fp32 model switched to bf16 renders exactly what a bf16 model with the same
+    weights renders (the context packs the streams of both precisions), and switches back"""
+    params = syn.make_params(seed=17, density_gain=40.0, xyz_dim=672)
+    rays = G.to_dev(syn.synthetic_rays(50, seed=9, unbounded=True))
+    m16, m32 = _model(params, 64, "bf16"), _model(params, 64, "fp32")
+    with torch.no_grad():
+        a = m16(rays, False, True)
+        b32 = m32(rays, False, True)
+        b = m32.set_precision("bf16")(rays, False, True)
+        c32 = m32.set_precision("fp32")(rays, False, True)
+    for lvl in range(2):
+        for x, y in zip(a[lvl], b[lvl]):
+            assert torch.equal(x, y)
+        for x, y in zip(b32[lvl], c32[lvl]):
+            assert torch.equal(x, y)
+    assert not torch.equal(a[1][0], b32[1][0])
+    with pytest.raises(ValueError):
+        m32.set_precision("fp16")
+
+
 def test_training_entry_points_refuse_bf16_for_this_model(G):
     params = syn.make_params(seed=17, density_gain=40.0, xyz_dim=672)
     m16 = _model(params, 64, "bf16")
