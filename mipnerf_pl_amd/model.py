@@ -746,7 +746,10 @@ class GraphedFrame:
         if rays.origins.shape[0] != self.n:
             raise ValueError(f"GraphedFrame captured for {self.n} rays, got {rays.origins.shape[0]}")
         self.model.mlp.native(self.dev)         # re-pack OUTSIDE the graph when a parameter changed
+        if self.graph is not None and getattr(self, "_captured_precision", None) != self.model.precision:
+            self.graph = None                   # MipNerf.set_precision since the capture: the graph holds the other precision's launches
         if self.graph is None:
+            self._captured_precision = self.model.precision
             self._capture()
         for dst, src in zip(self.static_in, rays):
             dst.copy_(src)

@@ -173,3 +173,12 @@ def test_unbounded_model_trains_in_fp32(G):
     system.enable_hip_graph(True)
     c2, f2, _ = system.render_image((img_rays, torch.zeros(1, 6, 8, 3, device=DEV)))
     assert torch.equal(f2, f_rgb) and torch.equal(c2, c_rgb)
+    # trained in fp32, rendered in bf16 (round 4: k_pre_gemm + trunk kernel): the live model switched over; the captured frame notices the
+    # switch, re-captures, and equals the eager bf16 frame; close to the fp32 frame
+    system.mip_nerf.set_precision("bf16")
+    c3, f3, _ = system.render_image((img_rays, torch.zeros(1, 6, 8, 3, device=DEV)))
+    system.enable_hip_graph(False)
+    c4, f4, _ = system.render_image((img_rays, torch.zeros(1, 6, 8, 3, device=DEV)))
+    assert torch.equal(f3, f4) and torch.equal(c3, c4) and not torch.equal(f3, f_rgb)
+    assert float((f3 - f_rgb).abs().max()) <= 3e-2
+    system.mip_nerf.set_precision("fp32")
