@@ -56,7 +56,6 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     ring_bytes = RING_SLOTS * GROUP * CHUNK
     bias_bytes = 2 * nt * 128
     lds_bytes = ring_bytes + bias_bytes
-    per_pass = nk * nt
     split = p.split
     depth = DEPTH_SPLIT if split else DEPTH
     nsteps = nk if split else 2 * nk     # k-steps per tile and wave

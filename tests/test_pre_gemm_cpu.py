@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import synthetic_inputs as syn
-from mipnerf_pl_amd.mlp_plan import Plan, bf16_round
+from mipnerf_pl_amd.mlp_plan import Plan
 from mipnerf_pl_amd.mlp_pre_plan import GROUP, MAGIC, RING_SLOTS, PrePlan, emulate_pre_gemm, emulate_pre_wave, supported
 from oracle import mipnerf_oracle as orc
 
@@ -62,7 +62,7 @@ def test_emulated_wave_through_both_kernels_equals_oracle(vi):
     p5 = enc @ params[f"layers.{p.skip_layer}.0.weight"][:, arch.net_width:].T + params[f"layers.{p.skip_layer}.0.bias"]
     for n in (0, 7, 31):
         for f in (0, 5, 100, 255):
-            t, r_ = f // 32, None
+            t = f // 32
             # feature f of sample n sits in fragment k = kmap^-1: search the dlayout
             hits = [(k, hi, j) for k in range(16) for hi in range(2) for j in range(8) if Plan.kmap(1, k, hi, j) == f]
             assert len(hits) == 1
@@ -160,7 +160,7 @@ def test_generated_gemm_body(vi, split):
     # counted waits: never more than the vector-memory operations known to be younger than the awaited group's DMA (its successor's four
     # chunks + the loads of two barrier intervals), minus the margin
     ks_ = [int(x) for x in re.findall(r"RING_BARRIER\((\d+)\);", src)]
-    assert ks_ and max(ks_) <= 4 + 2 * per_gap - gp.VM_MARGIN and min(ks_) >= 4 - (0 if split else 0)
+    assert ks_ and max(ks_) <= 4 + 2 * per_gap - gp.VM_MARGIN and min(ks_) >= 4
 
 
 @pytest.mark.parametrize("vi", VIS)
