@@ -190,12 +190,15 @@ def test_compiled_gemm_kernel_keeps_the_counted_waits_honest(vi, tmp_path):
     call is left in the kernel."""
     import shutil
     import subprocess
-    obj = os.path.join(REPO, "mipnerf_pl_amd", "csrc", f"pre_gemm_gen_v{vi}.o")
-    if not (os.path.exists(obj) and os.path.exists(OBJDUMP)):
+    lib = os.path.join(REPO, "mipnerf_pl_amd", "csrc", "libmipnerf_hip.so")
+    if not (os.path.exists(lib) and os.path.exists(OBJDUMP)):
         pytest.skip("needs the built library (python -m mipnerf_pl_amd.build) and llvm-objdump")
-    shutil.copy(obj, tmp_path / "x.o")
-    subprocess.run([OBJDUMP, "--offloading", "x.o"], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    co = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    shutil.copy(lib, tmp_path / "x.so")
+    subprocess.run([OBJDUMP, "--offloading", "x.so"], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    co = []                                                    # one code object per translation unit: the one that defines this variant's kernel
+    for f in sorted(os.listdir(tmp_path)):
+        if "gfx950" in f and f"pre_v{vi}" in subprocess.run([OBJDUMP, "-t", f], cwd=tmp_path, capture_output=True, text=True).stdout:
+            co.append(f)
     assert len(co) == 1
     dis = subprocess.run([OBJDUMP, "-d", co[0]], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
     kernels = re.split(r"\n[0-9a-f]+ <[^>]*k_pre_gemm[^>]*>:\n", dis)[1:]
