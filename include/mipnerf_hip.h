@@ -189,7 +189,8 @@ int mipnerf_pos_enc(int64_t num_rays, int32_t deg_view, const float* viewdirs, v
  * sigmoid/padding and softplus(raw+bias); raw [M,4] = (raw_rgb, raw_density) or NULL.
  * bf16 on the unbounded-scene variant runs two kernels with 1.5 KiB of scratch per sample between them; this entry point has no
  * workspace argument, so the context keeps that buffer and GROWS it with hipMalloc when num_points exceeds every earlier call
- * (synchronises the stream, not capturable into a hipGraph at that moment) -- mipnerf_forward uses the caller's workspace. */
+ * (synchronises the stream, not capturable into a hipGraph at that moment; one stream at a time per context for this entry point on
+ * that variant) -- mipnerf_forward uses the caller's workspace and has neither restriction. */
 int mipnerf_mlp_forward(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples,
                         const void* enc, const void* viewenc, int precision, float* rgb_sigma,
                         float* raw, void* stream);
