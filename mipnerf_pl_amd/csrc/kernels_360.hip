@@ -82,17 +82,20 @@ __device__ __forceinline__ void ipe360_pair(float y, float var, int l, int min_d
     fc = (OutT)(damp * cs);
 }
 
-// The bf16 fragment layout as its own kernel: one workgroup per TWO wave tiles (64 samples).  The Gaussian of a sample is formed ONCE (the
-// row-major kernel below recomputes it in each of its 21 threads) by one full wave -- which wave rotates with the workgroup index, so that the
-// serial part does not always land on the same SIMD --, its 21 projections go through LDS, and every thread then writes whole 16-byte
-// fragment vectors -- lane n of a vector = sample n, so a wave's stores are lane-linear -- pairing the "sin" vector of eight
-// (degree, direction) features with its "cos" vector 21 k-steps later (same damping factor).  Needs 21 * L to be a multiple of 8; the buffer
-// covers whole 256-sample tiles (an even number of wave tiles), samples past the end repeat the last one.
+// The encoding of a TILE of 64 samples per workgroup (what mipnerf_forward and the per-stage entry point use when only the encoding is asked for).
+// The Gaussian of a sample is formed ONCE (k_cast_ipe_360 below recomputes it in each of its 21 threads) by one full wave -- which wave rotates
+// with the workgroup index, so that the serial part does not always land on the same SIMD --, its 21 projections go through LDS, and every thread
+// then writes whole vectors of eight consecutive features, pairing the "sin" vector of eight (degree, direction) features with its "cos" vector
+// 21 L features later (same damping factor).  Needs 21 * L to be a multiple of 8.  Same per-feature expressions as k_cast_ipe_360: same bits.
+//   FRAG (bf16 only): the MFMA B-operand fragments of enc360_index -- lane n of a vector = sample n, so a wave's stores are lane-linear; the
+//     buffer covers whole 256-sample tiles (an even number of wave tiles), samples past the end repeat the last one;
+//   rows: row-major [M, F]: consecutive threads write consecutive 8-feature runs of one sample's row.
 constexpr int kFragSamples = 64;
+template <typename OutT, bool FRAG>
 __global__ void __launch_bounds__(256)
-k_cast_ipe_360_frag(int64_t B, int N, int min_deg, int L, int contracted, const float* __restrict__ t, const float* __restrict__ origins,
-                    const float* __restrict__ dirs, const float* __restrict__ radii, __bf16* __restrict__ enc) {
-    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+k_cast_ipe_360_tile(int64_t B, int N, int min_deg, int L, int contracted, const float* __restrict__ t, const float* __restrict__ origins,
+                    const float* __restrict__ dirs, const float* __restrict__ radii, OutT* __restrict__ enc) {
+    typedef OutT vec8 __attribute__((ext_vector_type(8)));
     __shared__ GaussFull sg[kFragSamples];
     __shared__ float sy[kFragSamples][kBasis360N], sv[kFragSamples][kBasis360N];
     const int tid = threadIdx.x;
@@ -115,24 +118,30 @@ k_cast_ipe_360_frag(int64_t B, int N, int min_deg, int L, int contracted, const 
         sv[m][j] = var;
     }
     __syncthreads();
-    const int nq = kBasis360N * L / 8;          // vectors per half (42 for 16 degrees); k-steps per sample = nq
-    bf16x8* out = reinterpret_cast<bf16x8*>(enc) + (s0 >> 5) * (int64_t)(nq * 64);
+    const int nq = kBasis360N * L / 8;          // vectors per half (42 for 16 degrees); fragment layout: k-steps per sample = nq
     for (int w = tid; w < kFragSamples * nq; w += 256) {
-        const int m = w & 63, q = w >> 6;       // consecutive threads = consecutive samples of the same vector index
-        bf16x8 fs, fc;
+        // FRAG: consecutive threads = consecutive samples of one vector index; rows: consecutive vector indices of one sample
+        const int m = FRAG ? (w & 63) : w / nq, q = FRAG ? (w >> 6) : w - (w / nq) * nq;
+        vec8 fs, fc;
         int l = (q * 8) / kBasis360N, j = q * 8 - l * kBasis360N;       // (degree, direction) of the vector's first feature, then stepped
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            __bf16 a, c;
-            ipe360_pair<__bf16>(sy[m][j], sv[m][j], l, min_deg, a, c);
+            OutT a, c;
+            ipe360_pair<OutT>(sy[m][j], sv[m][j], l, min_deg, a, c);
             fs[i] = a;
             fc[i] = c;
             if (++j == kBasis360N) { j = 0; ++l; }
         }
-        // feature f = 8 q + i of sample m: wave tile m / 32, k-step q / 2, lane half q % 2, lane m % 32; the "cos" half starts nq vectors later
-        bf16x8* o = out + (m >> 5) * (nq * 64) + (m & 31);
-        o[(q >> 1) * 64 + (q & 1) * 32] = fs;
-        o[((q + nq) >> 1) * 64 + ((q + nq) & 1) * 32] = fc;
+        if (FRAG) {
+            // feature f = 8 q + i of sample m: wave tile m / 32, k-step q / 2, lane half q % 2, lane m % 32; the "cos" half starts nq vectors later
+            vec8* o = reinterpret_cast<vec8*>(enc) + (s0 >> 5) * (int64_t)(nq * 64) + (m >> 5) * (nq * 64) + (m & 31);
+            o[(q >> 1) * 64 + (q & 1) * 32] = fs;
+            o[((q + nq) >> 1) * 64 + ((q + nq) & 1) * 32] = fc;
+        } else if (s0 + m < M) {
+            vec8* row = reinterpret_cast<vec8*>(enc + (s0 + m) * (int64_t)(16 * nq));
+            row[q] = fs;
+            row[q + nq] = fc;
+        }
     }
 }
 
@@ -241,10 +250,13 @@ hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int c
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     const int L = max_deg - min_deg;
     if (frag && (!bf16 || (2 * kBasis360N * L) % 16 != 0)) return hipErrorInvalidValue;
-    if (frag && enc && !means && (kBasis360N * L) % 8 == 0) {
-        const int64_t wts = (B * (int64_t)N + kFragSamples - 1) / kFragSamples;
-        if (wts > 0x7fffffff) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_cast_ipe_360_frag, dim3((unsigned)wts), block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii, (__bf16*)enc);
+    if (enc && !means && (kBasis360N * L) % 8 == 0) {         // only the encoding: the tiled kernel (one Gaussian per sample, vector stores)
+        const int64_t wgs = (B * (int64_t)N + kFragSamples - 1) / kFragSamples;
+        if (wgs > 0x7fffffff) return hipErrorInvalidValue;
+        const dim3 g((unsigned)wgs);
+        if (frag) hipLaunchKernelGGL((k_cast_ipe_360_tile<__bf16, true>), g, block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii, (__bf16*)enc);
+        else if (bf16) hipLaunchKernelGGL((k_cast_ipe_360_tile<__bf16, false>), g, block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii, (__bf16*)enc);
+        else hipLaunchKernelGGL((k_cast_ipe_360_tile<float, false>), g, block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii, (float*)enc);
         return hipGetLastError();
     }
     if (bf16)

@@ -182,3 +182,32 @@ def test_unbounded_model_trains_in_fp32(G):
     assert torch.equal(f3, f4) and torch.equal(c3, c4) and not torch.equal(f3, f_rgb)
     assert float((f3 - f_rgb).abs().max()) <= 3e-2
     system.mip_nerf.set_precision("fp32")
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 13), (40, 64)])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_tiled_encoding_kernel_equals_the_per_direction_kernel(G, shape, precision):
+    """mipnerf_cast_ipe_360 asked for the encoding only runs the tiled kernel (one Gaussian per sample, vector stores; round 4); asked for the
+    Gaussians as well it runs the per-(sample, direction) kernel of round 3.  Same per-feature expressions: the same bits, in both output types,
+    at ragged sample counts (the row-major buffer ends exactly at the last sample: nothing may be written behind it)."""
+    import ctypes as C
+    from mipnerf_pl_amd import _lib as L
+    from mipnerf_pl_amd import ops
+    B, N = shape
+    rays = G.to_dev(syn.synthetic_rays(B, seed=B + N, unbounded=True))
+    t_inv, t = ops.sample_t_360(N, rays.near, rays.far, False)
+    prec = L.PREC_BF16 if precision == "bf16" else L.PREC_FP32
+    dt = torch.bfloat16 if precision == "bf16" else torch.float32
+    guard = 64
+    a = torch.full((B * N * 672 + guard,), 7.0, device=DEV, dtype=dt)          # canary behind the last row
+    b = torch.empty(B * N * 672, device=DEV, dtype=dt)
+    means = torch.empty(B, N, 3, device=DEV)
+    covs = torch.empty(B, N, 3, 3, device=DEV)
+    o, d, r = rays.origins.contiguous(), rays.directions.contiguous(), rays.radii.contiguous()
+    P = lambda x: C.c_void_p(x.data_ptr())                                       # noqa: E731
+    L.check(L.lib().mipnerf_cast_ipe_360(B, N, 0, 16, 1, P(t), P(o), P(d), P(r), P(a), prec, None, None, ops._stream()), "tiled")
+    L.check(L.lib().mipnerf_cast_ipe_360(B, N, 0, 16, 1, P(t), P(o), P(d), P(r), P(b), prec, P(means), P(covs), ops._stream()), "per-direction")
+    torch.cuda.synchronize()
+    assert torch.equal(a[:B * N * 672], b)
+    assert bool((a[B * N * 672:] == 7.0).all())
+    assert bool(torch.isfinite(b.float()).all())
