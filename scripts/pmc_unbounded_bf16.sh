@@ -16,7 +16,7 @@ def means(counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
         n = r["Kernel_Name"]
-        k = "k_cast_ipe_360_frag" if "cast_ipe_360_frag" in n else "k_pre_gemm" if "k_pre_gemm" in n else "k_mlp_bf16 (trunk)" if "k_mlp_bf16" in n else None
+        k = "k_cast_ipe_360_tile" if "cast_ipe_360_tile" in n else "k_pre_gemm" if "k_pre_gemm" in n else "k_mlp_bf16 (trunk)" if "k_mlp_bf16" in n else None
         if k:
             acc[k].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}

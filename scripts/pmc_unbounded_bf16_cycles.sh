@@ -14,7 +14,7 @@ d = sys.argv[1]
 M = 8192 * 256
 rows = list(csv.DictReader(open(glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0])))
 trace = list(csv.DictReader(open(glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0])))
-for key, name, mfma_per_wave_tile in (("k_pre_gemm", "k_pre_gemm", 672), ("v4pre", "trunk k_mlp_bf16", 1120), ("cast_ipe_360_frag", "k_cast_ipe_360_frag", 0)):
+for key, name, mfma_per_wave_tile in (("k_pre_gemm", "k_pre_gemm", 672), ("v4pre", "trunk k_mlp_bf16", 1120), ("cast_ipe_360_tile", "k_cast_ipe_360_tile", 0)):
     acc = collections.defaultdict(list)
     for r in rows:
         if key in r["Kernel_Name"]:
