@@ -49,7 +49,7 @@ template <typename OutT> struct Ipe360Math;
 template <> struct Ipe360Math<float> {
     // sin(x) and "cos" = sin(fl32(x + fl32(pi/2))), the reference's form (mip.py:349-350)
     __device__ static void sincos(float x, float& s, float& c) { s = sin_accurate(x); c = sin_accurate(x + kHalfPiF); }
-    __device__ static float exp(float x) { return exp_accurate(x); }
+    __device__ static float damp(float vs) { return exp_accurate(-0.5f * vs); }       // exp(-0.5 * 4^l var), the reference's expression
 };
 template <> struct Ipe360Math<__bf16> {
     // ONE range reduction for the pair, in two-float fp32 arithmetic (x is up to 2^16 rad at the top degree; the fp64 form of sin_fast costs
@@ -66,16 +66,19 @@ template <> struct Ipe360Math<__bf16> {
         s = __builtin_amdgcn_sinf(rf);
         c = __builtin_amdgcn_sinf(rf + 0.25f);
     }
-    __device__ static float exp(float x) { return exp_fast(x); }
+    __device__ static float damp(float vs) { return __builtin_amdgcn_exp2f(vs * -0.72134752f); }      // exp(-0.5 vs) = 2^(-0.5 log2(e) vs): one multiply
 };
 // off-axis IPE feature pair (l, basis j) from the projection (y, var): exp(-0.5 * 4^l var) * (sin(2^l y), sin(2^l y + pi/2));
 // the expressions of raymath360.hpp:ipe360_feature
 template <typename OutT>
 __device__ __forceinline__ void ipe360_pair(float y, float var, int l, int min_deg, OutT& fs, OutT& fc) {
-    const float scale = (float)(1u << (l + min_deg));
+    // 2^e and 4^e assembled from the exponent (the same values as (float)(1u << e) and its square, e <= 31, without a conversion per feature;
+    // with a wave-uniform l they stay in scalar registers)
+    const int e = l + min_deg;
+    const float scale = __builtin_bit_cast(float, (e + 127) << 23);
     const float ys = y * scale;
-    const float vs = var * (scale * scale);
-    const float damp = Ipe360Math<OutT>::exp(-0.5f * vs);
+    const float vs = var * __builtin_bit_cast(float, (2 * e + 127) << 23);
+    const float damp = Ipe360Math<OutT>::damp(vs);
     float sn, cs;
     Ipe360Math<OutT>::sincos(ys, sn, cs);
     fs = (OutT)(damp * sn);
@@ -96,8 +99,11 @@ __global__ void __launch_bounds__(256)
 k_cast_ipe_360_tile(int64_t B, int N, int min_deg, int L, int contracted, const float* __restrict__ t, const float* __restrict__ origins,
                     const float* __restrict__ dirs, const float* __restrict__ radii, OutT* __restrict__ enc) {
     typedef OutT vec8 __attribute__((ext_vector_type(8)));
+    // projections of a sample: its 21 directions followed by the first 7 again, so that the eight consecutive features of a vector
+    // (directions j0 .. j0 + 7, wrapping into the next degree) are eight consecutive LDS words -- one address per vector, literal offsets
+    constexpr int kRow = kBasis360N + 7;
     __shared__ GaussFull sg[kFragSamples];
-    __shared__ float sy[kFragSamples][kBasis360N], sv[kFragSamples][kBasis360N];
+    __shared__ float sy[kFragSamples][kRow], sv[kFragSamples][kRow];
     const int tid = threadIdx.x;
     const int64_t s0 = (int64_t)blockIdx.x * kFragSamples, M = B * (int64_t)N;
     if ((tid >> 6) == (int)(blockIdx.x & 3)) {
@@ -110,27 +116,30 @@ k_cast_ipe_360_tile(int64_t B, int N, int min_deg, int L, int contracted, const 
         sg[m] = conical_frustum_to_gaussian_full(t[b * (N + 1) + i], t[b * (N + 1) + i + 1], d, o, radii[b], contracted != 0);
     }
     __syncthreads();
-    for (int idx = tid; idx < kFragSamples * kBasis360N; idx += 256) {
-        const int m = idx / kBasis360N, j = idx - m * kBasis360N;
+    for (int idx = tid; idx < kFragSamples * kRow; idx += 256) {
+        const int m = idx / kRow, jj = idx - m * kRow;
         float y, var;
-        project_360(sg[m], j, y, var);
-        sy[m][j] = y;
-        sv[m][j] = var;
+        project_360(sg[m], jj < kBasis360N ? jj : jj - kBasis360N, y, var);
+        sy[m][jj] = y;
+        sv[m][jj] = var;
     }
     __syncthreads();
     const int nq = kBasis360N * L / 8;          // vectors per half (42 for 16 degrees); fragment layout: k-steps per sample = nq
     for (int w = tid; w < kFragSamples * nq; w += 256) {
         // FRAG: consecutive threads = consecutive samples of one vector index; rows: consecutive vector indices of one sample
-        const int m = FRAG ? (w & 63) : w / nq, q = FRAG ? (w >> 6) : w - (w / nq) * nq;
+        // (FRAG: q is the same for the 64 threads of a wave -- readfirstlane tells the compiler, so the (degree, direction) stepping, the
+        // frequency scales and the LDS column offsets below become scalar work)
+        const int m = FRAG ? (w & 63) : w / nq, q = FRAG ? __builtin_amdgcn_readfirstlane(w >> 6) : w - (w / nq) * nq;
         vec8 fs, fc;
-        int l = (q * 8) / kBasis360N, j = q * 8 - l * kBasis360N;       // (degree, direction) of the vector's first feature, then stepped
+        const int l0 = (q * 8) / kBasis360N, j0 = q * 8 - l0 * kBasis360N;       // (degree, direction) of the vector's first feature
+        const float* py = &sy[m][j0];
+        const float* pv = &sv[m][j0];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             OutT a, c;
-            ipe360_pair<OutT>(sy[m][j], sv[m][j], l, min_deg, a, c);
+            ipe360_pair<OutT>(py[i], pv[i], l0 + (j0 + i >= kBasis360N ? 1 : 0), min_deg, a, c);      // past direction 20: the next degree
             fs[i] = a;
             fc[i] = c;
-            if (++j == kBasis360N) { j = 0; ++l; }
         }
         if (FRAG) {
             // feature f = 8 q + i of sample m: wave tile m / 32, k-step q / 2, lane half q % 2, lane m % 32; the "cos" half starts nq vectors later
