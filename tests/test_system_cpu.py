@@ -212,3 +212,23 @@ def test_bench_scale_model_and_pmc_round_rule(tmp_path):
     # the committed file is this round's
     t, src = bench.pmc_traffic("inference", "bf16", 524288)
     assert t and t > 12124160 and "round" in src
+
+
+def test_unbounded_model_precision_rules_on_the_host():
+    """MipNerf(unbounded=True): fp32 unless asked otherwise; bf16 is accepted (inference kernels exist since round 4) and can be switched to on
+    a live model; an unknown precision is refused; the 672-wide first layer / skip concat follow from 42 features per degree"""
+    import pytest
+    from mipnerf_pl_amd import MipNerf
+    from mipnerf_pl_amd import _lib as L
+    m = MipNerf(num_samples=8, unbounded=True)
+    assert m.precision == L.PREC_FP32 and m.mlp.precision == L.PREC_FP32
+    assert tuple(m.mlp.layers[0][0].weight.shape) == (256, 672) and tuple(m.mlp.layers[5][0].weight.shape) == (256, 256 + 672)
+    b = MipNerf(num_samples=8, unbounded=True, precision="bf16")
+    assert b.precision == L.PREC_BF16 and b.mlp.precision == L.PREC_BF16
+    assert m.set_precision("bf16") is m and m.precision == L.PREC_BF16 and m.mlp.precision == L.PREC_BF16
+    m.set_precision("fp32")
+    assert m.precision == L.PREC_FP32
+    with pytest.raises(ValueError):
+        m.set_precision("fp16")
+    with pytest.raises(NotImplementedError):
+        MipNerf(num_samples=8, unbounded=True, disparity=True)
