@@ -63,6 +63,10 @@ def test_bench_single_gpu_line():
     assert 0.5 < sm["predicted"]["8"]["train_weak_efficiency"] < 1 and 0.5 < sm["predicted"]["8"]["render_strong_efficiency"] <= 1
     # ... and the same batch through the unbounded-scene model (configs[3] says "360 unbounded")
     assert line["fp32"]["unbounded"].get("finite") is True and line["fp32"]["unbounded"]["frac"] > 0.3, line["fp32"]["unbounded"]
+    # round 4: ... and in bf16 (k_pre_gemm + trunk kernel): several times faster than its fp32 forward, close to its frame
+    ub = line["fp32"]["unbounded"]["bf16"]
+    assert ub.get("finite") is True and ub["frac"] > 0.25 and ub["psnr_vs_fp32_frame_db"] > 45, ub
+    assert ub["ms_per_step"] < 0.4 * line["fp32"]["unbounded"]["ms_per_step"], (ub, line["fp32"]["unbounded"])
 
 
 @pytest.mark.gpu
