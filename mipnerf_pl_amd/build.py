@@ -47,7 +47,9 @@ UNITS = [
 DIAG_LIB = os.path.join(CSRC, "libmipnerf_diag.so")
 DIAG_UNITS = [("kernels_diag.hip", []), ("diag_capi.hip", [])]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
-          "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
+          "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result",
+          # range reduction of the bf16 pipeline's fast sine (raymath.hpp: sin_fast): 1 = two-float fp32, 0 = fp64
+          "-DMIP_SIN_FAST_TWOFLOAT=" + os.environ.get("MLP_SIN_TWOFLOAT", "0")]
 
 
 def hipcc() -> str:

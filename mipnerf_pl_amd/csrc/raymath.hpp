@@ -65,10 +65,24 @@ MIP_HD float exp_accurate(float x) { return expf(x); }
 // exact argument reduction in fp64 -- x/(2 pi) is formed with a 53-bit product, so even at |x| = 3e5 rad
 // the reduced phase is good to 1e-11 turns -- followed by the hardware v_sin_f32 (input in turns) and
 // v_exp_f32.  ~12 issue slots instead of ~150 for the accurate libm pair.
+#ifndef MIP_SIN_FAST_TWOFLOAT
+#define MIP_SIN_FAST_TWOFLOAT 0
+#endif
 __device__ __forceinline__ float sin_fast(float x) {
+#if MIP_SIN_FAST_TWOFLOAT
+    // the same reduction in two-float fp32 arithmetic (six full-rate instructions instead of five half-/quarter-rate fp64 ones): 1 / 2 pi = hi + lo,
+    // p = fl(x hi), e = x hi - p exactly (fma), t = fl(x lo + e), frac(x / 2 pi) = (p - rint(p)) + t with an exact subtraction; 2.6e-8 turns
+    // against the fp64 form on 2e5 arguments up to 2^17 rad (build knob MLP_SIN_TWOFLOAT, see build.py)
+    constexpr float kHi = 0.15915494f, kLo = 6.4206382e-09f;
+    const float p = x * kHi;
+    const float e = __builtin_fmaf(x, kHi, -p);
+    const float t = __builtin_fmaf(x, kLo, e);
+    return __builtin_amdgcn_sinf((p - __builtin_rintf(p)) + t);
+#else
     double r = (double)x * 0.15915494309189535;   // 1 / (2 pi)
     r -= rint(r);                                 // [-0.5, 0.5] turns
     return __builtin_amdgcn_sinf((float)r);
+#endif
 }
 __device__ __forceinline__ float exp_fast(float x) { return __expf(x); }
 #endif
