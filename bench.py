@@ -390,6 +390,22 @@ def pmc_traffic(kind, precision, samples_per_launch=None, path=None):
     return None, None
 
 
+def unbounded_bf16_traffic(samples_per_launch, path=None):
+    """HBM bytes per launch of the three kernels of the unbounded model's bf16 forward, from this round's separate --pmc passes
+    (profiles/mlp_pmc.json: "unbounded_bf16", scripts/pmc_unbounded_bf16.sh); None when the file is another round's or another size's"""
+    path = path or os.path.join(REPO, "profiles", "mlp_pmc.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        pj = json.load(f)
+    u = pj.get("unbounded_bf16")
+    if pj.get("round") != CURRENT_ROUND or not u or u.get("samples_per_launch") != samples_per_launch:
+        return None
+    out = {k: v["hbm_bytes_per_launch"] for k, v in u["kernels"].items()}
+    out["source"] = f"profiles/mlp_pmc.json (rocprofv3 --pmc passes of round {CURRENT_ROUND}, not this run)"
+    return out
+
+
 def measure_one_rank_rccl_allreduce(numel, dev):
     """N = 1 only: what ONE gradient all-reduce costs on the launch stream before any byte crosses a link -- a 1-rank RCCL communicator
     on this GPU (HIP events around all_reduce + wait, like GraphedTrainStep's collective form).  Runs in a CHILD process with a hard
@@ -622,7 +638,7 @@ def run_fp32_c4(args, e):
                            "mlp_ms_per_level": round(blaunch, 4), "achieved": round(btf, 2), "peak": PEAK_TFLOPS["bf16"],
                            "frac": round(btf / PEAK_TFLOPS["bf16"], 4), "kernels": "k_pre_gemm + k_mlp_bf16 (trunk), timed together per level",
                            "psnr_vs_fp32_frame_db": round(float(-10 * math.log10(max(mse, 1e-20))), 2),
-                           "finite": bool(torch.isfinite(bout[-1][0]).all())}
+                           "finite": bool(torch.isfinite(bout[-1][0]).all()), "traffic": unbounded_bf16_traffic(M)}
         except Exception as ex:  # noqa: BLE001
             unb["bf16"] = {"error": f"{type(ex).__name__}: {ex}"}
     except Exception as ex:  # noqa: BLE001  (an extra must not take the record down)
