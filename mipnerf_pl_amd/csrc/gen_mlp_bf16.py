@@ -43,6 +43,9 @@ SETPRIO = os.environ.get("MLP_SETPRIO", "1") == "1"
 # that reads the encoding: its LDS area is free from there on) instead of in a VALU-only phase at the start of every tile.
 IPE_SHADOW = os.environ.get("MLP_IPE_SHADOW", "0") == "1"    # measured: -0.56 % cycles, +0.25 % time (profiles/r03f_ipe_shadow_ab.txt): off
 IPE_SHADOW_STRIDE = int(os.environ.get("MLP_IPE_SHADOW_STRIDE", "4"))    # one piece every STRIDE slots
+# trunk kernels of the two-kernel form: pre_x / pre_acc (read once, 1.5 KB per sample) with the non-temporal policy, so that they do not push the weight
+# stream out of the L2: 7.803 / 7.812 / 7.819 vs 7.835 / 7.837 / 7.862 ms per forward in three alternating pairs (-0.4 %, profiles/r04z_trunk_nt_loads_ab.txt)
+PRE_NT = os.environ.get("MLP_PRE_NT_LOADS", "1") == "1"
 NE = 3                # rotating registers for LDS-resident B operands (E0..E2)
 ENC_WAVE_BYTES = 8192  # wave-private LDS: 6 KiB encoding + 2 KiB view encoding
 
@@ -250,13 +253,17 @@ __device__ __forceinline__ void epilogue_half(const f32x16& acc, bf16x8& o) {
     }
 }
 
+// (PRE_LD: read-once data of the trunk kernels -- plain or non-temporal loads, build knob MLP_PRE_NT_LOADS)
+#ifndef PRE_LD
+#define PRE_LD(ptr) (*(ptr))
+#endif
 // Trunk kernels of the two-kernel form (mlp_pre_plan.py): one accumulator tile as k_pre_gemm stored it -- registers 4q .. 4q+3 of every
 // lane form one lane-linear 1-KiB row, four rows per tile.
 typedef __attribute__((ext_vector_type(4))) float f32x4_;
 __device__ __forceinline__ void pre_load(f32x16& acc, const char* p) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4_ v = *reinterpret_cast<const f32x4_*>(p + q * 1024);
+        const f32x4_ v = PRE_LD(reinterpret_cast<const f32x4_*>(p + q * 1024));
         acc[4 * q] = v[0]; acc[4 * q + 1] = v[1]; acc[4 * q + 2] = v[2]; acc[4 * q + 3] = v[3];
     }
 }
@@ -471,6 +478,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         e(f"namespace v{variant}{'pre' if pre else ''} {{")
     e("typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;")
     e("typedef __attribute__((ext_vector_type(16))) float f32x16;")
+    if pre and PRE_NT:
+        e("#define PRE_LD(ptr) __builtin_nontemporal_load(ptr)")
     e(f"constexpr int kRingBytes = {ring_bytes};")
     e(f"constexpr int kBiasBytes = {nbias_bytes};")
     e(f"constexpr int kEncOff = {enc_off};")
@@ -539,7 +548,7 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         e("        const char* prex_lane = pre_x + wt * 16384 + lane16;")
         e("        const char* pre_lane = pre_acc + wt * 32768 + lane16;")
         for k in range(16):
-            e(f"        X[{k}] = *reinterpret_cast<const bf16x8*>(prex_lane + {k * 1024});")
+            e(f"        X[{k}] = PRE_LD(reinterpret_cast<const bf16x8*>(prex_lane + {k * 1024}));")
     e("        f32x16 acc00, acc01, acc10, acc11;")
     e("        float raw_density = 0.0f, raw_r = 0.0f, raw_g = 0.0f, raw_b = 0.0f;")
 
