@@ -169,7 +169,7 @@ def test_generated_trunk(vi):
     them), one extra ring barrier for the zero-padding group, and the register hazard replay of gen_mlp_bf16 passed (it asserts)"""
     p = PrePlan.build(gb.VARIANTS[vi])
     src = gb.gen_kernel(p.trunk, vi)
-    assert len(re.findall(r"X\[\d+\] = \*reinterpret_cast<const bf16x8\*>\(prex_lane", src)) == 16
+    assert len(re.findall(r"X\[\d+\] = PRE_LD\(reinterpret_cast<const bf16x8\*>\(prex_lane", src)) == 16
     assert sorted(int(x) for x in re.findall(r"pre_load\(acc\d\d, pre_lane \+ (\d+)\);", src)) == [t * 4096 for t in range(8)]
     skip_first = p.trunk.ops[p.skip_layer - 1].first_tile
     bias_tiles = {int(x) for x in re.findall(r"BIAS\(acc\d\d, (\d+)\);", src)}
