@@ -52,6 +52,22 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"
           "-DMIP_SIN_FAST_TWOFLOAT=" + os.environ.get("MLP_SIN_TWOFLOAT", "0")]
 
 
+# Timing-experiment knobs whose build gives WRONG results (value = the harmless default).  A stale variable in the environment must not
+# silently produce a product library with wrong gradients: such a build needs MIPNERF_EXPERIMENT_BUILD=1 AND its own MIPNERF_LIB_NAME, and
+# the library it produces refuses mipnerf_create() unless the process sets MIPNERF_ALLOW_EXPERIMENT_LIB=1 (capi.hip).
+WRONG_RESULT_KNOBS = {"MLP_ABLATE_BARRIER": "0", "MLP_ABLATE_WAIT": "0", "MLP_ABLATE_LDA": "0", "MLP_F32R_GEN_ABLATE": "0", "MLP_F32R_ABLATE": "",
+                      "MLP_TRAIN_ABLATE_TMFMA": "0", "MLP_WGRAD_TR": "0", "MLP_TRAIN_SKIP_STORES": "0", "MLP_WGRAD_RECOMPUTE_PROBE": "0"}
+
+
+def experiment_flags():
+    """The wrong-result knobs that are switched on, as "NAME=value ..." ("" for a product build); raises when they are set without the opt-in."""
+    on = [f"{k}={os.environ[k]}" for k, d in sorted(WRONG_RESULT_KNOBS.items()) if os.environ.get(k, d) != d]
+    if on and (os.environ.get("MIPNERF_EXPERIMENT_BUILD") != "1" or os.path.basename(LIB) == "libmipnerf_hip.so"):
+        raise RuntimeError("timing-experiment variables are set (" + " ".join(on) + "): they produce WRONG results.  Unset them, or opt in with "
+                           "MIPNERF_EXPERIMENT_BUILD=1 and a MIPNERF_LIB_NAME other than libmipnerf_hip.so")
+    return " ".join(on)
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -127,12 +143,14 @@ def tables_object() -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    experiment_flags()            # refuse BEFORE the generators overwrite the tracked sources with an ablated form
     generate()
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".bin"))]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "mipnerf_hip.h"))
     deps.append(os.path.join(os.path.dirname(HERE), "include", "mipnerf_diag.h"))
     stamp = os.path.join(CSRC, ".build_stamp_" + os.path.basename(LIB))
-    units = UNITS[:-1] + variant_units() + UNITS[-1:]          # capi.hip last
+    exp = experiment_flags()
+    units = UNITS[:-1] + variant_units() + [("capi.hip", ['-DMIPNERF_EXPERIMENT_BUILD="%s"' % exp] if exp else [])]          # capi.hip last
     dig = _digest(deps, COMMON + sum((f for _, f in units), []) + [f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MLP_")])
     if not force and os.path.exists(LIB) and os.path.exists(DIAG_LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         if verbose:

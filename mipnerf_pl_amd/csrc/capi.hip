@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -277,6 +278,9 @@ struct mipnerf_ctx {
     float* d_pre_trunk_bias = nullptr;
     void* d_pre_scratch = nullptr;   // pre_x | pre_acc of mipnerf_mlp_forward (mipnerf_forward carves them out of the caller's workspace)
     size_t pre_scratch_bytes = 0;
+    hipEvent_t pre_scratch_event = nullptr;     // recorded behind the last user's kernels: another stream waits for it before it overwrites the buffer
+    void* pre_scratch_stream = nullptr;
+    bool pre_scratch_used = false;
     // training (bf16): W^T stream of the dgrad kernel, wgrad job tables
     TrainTables tt;
     int32_t* d_pack_dgrad = nullptr;
@@ -407,6 +411,13 @@ int mipnerf_variant_arch(int variant, mipnerf_config* cfg, int* has_bf16_trainin
 int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
     using namespace mip::plan;
     if (!cfg || !out) return fail(MIPNERF_E_INVALID, "null argument");
+#ifdef MIPNERF_EXPERIMENT_BUILD
+    // build.py compiled this library with timing-experiment knobs that produce WRONG results (ablated barriers / operand reads /
+    // transposing MFMAs ...): it refuses to serve unless the process says it knows
+    if (!getenv("MIPNERF_ALLOW_EXPERIMENT_LIB"))
+        return fail(MIPNERF_E_UNSUPPORTED, "this library is a timing-experiment build (" MIPNERF_EXPERIMENT_BUILD "): its results are wrong by "
+                                           "construction; set MIPNERF_ALLOW_EXPERIMENT_LIB=1 to time it, or rebuild without those variables");
+#endif
     if (cfg->num_samples < 1 || cfg->num_samples > MIPNERF_MAX_SAMPLES)
         return fail(MIPNERF_E_INVALID, "num_samples must be in [1, %d]", MIPNERF_MAX_SAMPLES);
     if (cfg->num_levels < 1 || cfg->num_levels > 2) return fail(MIPNERF_E_UNSUPPORTED, "num_levels must be 1 or 2");
@@ -561,6 +572,7 @@ int mipnerf_destroy(mipnerf_ctx* c) {
     for (int i = 0; i < 4; ++i) (void)hipFree(c->d_pre_idx[i]);
     (void)hipFree(c->d_pre_gemm_stream); (void)hipFree(c->d_pre_gemm_bias); (void)hipFree(c->d_pre_trunk_stream); (void)hipFree(c->d_pre_trunk_bias);
     (void)hipFree(c->d_pre_scratch);
+    if (c->pre_scratch_event) (void)hipEventDestroy(c->pre_scratch_event);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     delete c;
     return MIPNERF_OK;
@@ -595,7 +607,9 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
     // transposed (dgrad) stream and W_extra^T (a gather through an index table like the others)
     mip::PackSegments sg;
     memset(&sg, 0, sizeof sg);
+    bool sg_overflow = false;
     auto add = [&](const int32_t* table, int64_t n, void* out, bool bf16) {
+        if (sg.n >= mip::kMaxPackSegments) { sg_overflow = true; return; }       // checked BEFORE the arrays are written
         sg.table[sg.n] = table; sg.out[sg.n] = out; sg.bf16[sg.n] = bf16 ? 1 : 0;
         sg.start[sg.n + 1] = sg.start[sg.n] + n;
         ++sg.n;
@@ -617,7 +631,7 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
         add(c->d_pre_idx[2], (int64_t)c->pre.n_trunk_chunks * 512, c->d_pre_trunk_stream, true);
         add(c->d_pre_idx[3], (int64_t)c->pre.n_trunk_tiles * 32, c->d_pre_trunk_bias, false);
     }
-    if (sg.n > mip::kMaxPackSegments) return fail(MIPNERF_E_INVALID, "set_params: %d pack segments, the library handles %d", sg.n, mip::kMaxPackSegments);
+    if (sg_overflow) return fail(MIPNERF_E_INVALID, "set_params: more than %d pack segments", mip::kMaxPackSegments);
     HIP_TRY(mip::launch_pack_multi(sg, pp, S(stream)));
     c->pp = pp;
     c->params_set = true;
@@ -682,14 +696,22 @@ static int mlp_forward_noise(mipnerf_ctx* c, int64_t M, int32_t N, const void* e
             // the two-kernel form needs 1.5 KiB of scratch per sample between its kernels; this per-stage entry point has no workspace
             // argument, so the context keeps a buffer that grows on demand (hipMalloc: not capturable -- mipnerf_forward uses the caller's)
             const size_t need = pre_x_bytes(M) + pre_acc_bytes(M);
+            // ONE buffer per context: a call on another stream than the previous one waits for that call's kernels (event recorded behind
+            // them below) before it overwrites the buffer; a regrow waits for every user
+            if (!c->pre_scratch_event) { HIP_TRY(hipEventCreateWithFlags(&c->pre_scratch_event, hipEventDisableTiming)); }
             if (need > c->pre_scratch_bytes) {
                 HIP_TRY(hipStreamSynchronize(S(stream)));
+                if (c->pre_scratch_used) { HIP_TRY(hipEventSynchronize(c->pre_scratch_event)); }
                 (void)hipFree(c->d_pre_scratch);
                 c->d_pre_scratch = nullptr; c->pre_scratch_bytes = 0;
                 HIP_TRY(hipMalloc(&c->d_pre_scratch, need));
                 c->pre_scratch_bytes = need;
+            } else if (c->pre_scratch_used && c->pre_scratch_stream != stream) {
+                HIP_TRY(hipStreamWaitEvent(S(stream), c->pre_scratch_event, 0));
             }
             HIP_TRY(launch_bf16_pre(c, enc, 0, viewenc, rgb_sigma, raw, M, N, c->d_pre_scratch, (char*)c->d_pre_scratch + pre_x_bytes(M), dnoise, S(stream)));
+            HIP_TRY(hipEventRecord(c->pre_scratch_event, S(stream)));
+            c->pre_scratch_stream = stream; c->pre_scratch_used = true;
             return MIPNERF_OK;
         }
         HIP_TRY(launch_bf16_variant(c, enc, viewenc, rgb_sigma, raw, M, N, c->mlp_dma != 0, nullptr, dnoise, S(stream)));
@@ -1381,8 +1403,12 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
                                                       t_inv[lvl], stream))) return rc;
                 HIP_TRY(mip::launch_reciprocal((int64_t)B * (N + 1), t_inv[lvl], o.t_samples, S(stream)));
             }
+            // dtype of the encoding = the precision (fragments when the two-kernel form will read them); an unbounded variant with bf16
+            // kernels of some OTHER form must not be handed fp32 rows here
+            if (precision == MIPNERF_PREC_BF16 && !pre_form)
+                return fail(MIPNERF_E_UNSUPPORTED, "forward: bf16 inference of an unbounded variant needs the two-kernel (pre-GEMM) form");
             HIP_TRY(mip::launch_cast_ipe_360(B, N, cfg.min_deg_point, cfg.max_deg_point, 1, o.t_samples, rays->origins, rays->directions,
-                                             rays->radii, enc, pre_form, nullptr, nullptr, S(stream), pre_form));
+                                             rays->radii, enc, precision == MIPNERF_PREC_BF16, nullptr, nullptr, S(stream), pre_form));
         } else if (lvl == 0) {
             if (!have_t0 && (rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, o.t_samples, stream))) return rc;
         } else if (!have_resampled) {

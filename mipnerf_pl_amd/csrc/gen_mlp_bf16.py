@@ -722,15 +722,17 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e(f"    grid_limit *= {WG_PER_CU};      // workgroups per CU (LDS: {lds_bytes} B each)")
     e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
     e("    if (grid < 1) grid = 1;")
-    e("    static bool attr_done = false;")
-    e("    if (!attr_done) {")
+    e("    static int attr_done[64] = {};")
+    e("    int dev = 0;")
+    e("    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;")
+    e("    if (!attr_done[dev]) {")
     e("        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_bf16<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
     e("        if (er != hipSuccess) return er;")
     e("        er = hipFuncSetAttribute((const void*)k_mlp_bf16<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
     e("        if (er != hipSuccess) return er;")
     e("        er = hipFuncSetAttribute((const void*)k_mlp_bf16<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
     e("        if (er != hipSuccess) return er;")
-    e("        attr_done = true;")
+    e("        attr_done[dev] = 1;")
     e("    }")
     e("    RayIn rin = {nullptr, nullptr, nullptr, nullptr, 0, 0};")
     e("    if (rays) rin = RayIn{rays->t, rays->origins, rays->dirs, rays->radii, rays->min_deg, rays->disable_integration};")

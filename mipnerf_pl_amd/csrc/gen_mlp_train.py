@@ -497,13 +497,15 @@ def gen_trainfwd(tp: TrainPlan, variant: int = 0) -> str:
     e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
     e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
     e("    if (grid < 1) grid = 1;")
-    e("    static bool attr_done = false;")
-    e("    if (!attr_done) {")
+    e("    static int attr_done[64] = {};")
+    e("    int dev = 0;")
+    e("    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;")
+    e("    if (!attr_done[dev]) {")
     e("        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_bf16_trainfwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
     e("        if (er != hipSuccess) return er;")
     e("        er = hipFuncSetAttribute((const void*)k_mlp_bf16_trainfwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
     e("        if (er != hipSuccess) return er;")
-    e("        attr_done = true;")
+    e("        attr_done[dev] = 1;")
     e("    }")
     e("    RayIn rin = {nullptr, nullptr, nullptr, nullptr, 0, 0};")
     e("    if (rays) rin = RayIn{rays->t, rays->origins, rays->dirs, rays->radii, rays->min_deg, rays->disable_integration};")
@@ -652,11 +654,13 @@ def gen_dgrad(tp: TrainPlan, variant: int = 0) -> str:
     e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
     e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
     e("    if (grid < 1) grid = 1;")
-    e("    static bool attr_done = false;")
-    e("    if (!attr_done) {")
+    e("    static int attr_done[64] = {};")
+    e("    int dev = 0;")
+    e("    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;")
+    e("    if (!attr_done[dev]) {")
     e("        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_bf16_dgrad, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
     e("        if (er != hipSuccess) return er;")
-    e("        attr_done = true;")
+    e("        attr_done[dev] = 1;")
     e("    }")
     e(f"    hipLaunchKernelGGL(k_mlp_bf16_dgrad, dim3(grid), dim3({WAVES * 64}), kLdsBytes, st, (const char*)stream_wT,")
     e("                       (const float4*)d_raw, (const char*)masks, (char*)GT, M, ntiles);")

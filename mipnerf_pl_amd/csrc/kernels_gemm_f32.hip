@@ -437,13 +437,15 @@ hipError_t launch_gemm_f32_big(bool trans_a, int M, int N, int64_t K, const floa
     float* bias_partial = bias_out ? partial + (int64_t)splits * M * N : nullptr;
     const GemmEpi epi = {relu_x, r1_col, r1_row, r1_ld, relu_x && ldc % 4 == 0 ? relu_bits : nullptr};
     constexpr int kLds = 2 * 16 * (256 + 4 + 128 + 4) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static int attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
         hipError_t er = hipFuncSetAttribute((const void*)k_gemm_f32_big<true, 16, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (er != hipSuccess) return er;
         er = hipFuncSetAttribute((const void*)k_gemm_f32_big<false, 16, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
         if (er != hipSuccess) return er;
-        attr_done = true;
+        attr_done[dev] = 1;
     }
     if (trans_a) {
         const dim3 grid((unsigned)((M + 255) / 256), (unsigned)((N + 127) / 128), (unsigned)splits);

@@ -245,11 +245,13 @@ int mlp_wgrad_lds_bytes() { return kWgradLds; }
 
 hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs, const void* wg_tab, int num_wgs,
                             int64_t n_wt, int NH, int NG, float* partials, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static int attr_done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!attr_done[dev]) {
         hipError_t er = hipFuncSetAttribute((const void*)k_mlp_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, kWgradLds);
         if (er != hipSuccess) return er;
-        attr_done = true;
+        attr_done[dev] = 1;
     }
     hipLaunchKernelGGL(k_mlp_wgrad, dim3(num_wgs), dim3(512), kWgradLds, st, (const char*)HT, (const char*)GT, jobs,
                        (const int4*)wg_tab, n_wt, NH, NG, partials);

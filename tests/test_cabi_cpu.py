@@ -260,3 +260,42 @@ def test_width_padding_keeps_the_function_and_its_gradient(lib, w, wc, depth, sk
     assert float(flat.grad[mask].abs().max()) == 0.0                        # padded entries never move under any optimiser
     # nothing wider than the widest generated shape
     assert M.containing_variant(dict(arch, net_width=600), True, False, False) is None
+
+
+def test_launch_attribute_caches_are_per_device(lib):
+    """hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property: a launcher that remembers "done" once per process would
+    launch its > 64-KiB-LDS kernel without the attribute on the second GPU a process touches (MLP.native(device) keeps one context per
+    device).  Every cache in the hand-written and the generated sources must be indexed by the current device."""
+    csrc = os.path.join(REPO, "mipnerf_pl_amd", "csrc")
+    checked = 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".hpp", ".py")):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        if "hipFuncSetAttribute" not in src:
+            continue
+        checked += 1
+        assert not re.search(r"static\s+bool\s+\w*attr\w*", src), f"{f}: per-process attribute cache"
+        for m in re.finditer(r"static\s+int\s+(\w*attr\w*)\s*\[", src):
+            assert re.search(r"hipGetDevice\s*\(", src), f"{f}: {m.group(1)} is not indexed by the device"
+    assert checked >= 10
+
+
+def test_wrong_result_build_knobs_need_an_explicit_opt_in(monkeypatch):
+    """the timing-experiment variables (ablated barriers, transposing reads on untransposed data, ...) give WRONG results; a stale
+    one in the environment must not silently build the product library.  build.py refuses them unless MIPNERF_EXPERIMENT_BUILD=1 AND the
+    output is not libmipnerf_hip.so; the library such a build produces refuses mipnerf_create() without MIPNERF_ALLOW_EXPERIMENT_LIB=1."""
+    from mipnerf_pl_amd import build as b
+    for k in b.WRONG_RESULT_KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    assert b.experiment_flags() == ""
+    monkeypatch.setenv("MLP_WGRAD_TR", "1")
+    with pytest.raises(RuntimeError, match="WRONG results"):
+        b.experiment_flags()
+    monkeypatch.setenv("MIPNERF_EXPERIMENT_BUILD", "1")
+    with pytest.raises(RuntimeError, match="WRONG results"):        # still the product library's name
+        b.experiment_flags()
+    monkeypatch.setattr(b, "LIB", os.path.join(b.CSRC, "libmipnerf_hip_exp.so"))
+    assert b.experiment_flags() == "MLP_WGRAD_TR=1"
+    src = open(os.path.join(REPO, "mipnerf_pl_amd", "csrc", "capi.hip")).read()
+    assert "MIPNERF_ALLOW_EXPERIMENT_LIB" in src and "#ifdef MIPNERF_EXPERIMENT_BUILD" in src
