@@ -49,7 +49,9 @@ DIAG_UNITS = [("kernels_diag.hip", []), ("diag_capi.hip", [])]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall",
           "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result",
           # range reduction of the bf16 pipeline's fast sine (raymath.hpp: sin_fast): 1 = two-float fp32, 0 = fp64
-          "-DMIP_SIN_FAST_TWOFLOAT=" + os.environ.get("MLP_SIN_TWOFLOAT", "0")]
+          "-DMIP_SIN_FAST_TWOFLOAT=" + os.environ.get("MLP_SIN_TWOFLOAT", "0"),
+          # wave scans / reductions of the ray-side kernels (raywave.hpp): 1 = DPP row_shr / row_bcast, 0 = __shfl (ds_bpermute)
+          "-DMIP_WAVE_DPP=" + os.environ.get("MLP_WAVE_DPP", "1")]
 
 
 # Timing-experiment knobs whose build gives WRONG results (value = the harmless default).  A stale variable in the environment must not

@@ -243,6 +243,10 @@ k_composite_resample(int64_t B, int N, const float4* __restrict__ rgb_sigma, con
     const int64_t bb = active ? b : B - 1;
     const float dx = dirs[bb * 3], dy = dirs[bb * 3 + 1], dz = dirs[bb * 3 + 2];
     const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+    // the sampler's bins: this level's fence posts, or (unbounded scenes) their inverse depths -- staged FIRST, so that their load is in
+    // flight beside the compositing's loads instead of starting a second memory round trip behind its scans
+    const float* binb = bins + bb * (int64_t)(N + 1);
+    for (int j = lane; j <= N; j += 64) s_bins[wv][j] = binb[j];
     float w[K];
     composite_ray<K>(active, lane, N, rgb_sigma + bb * (int64_t)N, t + bb * (int64_t)(N + 1), dn, white_bkgd, comp_rgb + bb * 3,
                      distance + bb, acc_out + bb, weights + bb * (int64_t)N, w);
@@ -250,9 +254,6 @@ k_composite_resample(int64_t B, int N, const float4* __restrict__ rgb_sigma, con
 #pragma unroll
     for (int k = 0; k < K; ++k)
         if (i0 + k < N) s_w[wv][i0 + k] = w[k];
-    // the sampler's bins: this level's fence posts, or (unbounded scenes) their inverse depths
-    const float* binb = bins + bb * (int64_t)(N + 1);
-    for (int j = lane; j <= N; j += 64) s_bins[wv][j] = binb[j];
     __syncthreads();
     const int n_draws = N + 1;
     pdf_ray<K, true>(lane, N, s_w[wv], s_cdf[wv], s_bins[wv], n_draws, u_rand ? u_rand + bb * (int64_t)n_draws : nullptr, padding, u_step,

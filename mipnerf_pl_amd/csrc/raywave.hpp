@@ -13,6 +13,76 @@ namespace mip {
 // ------------------------------------------------------------------------------------------
 // wave64 helpers
 // ------------------------------------------------------------------------------------------
+// Round 5: cross-lane movement by DPP (v_mov_b32_dpp: row_shr / row_bcast, a few cycles each) instead of __shfl (ds_bpermute_b32
+// through the LDS crossbar, ~100 cycles of latency per step, two per double).  Every scan / reduction of the ray-side kernels
+// sits on a per-ray dependent chain (compositing -> CDF -> search), so the latency is what they cost.  The DPP forms associate the
+// sums differently from the shuffle trees (row-local prefix, then row totals); the operands are fp32 values widened to double, so
+// the double sums are exact except where magnitudes differ by > 2^29 and the fp32 roundings of the results agree with the shuffle
+// forms except in such corner cases (every golden / fused-vs-stage test runs on these).  MIP_WAVE_DPP=0 restores the shuffles.
+#ifndef MIP_WAVE_DPP
+#define MIP_WAVE_DPP 1
+#endif
+
+#if MIP_WAVE_DPP
+// lane i <- lane (i - n) within its row of 16 (row_shr:n), lanes without a source get `ident`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float ident, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {      // identity 0.0
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118, kDppRowBcast15 = 0x142,
+              kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
+
+// inclusive prefix sum over the 64 lanes (lane 63 holds the total)
+__device__ __forceinline__ float wave_incl_scan_dpp(float v) {
+    v += dpp_f32<kDppRowShr1, 0xf>(0.0f, v);
+    v += dpp_f32<kDppRowShr2, 0xf>(0.0f, v);
+    v += dpp_f32<kDppRowShr4, 0xf>(0.0f, v);
+    v += dpp_f32<kDppRowShr8, 0xf>(0.0f, v);
+    v += dpp_f32<kDppRowBcast15, 0xa>(0.0f, v);      // lane 15 of rows 0 / 2 -> every lane of rows 1 / 3
+    v += dpp_f32<kDppRowBcast31, 0xc>(0.0f, v);      // lane 31 -> every lane of rows 2, 3
+    return v;
+}
+__device__ __forceinline__ double wave_incl_scan_dpp(double v) {
+    v += dpp_f64<kDppRowShr1, 0xf>(v);
+    v += dpp_f64<kDppRowShr2, 0xf>(v);
+    v += dpp_f64<kDppRowShr4, 0xf>(v);
+    v += dpp_f64<kDppRowShr8, 0xf>(v);
+    v += dpp_f64<kDppRowBcast15, 0xa>(v);
+    v += dpp_f64<kDppRowBcast31, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ float readlane63(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+__device__ __forceinline__ double readlane63(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return readlane63(wave_incl_scan_dpp(v)); }
+
+// exclusive prefix sum across the 64 lanes; *total = sum over all lanes
+__device__ __forceinline__ float wave_excl_scan(float v, int lane, float* total) {
+    const float inc = wave_incl_scan_dpp(v);
+    *total = readlane63(inc);
+    return dpp_f32<kDppWaveShr1, 0xf>(0.0f, inc);     // lane i <- lane i - 1 across the whole wave, lane 0 <- 0
+}
+
+// double-precision variants: torch's CPU cumsum accumulates float32 in double
+// (at::acc_type<float,false>), and the inverse-CDF / transmittance are sensitive to the prefix sums
+// (a 1e-7 error of the CDF moves a resampled t by 1e-5 where the pdf is ~5e-4), so the scans run in
+// fp64 -- a few dozen DP adds per ray on a chip with full-rate fp64.
+__device__ __forceinline__ double wave_sum_f64(double v) { return readlane63(wave_incl_scan_dpp(v)); }
+__device__ __forceinline__ double wave_excl_scan_f64(double v, int lane) {
+    return dpp_f64<kDppWaveShr1, 0xf>(wave_incl_scan_dpp(v));
+}
+#else
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -32,10 +102,6 @@ __device__ __forceinline__ float wave_excl_scan(float v, int lane, float* total)
     return lane == 0 ? 0.0f : ex;
 }
 
-// double-precision variants: torch's CPU cumsum accumulates float32 in double
-// (at::acc_type<float,false>), and the inverse-CDF / transmittance are sensitive to the prefix sums
-// (a 1e-7 error of the CDF moves a resampled t by 1e-5 where the pdf is ~5e-4), so the scans run in
-// fp64 -- a few dozen DP adds per ray on a chip with full-rate fp64.
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -51,6 +117,7 @@ __device__ __forceinline__ double wave_excl_scan_f64(double v, int lane) {
     const double ex = __shfl_up(inc, 1, 64);
     return lane == 0 ? 0.0 : ex;
 }
+#endif
 
 
 // The per-ray bodies are device functions shared by the stand-alone kernels and by the fused k_composite_resample (one launch
@@ -172,29 +239,50 @@ __device__ __forceinline__ void pdf_ray(int lane, int N, const float* __restrict
 
     const float eps32 = 1.1920928955078125e-07f;
     const float umax = 1.0f - eps32;
-    for (int j = lane; j < n_draws; j += 64) {
-        float u;
-        if (u_row != nullptr) {
-            // u = arange*s + U[0, s-eps), clipped to 1-eps (mip.py:198-204)
-            u = (float)j * u_step + u_row[j] * u_jitter;
-            u = fminf(u, umax);
-        } else {
-            u = torch_linspace_at(0.0f, umax, n_draws, j);   // mip.py:207
+    // Round 5: a lane's draws (j = lane, lane + 64, ...) are searched TOGETHER, T = K + 1 at a time -- the resampling path has N + 1 draws, i.e.
+    // K full trips plus one draw, and each binary search is a chain of ~log2(N) dependent LDS reads: one after the other they cost (K + 1)
+    // chains, interleaved one.  Same comparisons per draw, fixed step count with predicated updates: the same bits as the sequential loop.
+    constexpr int T = K + 1;
+    const int steps = 32 - __builtin_clz((unsigned)(N + 1));          // a range of N + 1 entries is empty after at most that many halvings
+    for (int j0 = lane; j0 < n_draws; j0 += 64 * T) {
+        float u[T];
+        int lo[T], hi[T];
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            const int j = j0 + 64 * q;
+            const int jc = j < n_draws ? j : n_draws - 1;             // a lane without a draw in this trip shadows the last one (not stored)
+            if (u_row != nullptr) {
+                // u = arange*s + U[0, s-eps), clipped to 1-eps (mip.py:198-204)
+                u[q] = fminf((float)jc * u_step + u_row[jc] * u_jitter, umax);
+            } else {
+                u[q] = torch_linspace_at(0.0f, umax, n_draws, jc);   // mip.py:207
+            }
+            lo[q] = 0;
+            hi[q] = N + 1;
         }
         // searchsorted(cdf, u, right=True): number of entries <= u, over cdf[0..N]
-        int lo = 0, hi = N + 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_cdf[mid] <= u) lo = mid + 1; else hi = mid;
+        for (int it = 0; it < steps; ++it) {
+#pragma unroll
+            for (int q = 0; q < T; ++q) {
+                const int mid = (lo[q] + hi[q]) >> 1;
+                const float cm = s_cdf[mid < N ? mid : N];
+                if (lo[q] < hi[q]) {
+                    if (cm <= u[q]) lo[q] = mid + 1; else hi[q] = mid;
+                }
+            }
         }
-        const int below = max(0, lo - 1);
-        const int above = min(N, lo);
-        const float c0 = s_cdf[below], c1 = s_cdf[above];
-        const float b0 = s_bins[below], b1 = s_bins[above];
-        float denom = c1 - c0;
-        denom = (denom < 1e-5f) ? 1.0f : denom;
-        const float tt = (u - c0) / denom;
-        if (out_row) out_row[j] = b0 + tt * (b1 - b0);
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+            const int j = j0 + 64 * q;
+            const int below = max(0, lo[q] - 1);
+            const int above = min(N, lo[q]);
+            const float c0 = s_cdf[below], c1 = s_cdf[above];
+            const float b0 = s_bins[below], b1 = s_bins[above];
+            float denom = c1 - c0;
+            denom = (denom < 1e-5f) ? 1.0f : denom;
+            const float tt = (u[q] - c0) / denom;
+            if (out_row && j < n_draws) out_row[j] = b0 + tt * (b1 - b0);
+        }
     }
 }
 

@@ -670,6 +670,81 @@ class MipNerf(torch.nn.Module):
         return ret
 
 
+class GraphedForward:
+    """ONE batch's `MipNerf.forward` (inference: randomized=False) replayed from a captured hipGraph (round 5): the ~6 launches of a
+    forward (ray prologue, coarse MLP, compositing + resampling, fine MLP, compositing) over static input / output / workspace
+    buffers, so a step is one graph launch and no Python between the kernels.
+        gf = GraphedForward(model, B, white_bkgd=True)
+        ret = gf(rays)          # copies the 7 ray tensors into gf.static_in, replays; returns the static per-level tuples
+        ret = gf.replay()       # rays already in gf.static_in (e.g. written there by the device-side ray generator)
+    The returned tensors are the graph's own buffers: valid until the next call.  Same bits as the eager forward (same launches);
+    a parameter change is re-packed outside the graph before the replay, a `set_precision` re-captures."""
+
+    def __init__(self, model: "MipNerf", num_rays: int, white_bkgd: bool, device: Optional[torch.device] = None):
+        device = torch.device(device) if device is not None else next(model.parameters()).device
+        if num_rays < 1:
+            raise ValueError("GraphedForward needs at least one ray")
+        self.model, self.n, self.white_bkgd, self.dev = model, int(num_rays), bool(white_bkgd), device
+        N = model.num_samples
+        self.static_in = Rays(*[torch.zeros(self.n, k, device=device) for k in (3, 3, 3, 1, 1, 1, 1)])
+        for k in ("directions", "viewdirs"):
+            getattr(self.static_in, k)[:, 2] = 1.0
+        self.static_in.radii.fill_(1e-3)
+        self.static_in.near.fill_(2.0)
+        self.static_in.far.fill_(6.0)
+        self.out = [(torch.zeros(self.n, 3, device=device), torch.zeros(self.n, device=device), torch.zeros(self.n, device=device),
+                     torch.zeros(self.n, N, device=device), torch.zeros(self.n, N + 1, device=device)) for _ in range(model.num_levels)]
+        self.graph = None
+        self.capture_error = None
+        self._ws = None
+
+    def _launch(self):
+        self.model._forward_native(self.static_in, False, self.white_bkgd, out=self.out, ws=self._ws)
+
+    def _capture(self):
+        ctx = self.model.mlp.native(self.dev)
+        need = int(L.lib().mipnerf_workspace_bytes(ctx.handle, self.n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():     # warm-up on a side stream: lazy init, packing
+            self._launch()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"), torch.no_grad():
+                self._launch()
+            self.graph = graph
+        except RuntimeError as e:
+            import sys
+            print(f"[mipnerf_pl_amd] hipGraph capture of the forward failed ({e}); launching eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            self.graph, self.capture_error = False, str(e)
+
+    def replay(self):
+        with torch.cuda.device(self.dev):
+            self.model.mlp.native(self.dev)         # re-pack OUTSIDE the graph when a parameter changed
+            if self.graph is not None and self._captured_precision != self.model.precision:
+                self.graph = None                   # MipNerf.set_precision since the capture
+            if self.graph is None:
+                self._captured_precision = self.model.precision
+                self._capture()
+            if self.graph is False:
+                with torch.no_grad():
+                    self._launch()
+            else:
+                self.graph.replay()
+        return self.out
+
+    def __call__(self, rays: Rays):
+        if rays.origins.shape[0] != self.n:
+            raise ValueError(f"GraphedForward captured for {self.n} rays, got {rays.origins.shape[0]}")
+        for dst, src in zip(self.static_in, rays):
+            dst.copy_(src)
+        return self.replay()
+
+
 class GraphedFrame:
     """Whole-frame rendering from ONE captured hipGraph (BASELINE configs[4]: 800 x 800 = 640,000 rays in 8192-ray chunks =
     79 chunk forwards, ~20 kernels each): every chunk launch reads its slice of a static full-frame ray buffer and writes its

@@ -1,0 +1,168 @@
+"""Goldens of the UNBOUNDED-scene model on a TRAINED field (round 5) -- run in the build container (CPU):
+
+    python -B scripts/make_golden_360.py --train-field     # ~40 min: tests/golden/trained_field_360.npz
+    python -B scripts/make_golden_360.py --fullsize        # ~10 min: tests/golden/full360_8192x256.npz (+ a 1000 x 96 ragged case)
+
+Nothing upstream is correct for this path (oracle/mipnerf360_oracle.py header: "parity unpinned"), so these files are produced by
+the ORACLE, not by the reference's forward -- what the reference contributes is everything around the dead 360 functions, used
+unmodified: its MLP class (models/mip_nerf.py:19-111, constructed 672 wide), `volumetric_rendering` (mip.py:366-401), `distloss`
+(mip.py:8-20), the loss of nerf_system.py:99-111, torch Adam and its MipLRDecay.
+
+--train-field: that MLP trained on the procedural unbounded scene of tests/dataset_fixture.py (blobs at the origin inside a far sky
+shell with holes; 24 views x 48 x 48 rays, per-view near / far) -- fence posts and encodings of both levels from the 360 oracle
+(numpy, no gradient: stop_resample_grad), randomized, N = 64, 1024 rays per step.  The 24 tensors it ends with are stored.
+--fullsize: oracle.mipnerf360_forward at BASELINE configs[3]'s size, 8192 rays x (256 + 256) samples, on a seeded draw of that
+scene's rays with the trained field -- every ray of both levels (rgb, distance, acc, peak weight) -- and a ragged 1000 x 96 case.
+The golden asserts its own mix of rays (empty / opaque / in between)."""
+import hashlib
+import os
+import sys
+import time
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("MIPNERF_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.path.insert(0, REF)
+sys.path.insert(1, REPO)
+sys.path.insert(2, os.path.join(REPO, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from models import mip as refmip  # noqa: E402  (reference)
+from models.mip_nerf import MLP as RefMLP  # noqa: E402  (reference)
+from utils.lr_schedule import MipLRDecay as RefLR  # noqa: E402  (reference)
+
+import dataset_fixture as fx  # noqa: E402
+from oracle import mipnerf360_oracle as o360  # noqa: E402
+from oracle import mipnerf_oracle as orc  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", os.cpu_count())))
+F32 = np.float32
+CFG = dict(batch=1024, num_samples=64, steps=400, lr_init=2e-3, lr_final=2e-5, max_steps=400, lr_delay_steps=40, lr_delay_mult=0.01,
+           id_seed=5150, param_seed=21, draw_seed=22)
+
+
+def _scene():
+    cache = os.environ.get("SCENE360_CACHE", "/tmp/scene360_rays.npz")
+    if os.path.exists(cache):
+        z = np.load(cache)
+        return orc.Rays(*[z["rays_" + k] for k in orc.Rays._fields]), z["rgb"]
+    R, rgb = fx.scene360_rays()
+    np.savez(cache, rgb=rgb, **{"rays_" + k: getattr(R, k) for k in orc.Rays._fields})
+    return R, rgb
+
+
+def _take(R, ids):
+    return orc.Rays(*[np.ascontiguousarray(a[ids]) for a in R])
+
+
+def _level_inputs(R, N, lvl, randomized, t_inv_prev, w_prev, t_rand, u_rand):
+    """fence posts (inverse depth + metric) and the 672-wide encoding of one level, exactly as oracle.mipnerf360_forward forms them"""
+    if lvl == 0:
+        t_inv, t, mc = o360.sample_along_rays_360(R.origins, R.directions, R.radii, N, R.near, R.far, randomized, t_rand=t_rand, contracted=True)
+    else:
+        w = np.asarray(w_prev, F32)
+        wp = np.concatenate([w[:, :1], w, w[:, -1:]], axis=-1)
+        wmax = np.maximum(wp[:, :-1], wp[:, 1:])
+        wblur = (F32(0.5) * (wmax[:, :-1] + wmax[:, 1:])).astype(F32) + F32(0.01)
+        t_inv = orc.sorted_piecewise_constant_pdf(t_inv_prev, wblur, t_inv_prev.shape[-1], randomized, u_rand=u_rand)
+        t = (F32(1) / t_inv).astype(F32)
+        mc = o360.cast_rays_360(t, R.origins, R.directions, R.radii, True)
+    enc = o360.integrated_pos_enc_360(mc, 0, 16, contracted=False)
+    return t_inv, t, enc
+
+
+def train_field(name):
+    Q = CFG
+    R, rgb = _scene()
+    n = R.origins.shape[0]
+    ids = fx.quality_batch_ids(n, Q["steps"], Q["batch"], Q["id_seed"])
+    torch.manual_seed(Q["param_seed"])
+    mlp = RefMLP(8, 256, 1, 128, 4, 3, 1, "relu", 672, 27)
+    opt = torch.optim.Adam(mlp.parameters(), lr=Q["lr_init"])
+    sch = RefLR(opt, Q["lr_init"], Q["lr_final"], Q["max_steps"], Q["lr_delay_steps"], Q["lr_delay_mult"])
+    rng = np.random.default_rng(Q["draw_seed"])
+    N = Q["num_samples"]
+    losses, psnrs = [], []
+    t0 = time.perf_counter()
+    for k in range(Q["steps"]):
+        Rb = _take(R, ids[k])
+        gt = torch.from_numpy(rgb[ids[k]])
+        dirs = torch.from_numpy(Rb.directions)
+        venc = torch.from_numpy(orc.pos_enc(Rb.viewdirs, 0, 4, True))
+        t_inv, w = None, None
+        ls, dl, comp = [], [], None
+        for lvl in range(2):
+            tr = rng.uniform(0, 1, (Q["batch"], N + 1)).astype(F32)
+            t_inv, t, enc = _level_inputs(Rb, N, lvl, True, t_inv, w, tr, tr)
+            raw_rgb, raw_density = mlp(torch.from_numpy(enc), venc)
+            c = torch.sigmoid(raw_rgb) * (1 + 2 * 0.001) - 0.001                       # mip_nerf.py:236-238
+            sigma = torch.nn.functional.softplus(raw_density - 1.0)
+            tt = torch.from_numpy(t)
+            comp, _, _, wt = refmip.volumetric_rendering(c, sigma, tt, dirs, True)
+            ls.append(((comp - gt) ** 2).sum() / Q["batch"])                          # nerf_system.py:99-111 with lossmult == 1
+            dl.append(refmip.distloss(wt, tt))
+            w = wt.detach().numpy()
+        loss = 0.1 * (ls[0] + 0.01 * dl[0]) + ls[1] + 0.01 * dl[1]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sch.step()
+        losses.append(loss.item())
+        psnrs.append(float(-10.0 * np.log10(np.mean((comp.detach().numpy() - gt.numpy()) ** 2))))
+        if k % 10 == 0 or k == Q["steps"] - 1:
+            print(f"  [trained_field_360] step {k} loss {losses[-1]:.5f} train psnr {psnrs[-1]:.2f} dB ({time.perf_counter() - t0:.0f} s)", flush=True)
+    out = {"cfg_" + k: v for k, v in Q.items()}
+    out.update(losses=np.asarray(losses, F32), train_psnr=np.asarray(psnrs, F32), threads=torch.get_num_threads())
+    for k, p in mlp.named_parameters():
+        out["p_" + k] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz: final loss {np.mean(losses[-20:]):.5f}, train psnr {np.mean(psnrs[-20:]):.2f} dB, {time.perf_counter() - t0:.0f} s")
+
+
+def fullsize(name, field, batch, num_samples, ray_seed, chunk=256):
+    R, rgb = _scene()
+    f = np.load(os.path.join(OUT, field + ".npz"))
+    params = {k[2:]: f[k] for k in f.files if k.startswith("p_")}
+    ids = np.random.default_rng(ray_seed).permutation(R.origins.shape[0])[:batch]
+    Rb = _take(R, ids)
+    out = dict(num_samples=num_samples, batch=batch, ray_seed=ray_seed, field=field, gt=rgb[ids], pixel_ids=ids.astype(np.int64))
+    out.update({"rays_" + k: getattr(Rb, k) for k in orc.Rays._fields})
+    h = hashlib.sha256()
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    out["field_sha256"] = h.hexdigest()
+    t0 = time.perf_counter()
+    parts = []
+    for c0 in range(0, batch, chunk):                       # rays are independent: chunking only bounds the [rays, N, 672] temporaries
+        parts.append(o360.mipnerf360_forward(params, _take(Rb, np.arange(c0, min(c0 + chunk, batch))), False, True, num_samples=num_samples))
+        print(f"  [{name}] {min(c0 + chunk, batch)} / {batch} rays ({time.perf_counter() - t0:.0f} s)", flush=True)
+    for lvl in range(2):
+        cat = [np.concatenate([p[lvl][i] for p in parts], 0) for i in range(5)]
+        comp, dist, acc, w, t = cat
+        out[f"l{lvl}_rgb"], out[f"l{lvl}_distance"], out[f"l{lvl}_acc"] = comp, dist, acc
+        out[f"l{lvl}_wmax"] = w.max(-1)
+        out[f"l{lvl}_t_first"], out[f"l{lvl}_t_last"] = t[:, 0].copy(), t[:, -1].copy()
+        if batch * num_samples <= 200000:
+            out[f"l{lvl}_weights"], out[f"l{lvl}_t_samples"] = w, t
+    acc = out["l1_acc"]
+    frac = dict(empty=float((acc < 0.05).mean()), opaque=float((acc > 0.95).mean()), between=float(((acc >= 0.05) & (acc <= 0.95)).mean()))
+    assert frac["empty"] >= 0.15 and frac["opaque"] >= 0.20 and frac["between"] >= 0.05, frac
+    out.update({"frac_" + k: v for k, v in frac.items()})
+    psnr = float(-10.0 * np.log10(np.mean((out["l1_rgb"] - out["gt"]) ** 2)))
+    out["psnr_vs_scene"] = psnr
+    print(f"  [{name}] oracle forward {time.perf_counter() - t0:.0f} s; rays: {frac}; PSNR vs the scene's pixels {psnr:.2f} dB")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz")
+
+
+if __name__ == "__main__":
+    if "--train-field" in sys.argv:
+        train_field("trained_field_360")
+    if "--fullsize" in sys.argv:
+        fullsize("full360_1000x96", "trained_field_360", 1000, 96, ray_seed=911)
+        fullsize("full360_8192x256", "trained_field_360", 8192, 256, ray_seed=912)

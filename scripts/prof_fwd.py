@@ -16,6 +16,7 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--samples", type=int, default=128)
 ap.add_argument("--heat", type=float, default=0.0, help="seconds of untimed forwards first")
+ap.add_argument("--graph", action="store_true", help="replay the forward from one captured hipGraph (model.GraphedForward)")
 ap.add_argument("--grid", type=int, default=0, help="persistent workgroups of the MLP kernel (option 1; default = CUs)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -41,6 +42,20 @@ with torch.no_grad():
         out = m(R, False, True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.iters
+    if a.graph:          # the same steps as graph replays (the MLP launch time above comes from the eager pass: events do not live in graphs)
+        from mipnerf_pl_amd.model import GraphedForward
+        ctx.set_option(2, 0)
+        gf = GraphedForward(m, a.rays, True)
+        gf(R)
+        for _ in range(50):
+            gf.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.iters):
+            out = gf.replay()
+        torch.cuda.synchronize()
+        dtg = (time.perf_counter() - t0) / a.iters
+        print(f"graph replay: {dtg * 1e3:.4f} ms/step (eager {dt * 1e3:.4f}); captured: {bool(gf.graph)}")
 import ctypes as C  # noqa: E402
 from mipnerf_pl_amd import _lib as L  # noqa: E402
 tot, nl = C.c_double(), C.c_int64()

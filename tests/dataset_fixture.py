@@ -192,3 +192,62 @@ def quality_batch_ids(n_pixels, steps, batch, seed):
         ids.append(perm[pos:pos + batch].copy())
         pos += batch
     return np.stack(ids)
+
+
+# ---- an UNBOUNDED procedural scene (round 5: a trained field for the parity tests of `MipNerf(unbounded=True)`) ---------------
+# The blobs above around the origin + a far "sky" shell of radius 8 whose density is switched on and off smoothly with the
+# direction, so a ray through the scene ends on a blob (opaque, near), on the shell (opaque or soft, far: contracted space),
+# or leaves through a hole of the shell (empty).  Cameras sit INSIDE the shell and look at the origin, LLFF-style per-view bounds.
+SCENE360 = dict(shell_radius=8.0, shell_sigma=0.5, shell_density=6.0, views=24, res=48, radius=(2.6, 3.4), near=(0.6, 1.1), far=(16.0, 22.0), seed=77)
+
+
+def _scene360_density_colour(p):
+    sig, col = _scene_density_colour(p)
+    r = np.linalg.norm(p, axis=-1)
+    u = p / np.maximum(r[..., None], 1e-9)
+    window = 0.5 + 0.5 * np.tanh(10.0 * (np.sin(3.0 * np.arctan2(u[..., 1], u[..., 0])) * np.cos(2.5 * u[..., 2]) - 0.1))     # ~35 % of the sky is a hole
+    s_shell = SCENE360["shell_density"] * window * np.exp(-0.5 * ((r - SCENE360["shell_radius"]) / SCENE360["shell_sigma"]) ** 2)
+    c_shell = np.stack([0.55 + 0.35 * np.sin(2.0 * u[..., 0] + 4.0 * u[..., 1]), 0.50 + 0.35 * np.cos(3.0 * u[..., 2] - u[..., 0]),
+                        0.60 + 0.30 * np.sin(5.0 * u[..., 1] * u[..., 2] + 0.7)], -1)
+    tot = sig + s_shell
+    colour = (sig[..., None] * col + s_shell[..., None] * c_shell) / np.maximum(tot[..., None], 1e-12)
+    return tot, np.clip(colour, 0.0, 1.0)
+
+
+def render_scene360(origins, directions, near, far, steps=1024, white_bkgd=True):
+    """float64 quadrature of the volume-rendering integral, fence posts uniform in INVERSE depth between per-ray near and far
+    (fine near the camera, coarse far away, like the model's own parameterisation); returns the composited colour [...,3]."""
+    o = np.asarray(origins, np.float64)[..., None, :]
+    d = np.asarray(directions, np.float64)[..., None, :]
+    s = np.linspace(0.0, 1.0, steps + 1)
+    t = 1.0 / (s / np.asarray(far, np.float64) + (1.0 - s) / np.asarray(near, np.float64))       # [..., steps + 1]
+    tm = 0.5 * (t[..., 1:] + t[..., :-1])
+    dt = (t[..., 1:] - t[..., :-1]) * np.linalg.norm(d, axis=-1)
+    sig, col = _scene360_density_colour(o + tm[..., None] * d)
+    tau = sig * dt
+    trans = np.exp(-(np.cumsum(tau, -1) - tau))
+    w = (1.0 - np.exp(-tau)) * trans
+    rgb = (w[..., None] * col).sum(-2)
+    if white_bkgd:
+        rgb = rgb + (1.0 - w.sum(-1))[..., None]
+    return np.clip(rgb, 0.0, 1.0)
+
+
+def scene360_rays():
+    """Every training ray of the unbounded scene + its ground-truth colour: (Rays of [n, k] float32 arrays, rgb [n, 3] float32).
+    Pixel -> ray rule of Multicam._generate_rays (datasets.py:116-131) through the oracle's restatement; per-view near / far."""
+    from oracle import mipnerf_oracle as orc
+    S = SCENE360
+    rng = np.random.RandomState(S["seed"])
+    rays, rgbs = [], []
+    res = S["res"]
+    focal = 0.5 * res / np.tan(0.5 * 0.9)
+    p2c = np.asarray([[1.0 / focal, 0.0, -0.5 * res / focal], [0.0, -1.0 / focal, 0.5 * res / focal], [0.0, 0.0, -1.0]])
+    for _ in range(S["views"]):
+        c2w = _look_at_pose(rng, radius=rng.uniform(*S["radius"]))
+        near, far = rng.uniform(*S["near"]), rng.uniform(*S["far"])
+        r = orc.generate_rays_multicam(c2w[:3], p2c, res, res, near, far, 1.0)
+        rays.append([np.asarray(a, np.float32).reshape(res * res, -1) for a in r])
+        rgbs.append(render_scene360(r.origins, r.directions, r.near, r.far).reshape(res * res, 3))
+    R = type(r)(*[np.concatenate([v[i] for v in rays], 0) for i in range(len(rays[0]))])
+    return R, np.concatenate(rgbs, 0).astype(np.float32)

@@ -29,6 +29,47 @@ TOL_FP32 = dict(rgb=5e-5, distance=2e-4, acc=5e-5, weights=5e-5, t_samples=2e-5)
 TOL_BF16 = dict(rgb=2e-2, distance=0.12, acc=3e-2, weights=0.1, t_samples=6e-2)
 NAMES = ("rgb", "distance", "acc", "weights", "t_samples")
 
+# round 5: the catch-all TOL_BF16 above is 1.5x the worst case over ALL goldens, i.e. 4-20x what most single cases
+# measure -- a regression that triples a case's error passed.  Per case: bound = 2 x the maximum MEASURED on MI355X for that case
+# (max over both levels; profiles/r04z_parity.jsonl, re-measured in profiles/r05_parity.jsonl), floored where the measured value is
+# ~0 (a floor of a few bf16 ulps of the quantity: errors that small are accumulation-order noise, not a level).  bf16 results are
+# deterministic for a given build; a change of a kernel's summation order moves them by far less than 2x.
+BF16_MEASURED = {
+    "forward fwd_c1_256x64_xavier": dict(rgb=5.6e-4, distance=7.5e-4, acc=2.6e-4, weights=6.0e-5, t_samples=5.7e-4),
+    "forward fwd_c1_256x64_trained": dict(rgb=1.8e-3, distance=2.1e-2, acc=9.7e-5, weights=7.1e-2, t_samples=1.9e-2),
+    "forward fwd_ragged_100x128_trained": dict(rgb=1.9e-3, distance=2.5e-2, acc=8.6e-4, weights=3.1e-2, t_samples=3.0e-2),
+    "forward fwd_unbounded_24x256_trained": dict(rgb=1.5e-3, distance=2.4e-2, acc=4.2e-7, weights=2.4e-2, t_samples=2.2e-2),
+    "forward fwd_disparity_32x64_trained": dict(rgb=8.6e-3, distance=2.7e-2, acc=1.7e-2, weights=3.1e-2, t_samples=4.0e-2),
+    "forward randomized": dict(rgb=1.1e-2, distance=7.9e-2, acc=2.1e-2, weights=1.3e-2, t_samples=1.8e-2),
+    "full_size B=4096": dict(rgb=9.1e-3, distance=3.7e-2, acc=1.9e-2, weights=1.9e-2, t_samples=1.1e-2),
+    "density_noise": dict(rgb=5.0e-4, distance=2.0e-3, acc=8.2e-4, weights=2.3e-3, t_samples=5.5e-3),
+    "variant var_d6s3_48x64": dict(rgb=4.9e-3, distance=5.4e-2, acc=8.6e-3, weights=4.0e-2, t_samples=3.3e-2),
+    "variant var_noview_48x64": dict(rgb=7.7e-4, distance=9.2e-3, acc=4.2e-4, weights=7.7e-3, t_samples=1.2e-2),
+    "variant var_w100c40_48x64": dict(rgb=2.2e-3, distance=2.0e-2, acc=1.9e-3, weights=2.6e-2, t_samples=2.5e-2),
+    "variant var_w128_48x64": dict(rgb=2.1e-3, distance=0.0, acc=3.5e-3, weights=2.8e-3, t_samples=1.1e-2),
+    "variant var_w200c72_48x64": dict(rgb=7.4e-4, distance=1.2e-2, acc=5.5e-5, weights=8.0e-3, t_samples=7.6e-3),
+    "ctor ctor_levels1_40x64": dict(rgb=9.3e-4, distance=0.0, acc=1.6e-3, weights=9.6e-4, t_samples=0.0),
+    "ctor ctor_scalars_40x64": dict(rgb=7.6e-4, distance=2.6e-3, acc=1.3e-5, weights=3.2e-3, t_samples=2.0e-3),
+    # level 0 of ctor_noint (level 1 is only required to be finite, see test_constructor_scalars_forward)
+    "ctor ctor_noint_40x64 level0": dict(rgb=1.1e-3, distance=0.0, acc=1.5e-3, weights=1.0e-3, t_samples=0.0),
+}
+# PSNR of the bf16 fine-level render against the reference's render, measured (dB); asserted at measured - 6 dB = twice the error
+BF16_PSNR_MEASURED = {"fwd_c1_256x64_xavier": 74.8, "fwd_c1_256x64_trained": 69.1, "fwd_ragged_100x128_trained": 68.2,
+                      "fwd_unbounded_24x256_trained": 67.9, "fwd_disparity_32x64_trained": 56.6}
+BF16_FLOOR = dict(rgb=4e-4, distance=2e-3, acc=4e-4, weights=2e-3, t_samples=2e-3)
+
+
+def bf16_tol(case):
+    """2 x the measured maxima of `case` (see BF16_MEASURED); the catch-all TOL_BF16 for a case without a record"""
+    m = BF16_MEASURED.get(case)
+    if m is None:
+        return dict(TOL_BF16)
+    return {k: min(TOL_BF16[k], max(2.0 * m[k], BF16_FLOOR[k])) for k in NAMES}
+
+
+def tol_for(precision, case):
+    return dict(TOL_FP32) if precision == "fp32" else bf16_tol(case)
+
 
 def to_dev(rays_np):
     return Rays(*[torch.from_numpy(np.ascontiguousarray(a)).to(DEV) for a in rays_np])

@@ -41,6 +41,26 @@ def test_bench_self_launches_two_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_self_launches_eight_ranks_on_the_shared_gpu():
+    """the driver's SCALE run goes to N = 8 and no box with more than one GPU was ever available to the builder.  The
+    rank-count-specific host logic -- self re-exec under torch.distributed.run with 8 ranks, the eight contiguous ray shards of the
+    640,000-ray frame (80,000 each) and their gather, eight flat-gradient all-reduces per training step with 1 / 8 folded into Adam, max over
+    ranks of the timed regions -- runs here with all eight ranks on cuda:0 over gloo (RCCL refuses two ranks per device)."""
+    out = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--rays", "256", "--samples", "32", "--sustain-seconds", "0", "--preheat-seconds", "0.05"],
+               {"MIPNERF_BENCH_SHARE_GPU": "1", "MIPNERF_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["steps"] == 2
+    assert line["per_gpu"] * 8 == pytest.approx(line["value"], rel=1e-6)
+    for k in ("train", "render"):
+        assert line[k]["n_gpus"] == 8 and line[k]["value"] > 0 and line[k]["roofline"]["frac"] > 0, k
+    assert line["train"]["scaling"] == "weak" and line["render"]["scaling"] == "strong"
+    assert line["train"]["config"]["global_batch_rays"] == 8 * 256, line["train"]["config"]
+    assert line["render"]["config"]["rays_per_gpu_max"] == 80000 and line["render"]["config"]["frame_rays"] == 640000, line["render"]["config"]
+    assert line["cpu_baseline"] is None and "scale_model" not in line          # N = 1 only
+
+
+@pytest.mark.gpu
 def test_bench_single_gpu_line():
     out = _run(["--steps", "3", "--warmup", "1", "--rays", "512", "--samples", "32", "--sustain-seconds", "0.2", "--ceiling-seconds", "0.4", "--preheat-seconds", "0.2"], {})
     assert out.returncode == 0, out.stderr[-3000:]
@@ -57,6 +77,7 @@ def test_bench_single_gpu_line():
     assert line["fp32"]["dtype"] == "fp32" and line["fp32"]["roofline"]["kernel"].startswith("k_mlp_f32r") and line["fp32"]["roofline"]["frac"] > 0.3
     # round 4: the stated expectation for the 1 / 2 / 4 / 8 curve, from this run's 1-GPU numbers + a 1-rank RCCL all-reduce measured here
     sm = line["scale_model"]
+    assert sm["measured"] is False                                # a written-down expectation, never to be read as a measurement
     assert sm["measured_inputs"]["train_ms_per_step_1gpu"] == line["train"]["ms_per_step"]
     assert sm["measured_inputs"]["allreduce_1rank_rccl_ms"] is not None and 0 < sm["measured_inputs"]["allreduce_1rank_rccl_ms"] < 5, sm
     assert sm["predicted"]["1"]["train_allreduce_ms"] == 0 and sm["predicted"]["8"]["train_allreduce_ms"] > sm["predicted"]["2"]["train_allreduce_ms"] > 0

@@ -26,7 +26,7 @@ def run_case(G, name, precision, white):
     model = G.make_model(params, int(g["num_samples"]), precision, disparity=bool(g["disparity"]))
     with torch.no_grad():
         ret = model(G.to_dev(G.rays_of(g)), False, white)
-    tol = G.TOL_FP32 if precision == "fp32" else G.TOL_BF16
+    tol = G.tol_for(precision, f"forward {name}")
     errs = {}
     for lvl in range(2):
         for nm, val in zip(G.NAMES, ret[lvl]):
@@ -52,7 +52,8 @@ def test_forward_bf16_matches_reference(G, name):
     mse = float(np.mean((ret[1][0].cpu().numpy() - g["wb1_l1_rgb"]) ** 2))
     psnr = -10 * np.log10(max(mse, 1e-20))
     G.record(f"psnr_bf16_vs_reference {name}", psnr_db=psnr)
-    assert psnr > 55.0      # > 51.4 dB keeps a 35 dB render within 0.1 dB
+    # > 51.4 dB keeps a 35 dB render within 0.1 dB; per case: 6 dB (= twice the error) below what was measured on MI355X
+    assert psnr > max(55.0, G.BF16_PSNR_MEASURED[name] - 6.0), (psnr, G.BF16_PSNR_MEASURED[name])
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
@@ -64,7 +65,7 @@ def test_forward_randomized_with_injected_noise(G, precision):
     with torch.no_grad():
         ret = model(G.to_dev(G.rays_of(g)), True, True, t_rand=torch.from_numpy(g["t_rand"]).to(dev),
                     u_rand=torch.from_numpy(g["u_rand"]).to(dev))
-    tol = G.TOL_FP32 if precision == "fp32" else G.TOL_BF16
+    tol = G.tol_for(precision, "forward randomized")
     errs = {f"l{l}_{nm}": G.maxdiff(v, g[f"wb1_l{l}_{nm}"]) for l in range(2) for nm, v in zip(G.NAMES, ret[l])}
     G.record(f"forward randomized {precision}", **errs)
     for k, e in errs.items():
@@ -121,7 +122,7 @@ def test_full_size_properties(G, precision):
         assert np.all(dist >= t[:, 0]) and np.all(dist <= t[:, -1])
         for a, b in zip(full[lvl], sub[lvl]):
             assert torch.equal(a[1000:1100], b), "result must not depend on batch composition"
-    tol = G.TOL_FP32 if precision == "fp32" else G.TOL_BF16
+    tol = G.tol_for(precision, f"full_size B={B}")
     sl = slice(0, 64)
     oret = orc.mipnerf_forward(params, orc.Rays(*[a[sl] for a in rays]), False, True, num_samples=N)
     errs = {f"l{l}_{nm}": G.maxdiff(v[sl], o) for l in range(2) for nm, v, o in zip(G.NAMES, full[l], oret[l])}
@@ -162,7 +163,7 @@ def test_density_noise_matches_reference(G, precision):
     model = G.make_model(params, N, precision, density_noise=float(g["density_noise"]))
     rays = G.to_dev(G.rays_of(g))
     tr, ur, dz = (torch.from_numpy(g[k]).to(G.DEV) for k in ("t_rand", "u_rand", "density_randn"))
-    tol = G.TOL_FP32 if precision == "fp32" else G.TOL_BF16
+    tol = G.tol_for(precision, "density_noise")
     routes = {}
     with torch.no_grad():
         routes["inference"] = model(rays, True, True, t_rand=tr, u_rand=ur, density_randn=dz)
@@ -217,7 +218,7 @@ def test_constructor_variants_forward(G, name, precision):
     model = G.make_model(params, int(g["num_samples"]), precision, **VARIANT_KW[name])
     with torch.no_grad():
         ret = model(G.to_dev(G.rays_of(g)), False, True)
-    tol = G.TOL_FP32 if precision == "fp32" else G.TOL_BF16
+    tol = G.tol_for(precision, f"variant {name}")
     errs = {}
     for lvl in range(2):
         for nm, val in zip(G.NAMES, ret[lvl]):
@@ -301,16 +302,16 @@ def test_constructor_scalars_forward(G, name, precision):
     g = G.load_golden(name)
     params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
     model = G.make_model(params, int(g["num_samples"]), precision, **CTOR_KW[name])
-    tol = dict(G.TOL_FP32 if precision == "fp32" else G.TOL_BF16)
+    tol = G.tol_for(precision, f"ctor {name}")
     tol1 = tol
     if name == "ctor_noint_40x64":
         # disable_integration leaves the features at 2^15 x undamped (|arg| up to 2e5 rad, fp32 ulp 0.016 rad).  Level 0 (t is
         # deterministic) is as tight as ever; at level 1 a 1-ulp difference of a resampled t moves the top features by 1e-2 rad
         # and two correct fp32 evaluations differ by 4e-3 on acc (numpy oracle vs reference, scripts/make_golden.py): loose
-        # bound there.  bf16 (features rounded to 8 bits, fast sin): level 0 within the usual bf16 bounds x 2, level 1 only finite
+        # bound there.  bf16 (features rounded to 8 bits, fast sin): level 0 within 2x its measured maxima, level 1 only finite
         tol1 = dict(rgb=2e-2, acc=2e-2, distance=8e-2, weights=4e-2, t_samples=1e-3) if precision == "fp32" else None
         if precision == "bf16":
-            tol = {k: 2 * v for k, v in tol.items()}
+            tol = G.bf16_tol("ctor ctor_noint_40x64 level0")
     for wb in (True, False):
         with torch.no_grad():
             ret = model(G.to_dev(G.rays_of(g)), False, wb)
@@ -530,3 +531,54 @@ def test_padded_widths_on_every_structural_variant_fp32(G, kw):
         assert g.shape == p.shape
         assert G.maxdiff(g, p.grad) <= 1e-4 * max(float(p.grad.abs().max()), 1e-6), n
     G.record(f"padded_widths {kw.get('mlp_net_width')}", fwd_rel=G.maxdiff(got, ref) / scale)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("unbounded", [False, True])
+def test_graphed_forward_equals_eager(G, precision, unbounded):
+    """round 5: model.GraphedForward = one batch's forward replayed from ONE captured hipGraph over static buffers (what bench.py's
+    headline step replays).  Same launches, so the same bits as the eager forward; new rays through __call__, rays written into
+    `static_in` by the caller through replay(); a parameter change is picked up (re-pack outside the graph); set_precision re-captures."""
+    from mipnerf_pl_amd import MipNerf
+    from mipnerf_pl_amd.model import GraphedForward
+    import synthetic_inputs as syn
+    B, N = 300, 64
+    arch = dict(xyz_dim=672) if unbounded else {}
+    params = syn.make_params(seed=4, density_gain=30.0, **arch)
+    model = MipNerf(num_samples=N, precision=precision, unbounded=unbounded)
+    model.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    model = model.to(G.DEV)
+    gf = GraphedForward(model, B, True)
+    for seed in (1, 2):
+        rays = G.to_dev(syn.synthetic_rays(B, seed=seed, unbounded=unbounded))
+        with torch.no_grad():
+            want = [[t.clone() for t in lvl] for lvl in model(rays, False, True)]
+        got = gf(rays)
+        assert gf.graph, gf.capture_error
+        for la, lb in zip(got, want):
+            for a, b in zip(la, lb):
+                assert torch.equal(a, b)
+    # rays generated in place + replay()
+    rays = G.to_dev(syn.synthetic_rays(B, seed=3, unbounded=unbounded))
+    for dst, src in zip(gf.static_in, rays):
+        dst.copy_(src)
+    got = [[t.clone() for t in lvl] for lvl in gf.replay()]
+    with torch.no_grad():
+        want = model(rays, False, True)
+    assert all(torch.equal(a, b) for la, lb in zip(got, want) for a, b in zip(la, lb))
+    # a parameter update between replays reaches the graph (weights are re-packed outside of it)
+    with torch.no_grad():
+        model.mlp.color_layer.bias.add_(0.25)
+        want = [[t.clone() for t in lvl] for lvl in model(rays, False, True)]
+    got2 = gf.replay()
+    assert all(torch.equal(a, b) for la, lb in zip(got2, want) for a, b in zip(la, lb))
+    assert not torch.equal(got2[1][0], got[1][0])
+    # the other precision: the graph is re-captured
+    other = "fp32" if precision == "bf16" else "bf16"
+    model.set_precision(other)
+    got3 = [[t.clone() for t in lvl] for lvl in gf.replay()]
+    with torch.no_grad():
+        want3 = model(rays, False, True)
+    assert all(torch.equal(a, b) for la, lb in zip(got3, want3) for a, b in zip(la, lb))
+    with pytest.raises(ValueError):
+        gf(G.to_dev(syn.synthetic_rays(B + 1, seed=3, unbounded=unbounded)))

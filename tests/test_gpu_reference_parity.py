@@ -72,10 +72,11 @@ def test_full_size_every_ray(G, name, precision):
                 tol *= 5
             assert e <= tol, f"{name} fp32 {k}: {e} > {tol}"
     else:
-        assert errs["psnr_l1_rgb"] > 55.0, errs
-        assert errs["l0_rgb"] <= 1e-2 and errs["l1_rgb"] <= 1e-2, errs            # measured 2.6e-3 over 8192 rays
-        assert errs["l0_acc"] <= 1e-2 and errs["l1_acc"] <= 1e-2, errs
-        assert errs["l1_distance"] <= 0.1, errs                                    # measured 2.2e-2
+        # round 5: every bound = 2 x the value measured on MI355X (profiles/r04z_parity.jsonl), so that a 3 x regression fails
+        assert errs["psnr_l1_rgb"] > 66.0, errs                                    # measured 72.5 / 71.8 dB; -6 dB = twice the error
+        assert errs["l0_rgb"] <= 1.8e-3 and errs["l1_rgb"] <= 5.2e-3, errs         # measured 8.8e-4 / 2.6e-3 (max of the two configs)
+        assert errs["l0_acc"] <= 4e-4 and errs["l1_acc"] <= 4e-4, errs             # measured 1.2e-5 / 2.3e-5 (saturated fog: floor)
+        assert errs["l0_distance"] <= 1.2e-2 and errs["l1_distance"] <= 4.5e-2, errs    # measured 5.8e-3 / 2.2e-2
 
 
 @pytest.mark.parametrize("name", ["fulltrained_c2_4096x128", "fulltrained_c4_8192x256"])
@@ -120,11 +121,14 @@ def test_full_size_every_ray_on_a_trained_field(G, name, precision):
             assert e <= tol, f"{name} fp32 {k}: {e} > {tol}"
         assert abs(errs["psnr_vs_scene_pixels"] - errs["ref_psnr_vs_scene_pixels"]) < 1e-3
     else:
-        assert errs["psnr_l1_rgb"] > 55.0, errs
-        assert errs["l0_rgb"] <= 2e-2 and errs["l1_rgb"] <= 2e-2, errs
-        assert errs["l0_acc"] <= 2e-2 and errs["l1_acc"] <= 2e-2, errs
-        assert errs["l1_rgb_empty"] <= 5e-3 and errs["l1_acc_empty"] <= 5e-3, errs        # empty space stays empty in bf16
-        assert errs["l1_distance"] <= 0.1, errs
+        # round 5: 2 x the values measured on MI355X (profiles/r04z_parity.jsonl: rgb 2.1e-3, acc 2.6e-3, distance 8.8e-3 / 7.3e-3,
+        # empty rays rgb 2.7e-4 / acc 3.3e-4, opaque rays rgb 1.2e-3, 72.1 / 72.4 dB)
+        assert errs["psnr_l1_rgb"] > 66.0, errs
+        assert errs["l0_rgb"] <= 4.2e-3 and errs["l1_rgb"] <= 4.2e-3, errs
+        assert errs["l0_acc"] <= 5.2e-3 and errs["l1_acc"] <= 5.2e-3, errs
+        assert errs["l1_rgb_empty"] <= 6e-4 and errs["l1_acc_empty"] <= 7e-4, errs        # empty space stays empty in bf16
+        assert errs["l1_rgb_opaque"] <= 2.4e-3 and errs["l1_acc_opaque"] <= 1.3e-3, errs
+        assert errs["l0_distance"] <= 1.8e-2 and errs["l1_distance"] <= 1.5e-2, errs
         assert abs(errs["psnr_vs_scene_pixels"] - errs["ref_psnr_vs_scene_pixels"]) < 0.1       # the north star's 0.1 dB, on this frame
 
 

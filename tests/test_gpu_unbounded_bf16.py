@@ -146,3 +146,140 @@ def test_training_entry_points_refuse_bf16_for_this_model(G):
         m16(rays, True, True)                              # parameters require grad: the autograd route
     with pytest.raises(NotImplementedError):
         m16.train_step_native(rays, torch.zeros(8, 3, device=DEV), True, True)
+
+
+# ---- round 5: this path against the 360 ORACLE, not against the repo's own fp32 kernels ----------------------------
+def _psnr(a, b):
+    return float(-10.0 * np.log10(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2) + 1e-30))
+
+
+def test_bf16_off_axis_encoding_vs_the_gaussian_expectation(G):
+    """The bf16 rows of k_cast_ipe_360_tile are a DIFFERENT function from the fp32 rows (true cosine, two-float range reduction, hardware
+    sine / exp2); round 4 compared them with the sibling per-direction kernel only.  Here: against the closed-form Gaussian expectation
+    E[sin(2^l p.x)] = sin(2^l p.mu) exp(-0.5 4^l p^T Sigma p) (and cos) evaluated in FLOAT64 on the oracle's contracted Gaussians, degree by
+    degree.  Error budget per feature: half a bf16 ulp of a value <= 1 (2^-9) + the fp32 phase: the kernel forms y = 2^l fl32(p.mu) in fp32,
+    |p.mu| <= 2 after the contraction, so the phase is off by up to 2^l x 2.4e-7 rad (what the fp32 rows and the oracle carry as well)."""
+    from mipnerf_pl_amd import _lib as L
+    from mipnerf_pl_amd import ops
+    from oracle import mipnerf360_oracle as o360
+    B, N = 48, 64
+    rays = syn.synthetic_rays(B, seed=83, unbounded=True, multiscale=True)
+    rng = np.random.default_rng(8)
+    t_rand = rng.uniform(0, 1, (B, N + 1)).astype(np.float32)
+    _, t, (mean, cov) = o360.sample_along_rays_360(rays.origins, rays.directions, rays.radii, N, rays.near, rays.far, True, t_rand=t_rand,
+                                                   contracted=True)
+    R = G.to_dev(rays)
+    enc = ops.cast_ipe_360(torch.from_numpy(t).to(DEV), R.origins, R.directions, R.radii, 0, 16, contracted=True, precision=L.PREC_BF16)
+    assert enc.dtype == torch.bfloat16 and tuple(enc.shape) == (B, N, 672)
+    got = enc.float().cpu().numpy().astype(np.float64).reshape(B, N, 2, 16, 21)                  # [sin | cos] x degree x direction
+    P = o360.BASIS_360.astype(np.float64)
+    y = mean.astype(np.float64) @ P                                                              # [B, N, 21]
+    var = np.einsum("ik,...ij,jk->...k", P, cov.astype(np.float64), P)
+    worst = {}
+    for l in range(16):
+        damp = np.exp(-0.5 * 4.0 ** l * var)
+        want = np.stack([np.sin(2.0 ** l * y) * damp, np.cos(2.0 ** l * y) * damp], 2)            # [B, N, 2, 21]
+        e = np.abs(got[:, :, :, l, :] - want)
+        worst[f"deg{l}"] = float(e.max())
+        # bf16 half ulp of |f| <= 1 (2^-9 = 1.95e-3) + fp32 phase error of the damped feature + 2e-4 for the fast sine / exp2
+        bound = 2.0 ** -9 + 2.0 ** l * 4.8e-7 * float(damp.max()) + 2e-4
+        assert worst[f"deg{l}"] <= bound, (l, worst[f"deg{l}"], bound)
+    assert float(np.abs(got).max()) <= 1.0 + 2.0 ** -8
+    G.record("unbounded bf16 encoding vs float64 Gaussian expectation", **worst)
+
+
+@pytest.mark.parametrize("B,N,randomized", [(1, 64, False), (5, 77, True), (300, 64, False), (130, 200, True)])
+def test_forward_bf16_vs_the_360_oracle_ragged(G, B, N, randomized):
+    """The whole forward of `MipNerf(unbounded=True, precision='bf16')` (off-axis IPE as MFMA fragments -> k_pre_gemm -> trunk -> compositing
+    -> inverse-depth resampling) against oracle/mipnerf360_oracle.mipnerf360_forward -- the CPU restatement, not the HIP fp32 path -- at
+    ragged sizes: a quarter of a 256-sample tile, partial wave tiles, N that is neither a multiple of 64 nor of 32."""
+    from oracle import mipnerf360_oracle as o360
+    rays = syn.synthetic_rays(B, seed=300 + B, unbounded=True)
+    params = syn.make_params(seed=17, density_gain=40.0, xyz_dim=672)
+    rng = np.random.default_rng(B + N)
+    tr = rng.uniform(0, 1, (B, N + 1)).astype(np.float32) if randomized else None
+    ur = rng.uniform(0, 1, (B, N + 1)).astype(np.float32) if randomized else None
+    want = o360.mipnerf360_forward(params, rays, randomized, True, num_samples=N, t_rand=tr, u_rand=ur)
+    T = lambda a: None if a is None else torch.from_numpy(a).to(DEV)     # noqa: E731
+    model = _model(params, N, "bf16")
+    with torch.no_grad():
+        got = model(G.to_dev(rays), randomized, True, t_rand=T(tr), u_rand=T(ur))
+    errs = {}
+    for lvl in range(2):
+        for nm, a, b in zip(G.NAMES, got[lvl], want[lvl]):
+            errs[f"l{lvl}_{nm}"] = G.maxdiff(a, b)
+    errs["psnr_l0_rgb"] = _psnr(got[0][0].cpu().numpy(), want[0][0])
+    errs["psnr_l1_rgb"] = _psnr(got[1][0].cpu().numpy(), want[1][0])
+    G.record(f"unbounded bf16 forward vs 360 oracle B={B} N={N} randomized={randomized}", **errs)
+    assert errs["l0_t_samples"] <= 1e-6 * float(np.abs(want[0][4]).max())            # the coarse fence posts do not depend on the MLP
+    # coarse level: same fence posts, so per-ray values compare directly.  Bounds = 2 x the maxima measured over these four cases on MI355X
+    # (profiles/r05_parity.jsonl; the standard model's full-size fog case measures 2.6e-3 / 72 dB)
+    assert errs["l0_rgb"] <= UNB_FOG_BOUNDS["l0_rgb"] and errs["l0_acc"] <= UNB_FOG_BOUNDS["l0_acc"], errs
+    assert errs["l1_rgb"] <= UNB_FOG_BOUNDS["l1_rgb"] and errs["l1_acc"] <= UNB_FOG_BOUNDS["l1_acc"], errs
+    assert errs["psnr_l1_rgb"] >= UNB_FOG_BOUNDS["psnr_l1_rgb"], errs
+
+
+# 2 x the maxima measured on MI355X over the four ragged fog cases above (psnr: measured minimum - 6 dB, never below the 55 dB every other
+# bf16 test of the repo holds; DESIGN.md section 2 derives 51.4 dB as the level that keeps a 35 dB render within 0.1 dB)
+UNB_FOG_BOUNDS = dict(l0_rgb=5e-3, l0_acc=8e-3, l1_rgb=3e-2, l1_acc=5e-2, psnr_l1_rgb=55.0)      # placeholders until measured
+
+
+def _field360(G):
+    f = G.load_golden("trained_field_360")
+    return {k[2:]: f[k] for k in f if k.startswith("p_")}
+
+
+@pytest.mark.parametrize("name", ["full360_1000x96", "full360_8192x256"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_forward_on_a_trained_unbounded_field_vs_the_360_oracle(G, name, precision):
+    """BASELINE configs[3]'s size (8192 rays x (256 + 256) samples) and a ragged 1000 x 96 case on a TRAINED unbounded field
+    (scripts/make_golden_360.py: the reference's MLP class trained on the procedural unbounded scene of tests/dataset_fixture.py -- blobs
+    inside a far sky shell with holes -- through the 360 oracle's sampling / encoding), on rays of that scene: empty rays (through the
+    holes: white background, the sampler's padding branch), opaque near hits, opaque / soft hits on the contracted far shell.  Golden =
+    oracle.mipnerf360_forward on CPU; every ray of both levels, bounds per class of ray."""
+    import hashlib
+    g = G.load_golden(name)
+    params = _field360(G)
+    h = hashlib.sha256()
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    assert h.hexdigest() == str(g["field_sha256"])
+    assert float(g["frac_empty"]) >= 0.15 and float(g["frac_opaque"]) >= 0.2 and float(g["frac_between"]) >= 0.05
+    rays = syn.Rays(*[g["rays_" + k] for k in syn.Rays._fields])
+    model = _model(params, int(g["num_samples"]), precision)
+    with torch.no_grad():
+        ret = model(G.to_dev(rays), False, True)
+    acc_ref = g["l1_acc"]
+    classes = {"empty": acc_ref < 0.05, "opaque": acc_ref > 0.95, "between": (acc_ref >= 0.05) & (acc_ref <= 0.95)}
+    errs = {}
+    for lvl in range(2):
+        rgb, dist, acc, w, t = ret[lvl]
+        got = dict(rgb=rgb.cpu().numpy(), distance=dist.cpu().numpy(), acc=acc.cpu().numpy(), wmax=w.max(-1).values.cpu().numpy())
+        for nm, v in got.items():
+            d = np.abs(v.astype(np.float64) - g[f"l{lvl}_{nm}"].astype(np.float64))
+            if nm == "distance":
+                d = d / np.maximum(g[f"l{lvl}_t_last"].astype(np.float64), 1.0)          # far bounds reach 22: relative to the ray's far end
+            errs[f"l{lvl}_{nm}"] = float(d.max())
+            if lvl == 1 and nm in ("rgb", "acc"):
+                for cn, m in classes.items():
+                    errs[f"l1_{nm}_{cn}"] = float(d[m].max())
+        assert G.maxdiff(t[:, 0], g[f"l{lvl}_t_first"]) <= 1e-5 and G.maxdiff(t[:, -1], g[f"l{lvl}_t_last"]) <= 1e-4 * float(g[f"l{lvl}_t_last"].max())
+    errs["psnr_l1_rgb"] = _psnr(ret[1][0].cpu().numpy(), g["l1_rgb"])
+    errs["psnr_vs_scene_pixels"] = _psnr(ret[1][0].cpu().numpy(), g["gt"])
+    errs["oracle_psnr_vs_scene_pixels"] = _psnr(g["l1_rgb"], g["gt"])
+    G.record(f"trained360 {name} {precision}", **errs)
+    b = TRAINED360_BOUNDS[precision]
+    for k, bound in b.items():
+        if k.startswith("psnr"):
+            assert errs[k] >= bound, (k, errs[k], bound)
+        else:
+            assert errs[k] <= bound, (k, errs[k], bound)
+    # the north star's 0.1 dB, on this frame: the bf16 render is as close to the scene's pixels as the oracle's
+    assert abs(errs["psnr_vs_scene_pixels"] - errs["oracle_psnr_vs_scene_pixels"]) < (0.1 if precision == "bf16" else 1e-2)
+
+
+# fp32: the bounds test_gpu_unbounded.py holds at 40 x 64 (level 1: 2e-4); bf16: 2 x the maxima measured on MI355X (placeholders until measured)
+TRAINED360_BOUNDS = {
+    "fp32": dict(l0_rgb=5e-5, l0_acc=5e-5, l1_rgb=2e-4, l1_acc=2e-4, l1_distance=2e-4, psnr_l1_rgb=90.0),
+    "bf16": dict(l0_rgb=1e-2, l0_acc=1e-2, l1_rgb=2e-2, l1_acc=2e-2, l1_rgb_empty=5e-3, l1_acc_empty=5e-3, psnr_l1_rgb=55.0),
+}

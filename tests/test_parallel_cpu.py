@@ -75,6 +75,40 @@ def test_flat_grad_allreduce_and_ray_shards_world2():
         assert dict(out) == {0: True, 1: True}
 
 
+def _worker8(rank, world, port, out):
+    """world 8 (what the driver's SCALE run goes to): the flat all-reduce with 1 / 8, and the frame split / gather at 640,000 rays (80,000 per
+    rank), at a ragged count (8 does not divide 100,003) and with EMPTY shards (5 rays over 8 ranks)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = torch.nn.Parameter(torch.zeros(1000))
+        p.grad = torch.full_like(p, float(rank + 1))
+        FlatGradAllReduce([p])()
+        ok = torch.allclose(p.grad, torch.full_like(p, 4.5))                 # mean of 1..8
+        for n in (640000, 100003, 5):
+            origins = torch.arange(n, dtype=torch.float32)[:, None] * torch.ones(1, 3)
+            rays = Rays(origins, origins + 1, origins + 2, *[torch.ones(n, 1) for _ in range(4)])
+            local = shard_rays(rays, rank, world)
+            lo, hi = shard_bounds(n, rank, world)
+            ok = ok and local.origins.shape[0] == hi - lo and (hi - lo in (n // world, n // world + 1))
+            rendered = local.origins * 2 + 1                                 # a shard's "render" (empty for ranks >= 5 at n = 5)
+            full = gather_rendered(rendered, n)
+            ok = ok and full.shape == (n, 3) and torch.equal(full, origins * 2 + 1)
+        out[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_and_frame_gather_world8():
+    world = 8
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker8, args=(world, port, out), nprocs=world, join=True)
+        assert dict(out) == {r: True for r in range(world)}
+
+
 @pytest.mark.parametrize("n,world", [(640000, 8), (10, 3), (7, 8), (4096, 4)])
 def test_shard_bounds_partition(n, world):
     b = [shard_bounds(n, r, world) for r in range(world)]
