@@ -28,6 +28,9 @@ WAVES = 8
 CHUNK_BYTES = 1024
 PREFETCH = int(os.environ.get("MLP_TRAIN_PREFETCH", "4"))
 ABLATE_TMFMA = os.environ.get("MLP_TRAIN_ABLATE_TMFMA", "0") == "1"    # timing experiment: no transposing MFMAs (wrong T-blocks)
+# timing experiment: comma-separated forward op indices whose saved-activation T-blocks are neither transposed nor stored
+# ("store every other layer"; the weight-gradient kernel would recompute them: MLP_WGRAD_RECOMPUTE_PROBE).  Wrong gradients.
+SKIP_STORES = {int(x) for x in os.environ.get("MLP_TRAIN_SKIP_STORES", "0").split(",") if x.strip() and os.environ.get("MLP_TRAIN_SKIP_STORES", "0") != "0"}
 NE = 3
 
 TRAIN_PREAMBLE = r"""
@@ -303,7 +306,7 @@ def build_fwd_prog(tp: TrainPlan):
                         continue
                     post.append(f"epilogue_half<{relu}, 0>({acc}, {op.out}[{2 * t}]);  /*op{oi}*/")
                     post.append(f"epilogue_half<{relu}, 8>({acc}, {op.out}[{2 * t + 1}]);  /*op{oi}*/")
-                    if hb is not None:
+                    if hb is not None and oi not in SKIP_STORES:
                         if not ABLATE_TMFMA:
                             post_t.append(f"TMFMA0({acc}, {op.out}[{2 * t}], P1);  /*op{oi}*/")
                             post_t.append(f"MFMA({acc}, {op.out}[{2 * t + 1}], P2);  /*op{oi}*/")

@@ -64,6 +64,100 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* p) {
 #else
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 #endif
+
+// Timing experiment ("store every other layer, recompute the skipped one here"): MLP_WGRAD_RECOMPUTE_PROBE=<bit mask of
+// job ids>.  The workgroups of those jobs run k_wgrad_recompute_body: a stage carries the instruction mix of the role-flipped recompute
+// job -- wave w owns activation block w of the SKIPPED layer: it forms relu(W[block w, :] a_prev) for the stage's 32 samples (16 k-steps:
+// A = a_prev read from the stage's activation T-blocks with transposing ds_read_b64_tr_b16, B = its 16-KiB slice of W held in 64
+// registers), packs the tile to bf16 -- which IS its B operand of the weight-gradient MFMAs -- and contracts it against all eight delta
+// blocks (16 ds_read_b128 as A operands); the bias gradient of delta block w is 16 VALU adds.  Same HBM bytes per stage as today's job
+// (delta + a_prev); + 16 MFMAs, + 32 transposing LDS reads, + one epilogue per wave and stage.  The operands are whatever the T-blocks
+// hold: the RESULTS ARE WRONG by construction (build.py demands an opt-in).
+#if defined(MIP_WGRAD_RECOMPUTE_PROBE) && MIP_WGRAD_RECOMPUTE_PROBE
+typedef short v4s16p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_frag_tr(const char* p) {
+    const v4s16p lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16p*)(size_t)(p));
+    const v4s16p hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16p*)(size_t)(p + 8));
+    typedef short v8s16p __attribute__((ext_vector_type(8)));
+    const v8s16p v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ void k_wgrad_recompute_body(char* smem, const char* __restrict__ HT, const char* __restrict__ GT, const WgradJob* jp,
+                                                       const int4 wg, int64_t n_wt, int NH, int NG, float* __restrict__ partials, int lane, int wave) {
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int64_t lo = n_wt * wg.y / wg.z, hi = n_wt * (wg.y + 1) / wg.z;
+    const int nst = (int)(hi - lo);
+    // the job's own activation blocks are the ones the forward no longer stores (MLP_TRAIN_SKIP_STORES): read the NEXT layer's blocks
+    // (8 further on, stored, ordinary relu activations) in their place -- same bytes, operands that toggle like the real ones would
+    const int a_blk = jp->a_blk[wave], b_blk = jp->b_blk[wave] + 8;
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    float bias_sum = 0.0f;
+    bf16x8 wslice[16];                                    // this wave's 32 x 256 slice of the skipped layer's weights (any bits will do)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) wslice[k] = *reinterpret_cast<const bf16x8*>(HT + ((int64_t)(wave * 16 + k) * 64 + lane) * 16);
+    auto issue = [&](int64_t wt, int stage) {
+        char* st = smem + stage * kStageBytes;
+        dma_block(HT + (wt * NH + b_blk) * 2048, st + wave * 2048, lane16);
+        dma_block(GT + (wt * NG + a_blk) * 2048, st + 16384 + wave * 2048, lane16);
+    };
+    if (nst > 0) {
+#pragma unroll
+        for (int s = 0; s < kStages - 1; ++s) issue(lo + (s < nst ? s : nst - 1), s);
+        for (int i = 0; i < nst; ++i) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kStages - 2)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            const int nxt = i + kStages - 1;
+            issue(lo + (nxt < nst ? nxt : nst - 1), nxt % kStages);
+            const char* st = smem + (i % kStages) * kStageBytes + lane16;
+            f32x16 r0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) r0[r] = 0.0f;
+            bf16x8 t = lds_frag_tr(st);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {                // 16 k-steps over a_prev's 8 blocks x 2 fragments, next operand one step ahead
+                bf16x8 tn = t;
+                if (k + 1 < 16) tn = lds_frag_tr(st + (k + 1) * 1024);
+                r0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t, wslice[k], r0, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                t = tn;
+            }
+            bf16x8 x0, x1;                                // relu + bf16: the recomputed activation block, as B fragments
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x0[r] = (__bf16)fmaxf(r0[r], 0.0f);
+                x1[r] = (__bf16)fmaxf(r0[r + 8], 0.0f);
+            }
+            bf16x8 d0 = lds_frag(st + 16384), d1 = lds_frag(st + 16384 + 1024);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                 // all eight delta blocks against the wave's activation block
+                bf16x8 e0 = d0, e1 = d1;
+                if (j + 1 < 8) { e0 = lds_frag(st + 16384 + (j + 1) * 2048); e1 = lds_frag(st + 16384 + (j + 1) * 2048 + 1024); }
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, x0, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, x1, acc[j], 0, 0, 0);
+                if (j == wave) {                          // the bias gradient of delta block w: 16 VALU adds per stage
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) bias_sum += (float)d0[r] + (float)d1[r];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                d0 = e0; d1 = e1;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    float* out = partials + (int64_t)wg.w * kWgradJobFloats + (int64_t)wave * 9 * 1024 + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(out + j * 1024 + q * 4) = make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+    out[8 * 1024] = bias_sum;
+}
+#endif
 }  // namespace
 
 __global__ void __launch_bounds__(512)
@@ -76,6 +170,12 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
     const unsigned lane16 = (unsigned)lane * 16u;
     const int4 wg = wg_tab[blockIdx.x];                     // job, split, nsplits, partial slot
     const WgradJob* jp = jobs + wg.x;                       // uniform: scalar loads
+#if defined(MIP_WGRAD_RECOMPUTE_PROBE) && MIP_WGRAD_RECOMPUTE_PROBE
+    if ((MIP_WGRAD_RECOMPUTE_PROBE >> wg.x) & 1) {          // timing experiment, workgroup-uniform
+        k_wgrad_recompute_body(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, lane, wave);
+        return;
+    }
+#endif
     const int nA = jp->nA, nB = jp->nB;
     const bool with_bias = jp->bias != 0;
     const int64_t lo = n_wt * wg.y / wg.z, hi = n_wt * (wg.y + 1) / wg.z;

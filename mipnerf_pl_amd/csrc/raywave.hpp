@@ -264,24 +264,31 @@ __device__ __forceinline__ void pdf_ray(int lane, int N, const float* __restrict
         for (int it = 0; it < steps; ++it) {
 #pragma unroll
             for (int q = 0; q < T; ++q) {
+                // branch-free (selects): the T reads of a step are issued together; a finished search (lo == hi) re-reads an entry and keeps its range
                 const int mid = (lo[q] + hi[q]) >> 1;
-                const float cm = s_cdf[mid < N ? mid : N];
-                if (lo[q] < hi[q]) {
-                    if (cm <= u[q]) lo[q] = mid + 1; else hi[q] = mid;
-                }
+                const float cm = s_cdf[min(mid, N)];
+                const bool go = lo[q] < hi[q], le = cm <= u[q];
+                lo[q] = (go && le) ? mid + 1 : lo[q];
+                hi[q] = (go && !le) ? mid : hi[q];
             }
         }
+        float c0[T], c1[T], b0[T], b1[T];
+#pragma unroll
+        for (int q = 0; q < T; ++q) {                  // the 4 T interval reads of the trip together (pinned: the compiler would sink
+            const int below = max(0, lo[q] - 1);       // them into the store's branch, one dependent LDS round trip per draw)
+            const int above = min(N, lo[q]);
+            c0[q] = s_cdf[below]; c1[q] = s_cdf[above];
+            b0[q] = s_bins[below]; b1[q] = s_bins[above];
+        }
+#pragma unroll
+        for (int q = 0; q < T; ++q) asm volatile("" : "+v"(c0[q]), "+v"(c1[q]), "+v"(b0[q]), "+v"(b1[q]));
 #pragma unroll
         for (int q = 0; q < T; ++q) {
             const int j = j0 + 64 * q;
-            const int below = max(0, lo[q] - 1);
-            const int above = min(N, lo[q]);
-            const float c0 = s_cdf[below], c1 = s_cdf[above];
-            const float b0 = s_bins[below], b1 = s_bins[above];
-            float denom = c1 - c0;
+            float denom = c1[q] - c0[q];
             denom = (denom < 1e-5f) ? 1.0f : denom;
-            const float tt = (u[q] - c0) / denom;
-            if (out_row && j < n_draws) out_row[j] = b0 + tt * (b1 - b0);
+            const float tt = (u[q] - c0[q]) / denom;
+            if (out_row && j < n_draws) out_row[j] = b0[q] + tt * (b1[q] - b0[q]);
         }
     }
 }

@@ -206,7 +206,9 @@ class NativeContext:
             self._scratch = {}
         t = self._scratch.get(name)
         if t is None or t.numel() < nbytes:
-            t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            # MIPNERF_ZERO_SCRATCH=1: timing experiments whose kernels leave parts of a buffer unwritten (build.py: WRONG_RESULT_KNOBS)
+            alloc = torch.zeros if os.environ.get("MIPNERF_ZERO_SCRATCH") == "1" else torch.empty
+            t = alloc(nbytes, dtype=torch.uint8, device=self.device)
             self._scratch[name] = t
         return t
 

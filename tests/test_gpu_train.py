@@ -368,14 +368,17 @@ def test_flat_adam_equals_torch_adam(G):
     assert k0 == k1
     eg = G.maxdiff(g0, g1) / float(g0.abs().max())
     ep = G.maxdiff(p0, p1)
-    G.record("flat_adam_vs_torch_adam", grad_rel=eg, param_abs=ep, loss0=l0[-1], loss1=l1[-1])
+    emean = float((p0 - p1).abs().mean())
+    G.record("flat_adam_vs_torch_adam", grad_rel=eg, param_abs=ep, param_mean_abs=emean, loss0=l0[-1], loss1=l1[-1])
     assert eg <= 1e-6                     # same kernels; only (a + b) association of the two levels could differ
     # The two optimisers round differently by at most an fp32 ulp per step; once one master weight sits within that ulp of
     # a bf16 rounding boundary its packed value flips, the loss moves by ~1e-6 and Adam's g / sqrt(v) turns sign changes
     # of near-zero gradients into +-lr (observed: 3.5e-4 on a handful of parameters after 4 steps, loss equal to 2e-5).
     # Bound = a few learning rates; the per-step arithmetic itself is pinned by test_device_lr_schedule_equals_host_miplrdecay.
     assert ep <= 4 * 1.73e-4 and abs(l0[-1] - l1[-1]) <= 1e-4 * max(1.0, abs(l0[-1]))
-    assert float((p0 - p1).abs().mean()) <= 2e-7
+    # mean over the 612,740 parameters: a few hundred such flips of +-lr (round 5: the wave reductions of the ray kernels associate
+    # their sums differently, which moved WHICH gradients sit at zero; measured 1e-7 ... 4e-7)
+    assert emean <= 1e-6, emean
     assert l0[-1] != l0[0]                # the weights did move (re-pack after the raw-kernel update is effective)
 
 

@@ -221,7 +221,10 @@ def test_forward_bf16_vs_the_360_oracle_ragged(G, B, N, randomized):
 
 # 2 x the maxima measured on MI355X over the four ragged fog cases above (psnr: measured minimum - 6 dB, never below the 55 dB every other
 # bf16 test of the repo holds; DESIGN.md section 2 derives 51.4 dB as the level that keeps a 35 dB render within 0.1 dB)
-UNB_FOG_BOUNDS = dict(l0_rgb=5e-3, l0_acc=8e-3, l1_rgb=3e-2, l1_acc=5e-2, psnr_l1_rgb=55.0)      # placeholders until measured
+# measured (profiles/r05a_parity.jsonl): l0 rgb 3.1e-3 / acc 6.2e-3 (coarse PSNR 70.4-75.9 dB), l1 rgb 1.3e-2 / acc 2.3e-2, fine PSNR 57.6-65.7 dB.
+# The fine level of a FOG field is the hard case: random weights with 16 undamped degrees are white noise in space, so the 1e-2 shifts of
+# the resampled fence posts show up in the colour (the trained-field test below is the realistic one; scripts/analysis/bf16_360_error_budget.py)
+UNB_FOG_BOUNDS = dict(l0_rgb=6.2e-3, l0_acc=1.25e-2, l1_rgb=2.7e-2, l1_acc=4.7e-2, psnr_l1_rgb=55.0)
 
 
 def _field360(G):
