@@ -38,7 +38,8 @@ UNITS = [
     ("mlp_bf16_dgrad_gen.hip", NO_IEEE),
     ("kernels_wgrad.hip", ["-DMIP_WGRAD_NT=" + os.environ.get("MLP_WGRAD_NT", "1"), "-DMIP_WGRAD_STAGES=" + os.environ.get("MLP_WGRAD_STAGES", "4"),
                            "-DMIP_WGRAD_TR=" + os.environ.get("MLP_WGRAD_TR", "0"),
-                           "-DMIP_WGRAD_RECOMPUTE_PROBE=" + os.environ.get("MLP_WGRAD_RECOMPUTE_PROBE", "0")]),
+                           "-DMIP_WGRAD_RECOMPUTE_PROBE=" + os.environ.get("MLP_WGRAD_RECOMPUTE_PROBE", "0"),
+                           "-DMIP_WGRAD_RECOMPUTE_SCHED=" + os.environ.get("MLP_WGRAD_RECOMPUTE_SCHED", "0")]),
     ("kernels_eval.hip", ["-ffp-contract=off"]),
     ("selftest.hip", ["-ffp-contract=off"]),
     ("capi.hip", []),

@@ -1256,7 +1256,7 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     // ---- forward (mip_nerf.py:182-246), activations saved for the backward -------------------------------------------
     // option 4 (fuse_small): pos_enc + coarse fence posts in one launch; per level compositing + distloss (+ the next level's
     // fence posts) in one launch instead of three -- same per-ray device functions, same bits
-    const bool fuse_tail = c->fuse_small && (N <= 128 || (N > 192 && N <= 256));
+    const bool fuse_tail = c->fuse_small != 0;        // every N <= MIPNERF_MAX_SAMPLES (round 5: one set of K buckets in all per-ray kernels)
     if (c->fuse_small) {
         HIP_TRY(mip::launch_ray_prologue(B, cfg.deg_view, rays->viewdirs, viewenc, 32, true, N, rays->near, rays->far, t_rand, disparity,
                                          lv[0].t, S(stream)));
@@ -1439,7 +1439,7 @@ int mipnerf_forward(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const f
             return rc;
         }
         if (c->time_mlp == 1) HIP_TRY(hipEventRecord(e1, S(stream)));
-        if (c->fuse_small && lvl + 1 < cfg.num_levels && (N <= 128 || (N > 192 && N <= 256))) {
+        if (c->fuse_small && lvl + 1 < cfg.num_levels) {
             // compositing of this level + the next level's fence posts in one launch (weights go registers -> LDS, not through HBM)
             const mipnerf_level_out& nx = out[lvl + 1];
             if (!nx.t_samples) return fail(MIPNERF_E_INVALID, "forward: output pointer of level %d is null", lvl + 1);

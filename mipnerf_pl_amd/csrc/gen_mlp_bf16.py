@@ -64,9 +64,11 @@ VARIANTS = [
     # contracted Gaussians (kernels_360.hip) to the same 8 x 256 trunk (first layer 672 -> 256, skip concat 256 + 672).  fp32 only:
     # 42 k-steps per sample do not fit the bf16 kernels' 8-KiB wave-private encoding area.
     Arch(xyz_dim=672, feat_per_deg=42, bf16_kernels=False),
-    # two view layers (mlp_net_depth_condition = 2, mip_nerf.py:62-69): fp32 forward + GEMM backward (the bf16 stream would need
-    # one more ring group of zero padding than the inference generator's tile-to-tile phase allows; bf16 training is one view layer)
-    Arch(net_depth_condition=2, bf16_kernels=False),
+    # two view layers (mlp_net_depth_condition = 2, mip_nerf.py:62-69).  Round 5: bf16 INFERENCE kernel too -- its stream is 39 ring
+    # groups + one whole group of zero padding (the ring phase must be tile-invariant: an even number of groups), which the generator
+    # handles since the trunk kernels of round 4 (an extra GROUP_BEGIN at the tile end).  Training: fp32 forward + GEMM backward
+    # (the bf16 training schedule is generated for one view layer, mlp_train_plan.py).
+    Arch(net_depth_condition=2),
     # a 512-wide trunk with a 256-wide view layer (fp32 only: the bf16 kernels hold a layer's activations in registers, <= 256 wide)
     Arch(net_width=512, net_width_condition=256, bf16_kernels=False),
 ]
@@ -460,8 +462,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     assert lds_bytes <= 160 * 1024
     panels, slots = build_schedule(plan)
     nreal = len(slots)
-    # padding: inside the last ring group, or (trunk plans) exactly one whole group of zeros, begun by an extra GROUP_BEGIN at the tile end
-    assert nreal == plan.n_real_chunks and (nchunks - nreal < GROUP or (pre and nchunks - nreal == GROUP and nreal % GROUP == 0))
+    # padding: inside the last ring group, or exactly one whole group of zeros, begun by an extra GROUP_BEGIN at the tile end (trunk plans; two view layers)
+    assert nreal == plan.n_real_chunks and (nchunks - nreal < GROUP or (nchunks - nreal == GROUP and nreal % GROUP == 0))
     lines = []
     e = lines.append
     e("// AUTO-GENERATED by gen_mlp_bf16.py from mlp_plan.py -- do not edit by hand.")

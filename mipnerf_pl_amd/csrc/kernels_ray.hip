@@ -328,10 +328,11 @@ hipError_t launch_volumetric_rendering(int64_t B, int N, const float* rgb_sigma,
     hipLaunchKernelGGL((k_volumetric_rendering<KK>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd,  \
                        comp_rgb, distance, acc, weights)
     switch (K) {
+        // the K buckets EVERY per-ray kernel uses (1, 2, 4, 8 samples per lane): a ray's sums associate by K, so one set of buckets lets
+        // the fused launches (k_composite_resample, k_composite_train) reproduce the per-stage kernels bit for bit at every N <= 512
         case 1: MIP_VR(1); break;
         case 2: MIP_VR(2); break;
-        case 3: MIP_VR(3); break;
-        case 4: MIP_VR(4); break;
+        case 3: case 4: MIP_VR(4); break;
         case 5: case 6: case 7: case 8: MIP_VR(8); break;
         default: return hipErrorInvalidValue;
     }
@@ -386,8 +387,9 @@ hipError_t launch_composite_resample(int64_t B, int N, const float* rgb_sigma, c
     switch (K) {      // the same K buckets as the stand-alone kernels use, so both routes give the same bits
         case 1: MIP_CR(1); break;
         case 2: MIP_CR(2); break;
-        case 4: MIP_CR(4); break;                   // N in (192, 256]: both stand-alone kernels use K = 4 there too
-        default: return hipErrorNotSupported;       // K = 3, 5..8: the stand-alone kernels use different K buckets -> two launches
+        case 3: case 4: MIP_CR(4); break;
+        case 5: case 6: case 7: case 8: MIP_CR(8); break;
+        default: return hipErrorInvalidValue;
     }
 #undef MIP_CR
     return hipGetLastError();

@@ -247,11 +247,12 @@ hipError_t launch_composite_train(int64_t B, int N, const float* rgb_sigma, cons
         else hipLaunchKernelGGL((k_composite_train<KK, false>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd, comp_rgb, distance, acc, \
                                 weights, ray_loss, g_const, d_w, u_rand, padding, u_step, u_jitter, t_new);                               \
     } while (0)
-    switch (K) {      // the K buckets all three stand-alone kernels share (1, 2, 4), so the fused route gives the same bits
+    switch (K) {      // the K buckets every stand-alone per-ray kernel uses (1, 2, 4, 8), so the fused route gives the same bits at every N <= 512
         case 1: MIP_CT(1); break;
         case 2: MIP_CT(2); break;
-        case 4: MIP_CT(4); break;
-        default: return hipErrorNotSupported;
+        case 3: case 4: MIP_CT(4); break;
+        case 5: case 6: case 7: case 8: MIP_CT(8); break;
+        default: return hipErrorInvalidValue;
     }
 #undef MIP_CT
     return hipGetLastError();

@@ -74,6 +74,9 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_
 // (delta + a_prev); + 16 MFMAs, + 32 transposing LDS reads, + one epilogue per wave and stage.  The operands are whatever the T-blocks
 // hold: the RESULTS ARE WRONG by construction (build.py demands an opt-in).
 #if defined(MIP_WGRAD_RECOMPUTE_PROBE) && MIP_WGRAD_RECOMPUTE_PROBE
+#ifndef MIP_WGRAD_RECOMPUTE_SCHED
+#define MIP_WGRAD_RECOMPUTE_SCHED 0
+#endif
 typedef short v4s16p __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 lds_frag_tr(const char* p) {
     const v4s16p lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16p*)(size_t)(p));
@@ -114,6 +117,8 @@ __device__ __forceinline__ void k_wgrad_recompute_body(char* smem, const char* _
             const int nxt = i + kStages - 1;
             issue(lo + (nxt < nst ? nxt : nst - 1), nxt % kStages);
             const char* st = smem + (i % kStages) * kStageBytes + lane16;
+#if MIP_WGRAD_RECOMPUTE_SCHED == 0
+            // first form (profiles/r05b_*): one accumulator chain, the next operand one k-step ahead
             f32x16 r0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) r0[r] = 0.0f;
@@ -132,6 +137,29 @@ __device__ __forceinline__ void k_wgrad_recompute_body(char* smem, const char* _
                 x0[r] = (__bf16)fmaxf(r0[r], 0.0f);
                 x1[r] = (__bf16)fmaxf(r0[r + 8], 0.0f);
             }
+#else
+            // second form: two accumulator chains (even / odd k-steps), operands four k-steps ahead (a ring of four fragments)
+            f32x16 r0, r1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { r0[r] = 0.0f; r1[r] = 0.0f; }
+            bf16x8 tq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tq[k] = lds_frag_tr(st + k * 1024);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const bf16x8 t = tq[k & 3];
+                if (k & 1) r1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t, wslice[k], r1, 0, 0, 0);
+                else r0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t, wslice[k], r0, 0, 0, 0);
+                if (k + 4 < 16) tq[k & 3] = lds_frag_tr(st + (k + 4) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bf16x8 x0, x1;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x0[r] = (__bf16)fmaxf(r0[r] + r1[r], 0.0f);
+                x1[r] = (__bf16)fmaxf(r0[r + 8] + r1[r + 8], 0.0f);
+            }
+#endif
             bf16x8 d0 = lds_frag(st + 16384), d1 = lds_frag(st + 16384 + 1024);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {                 // all eight delta blocks against the wave's activation block

@@ -198,7 +198,7 @@ def quality_batch_ids(n_pixels, steps, batch, seed):
 # The blobs above around the origin + a far "sky" shell of radius 8 whose density is switched on and off smoothly with the
 # direction, so a ray through the scene ends on a blob (opaque, near), on the shell (opaque or soft, far: contracted space),
 # or leaves through a hole of the shell (empty).  Cameras sit INSIDE the shell and look at the origin, LLFF-style per-view bounds.
-SCENE360 = dict(shell_radius=8.0, shell_sigma=0.5, shell_density=6.0, views=24, res=48, radius=(2.6, 3.4), near=(0.6, 1.1), far=(16.0, 22.0), seed=77)
+SCENE360 = dict(shell_radius=8.0, shell_sigma=0.5, shell_density=6.0, views=28, res=44, fov=1.6, radius=(2.6, 3.4), near=(0.6, 1.1), far=(16.0, 22.0), seed=77)
 
 
 def _scene360_density_colour(p):
@@ -241,7 +241,7 @@ def scene360_rays():
     rng = np.random.RandomState(S["seed"])
     rays, rgbs = [], []
     res = S["res"]
-    focal = 0.5 * res / np.tan(0.5 * 0.9)
+    focal = 0.5 * res / np.tan(0.5 * S["fov"])       # wide: ~24 % of the rays leave through a hole of the shell, ~47 % end opaque
     p2c = np.asarray([[1.0 / focal, 0.0, -0.5 * res / focal], [0.0, -1.0 / focal, 0.5 * res / focal], [0.0, 0.0, -1.0]])
     for _ in range(S["views"]):
         c2w = _look_at_pose(rng, radius=rng.uniform(*S["radius"]))
