@@ -34,7 +34,7 @@ sys.path.insert(0, REPO)
 
 FLOP_PER_SAMPLE = 1_220_608          # 2 x 610,304 MAC of the MLP per ray-sample (forward)
 FLOP_PER_SAMPLE_TRAIN = 3_556_608    # forward + dgrad + wgrad
-CURRENT_ROUND = 4          # profiles/mlp_pmc.json must carry this round's PMC passes (VERDICT r03 hygiene): bump it and re-run scripts/pmc_traffic.sh every round
+CURRENT_ROUND = 5          # profiles/mlp_pmc.json must carry this round's PMC passes (VERDICT r03 hygiene): bump it and re-run scripts/pmc_traffic.sh every round
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 
 

@@ -44,6 +44,7 @@ BF16_MEASURED = {
     "full_size B=4096": dict(rgb=9.1e-3, distance=3.7e-2, acc=1.9e-2, weights=1.9e-2, t_samples=1.1e-2),
     "density_noise": dict(rgb=5.0e-4, distance=2.0e-3, acc=8.2e-4, weights=2.3e-3, t_samples=5.5e-3),
     "variant var_d6s3_48x64": dict(rgb=4.9e-3, distance=5.4e-2, acc=8.6e-3, weights=4.0e-2, t_samples=3.3e-2),
+    "variant var_dc2_48x64": dict(rgb=6.4e-3, distance=4.1e-2, acc=1.2e-2, weights=2.7e-2, t_samples=3.6e-2),
     "variant var_noview_48x64": dict(rgb=7.7e-4, distance=9.2e-3, acc=4.2e-4, weights=7.7e-3, t_samples=1.2e-2),
     "variant var_w100c40_48x64": dict(rgb=2.2e-3, distance=2.0e-2, acc=1.9e-3, weights=2.6e-2, t_samples=2.5e-2),
     "variant var_w128_48x64": dict(rgb=2.1e-3, distance=0.0, acc=3.5e-3, weights=2.8e-3, t_samples=1.1e-2),
