@@ -2,16 +2,16 @@
 # HBM bytes per launch of the MFMA kernels from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE
 # in SEPARATE passes, --kernel-trace only, FETCH_SIZE doubled on gfx950.  Writes gpurun_out/pmc_traffic.json (copy it to
 # profiles/mlp_pmc.json: bench.py reads roofline.traffic from there and refuses a file of another round).
-#   usage: ROUND=4 bash scripts/pmc_traffic.sh
+#   usage: ROUND=5 bash scripts/pmc_traffic.sh
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_traffic; mkdir -p $OUT
-ROUND=${ROUND:-4}
+ROUND=${ROUND:-5}
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/inf_$c -o pmc -- python $ROOT/bench.py --mode inference --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --preheat-seconds 0 --ceiling-seconds 0 > $OUT/inf_$c.log 2>&1; echo "pmc inference $c rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/inf_$c -o pmc -- python $ROOT/bench.py --mode inference --no-graph --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --preheat-seconds 0 --ceiling-seconds 0 > $OUT/inf_$c.log 2>&1; echo "pmc inference $c rc=$?"
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/train_$c -o pmc -- python $ROOT/bench.py --mode train --steps 3 --warmup 1 --no-graph --no-cpu-baseline --preheat-seconds 0 > $OUT/train_$c.log 2>&1; echo "pmc train $c rc=$?"
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/f32_$c -o pmc -- python $ROOT/bench.py --mode inference --precision fp32 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --preheat-seconds 0 > $OUT/f32_$c.log 2>&1; echo "pmc fp32 $c rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/f32_$c -o pmc -- python $ROOT/bench.py --mode inference --no-graph --precision fp32 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --preheat-seconds 0 > $OUT/f32_$c.log 2>&1; echo "pmc fp32 $c rc=$?"
 done
 python - $OUT $ROUND <<'PY' | tee $ROOT/gpurun_out/pmc_traffic_summary.txt
 import csv, glob, json, sys, collections

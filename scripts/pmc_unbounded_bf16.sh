@@ -8,7 +8,7 @@ cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o pmc -- python $ROOT/scripts/micro/prof_unbounded.py bf16 2 > $OUT/$c.log 2>&1; echo "pmc $c rc=$?"
 done
-python - $OUT <<'PY' | tee $ROOT/gpurun_out/r04y_unbounded_bf16_traffic.txt
+python - $OUT <<'PY' | tee $ROOT/gpurun_out/${TAG:-r05}_unbounded_bf16_traffic.txt
 import csv, glob, sys, collections
 out = sys.argv[1]
 def means(counter):

@@ -286,3 +286,30 @@ TRAINED360_BOUNDS = {
     "fp32": dict(l0_rgb=5e-5, l0_acc=5e-5, l1_rgb=2e-4, l1_acc=2e-4, l1_distance=2e-4, psnr_l1_rgb=90.0),
     "bf16": dict(l0_rgb=1e-2, l0_acc=1e-2, l1_rgb=2e-2, l1_acc=2e-2, l1_rgb_empty=5e-3, l1_acc_empty=5e-3, psnr_l1_rgb=55.0),
 }
+
+
+def test_mlp_forward_on_two_streams_shares_the_scratch_safely(G):
+    """mipnerf_mlp_forward of the two-kernel form keeps ONE context-owned scratch buffer (pre_x | pre_acc) between its two
+    kernels.  Calls on different streams used to share it without any ordering; now a call on another stream than the previous one
+    waits for that call's kernels (event recorded behind them).  Alternate two streams with different inputs, no host synchronisation
+    in between: every result must equal the single-stream result of its input."""
+    params = syn.make_params(seed=33, density_gain=8.0, xyz_dim=672)
+    model = _model(params, 64, "bf16")
+    rng = np.random.default_rng(11)
+    encs = [torch.from_numpy(rng.uniform(-1, 1, (300, 64, 672)).astype(np.float32)).to(DEV) for _ in range(4)]
+    v = torch.from_numpy(rng.uniform(-1, 1, (300, 27)).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        want = [torch.cat(model.mlp(e, v), -1).clone() for e in encs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [None] * len(encs)
+    with torch.no_grad():
+        for rep in range(3):
+            for i, e in enumerate(encs):
+                s = streams[i % 2]
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    got[i] = torch.cat(model.mlp(e, v), -1)
+            torch.cuda.synchronize()
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), rep
