@@ -98,6 +98,9 @@ class WJob:
     colmap: list            # [b_idx][32] -> col or -1
     biasmap: Optional[list] = None   # [a_idx][32] -> (bt, index) or None
     cost: float = 1.0       # relative HBM bytes per wave tile (for the split heuristic)
+    b_src: int = 0          # 0: B blocks are T-blocks of the saved-activation buffer HT; 1 (pre-GEMM plans): blocks of the ENCODING
+                            # FRAGMENT buffer the off-axis IPE kernel wrote (block b = its k-steps 2b, 2b+1: lane = sample, 8 features per
+                            # lane), read through transposing LDS loads -- no T-block copy of the 672-wide encoding is ever written
 
 
 @dataclass
@@ -112,16 +115,24 @@ class TrainPlan:
     bops: List[BOp] = field(default_factory=list)
     bchunks: list = field(default_factory=list)      # (op, tile, ks); padded with None
     jobs: List[WJob] = field(default_factory=list)
+    pre_gemm: bool = False                           # training form of the two-kernel bf16 MLP (mlp_pre_plan.py), see build()
+    NE: int = 0                                      # pre-GEMM plans: encoding blocks per wave tile in the fragment buffer
 
     @staticmethod
-    def build(arch: Arch = None) -> "TrainPlan":
-        fwd = Plan.build(arch or Arch())
+    def build(arch: Arch = None, pre_gemm: bool = False) -> "TrainPlan":
+        """pre_gemm (round 5): the training kernels of the architecture whose encoding is too wide for k_mlp_bf16's wave-private LDS area
+        (the unbounded-scene model, 672 features).  Forward-with-save = k_pre_gemm (unchanged: layer 0 and the encoding half of the skip
+        layer) + a TRUNK forward-with-save that starts from the preloaded register set X = bf16(relu(layer 0)) -- whose T-blocks and ReLU
+        mask it derives from those registers -- and initialises the skip layer's accumulators from k_pre_gemm's partial sums; the dgrad
+        stream is the standard one (no gradient flows into the encoding: mip_nerf.py:83-90 concatenates a constant); the two weight
+        matrices that multiply the encoding get weight-gradient jobs whose B blocks are the encoding FRAGMENTS (WJob.b_src = 1)."""
+        fwd = Plan.build(arch or Arch(), pre_gemm=pre_gemm)
         a = fwd.arch
         if a.net_depth_condition != 1:
             raise NotImplementedError("training kernels are generated for net_depth_condition == 1")
         if a.xyz_dim % TILE:
             raise NotImplementedError("training kernels need xyz_dim to be a multiple of 32")
-        tp = TrainPlan(fwd)
+        tp = TrainPlan(fwd, pre_gemm=pre_gemm)
         D, W, Wc, E = a.net_depth, a.net_width, a.net_width_condition, a.xyz_dim
         nW, nC, nE = W // TILE, Wc // TILE, E // TILE
         names = [n for n, _ in a.param_shapes()]
@@ -133,7 +144,10 @@ class TrainPlan:
             nonlocal hid
             tp.h_blocks[name] = (hid, n, kind)
             hid += n
-        hadd("enc", nE, NATURAL)
+        if pre_gemm:
+            tp.NE = nE              # the encoding stays in the fragment buffer (its own block index space 0 .. nE-1)
+        else:
+            hadd("enc", nE, NATURAL)
         for i in range(1, D + 1):
             hadd(f"x{i}", nW, DLAYOUT)
         views = bool(a.use_viewdirs)       # False: MLP.forward(x, None) -- colour head on the trunk output, no bottleneck / view layer
@@ -223,17 +237,32 @@ class TrainPlan:
                 out.append(row)
             return out
 
+        def enc_jobs(name, gname, wname, bname, ld, col0):
+            """pre-GEMM plans: delta (8 blocks) x the encoding's nE fragment blocks, <= 8 per job; natural feature order (column n of block
+            b <-> feature 32 b + n); the bias gradient rides on the first job"""
+            for c0 in range(0, nE, MAX_JOB_BLOCKS):
+                bl = list(range(c0, min(c0 + MAX_JOB_BLOCKS, nE)))
+                colmap = [[col0 + TILE * b + n for n in range(32)] for b in bl]
+                tp.jobs.append(WJob(f"{name}.{c0 // MAX_JOB_BLOCKS}", blocks(tp.g_blocks, gname), bl, rows_d(pid[wname], ld, nW), colmap,
+                                    bias_d(pid[bname], nW) if (bname is not None and c0 == 0) else None, cost=(nW + len(bl)) / 16, b_src=1))
+
         for i in range(D):
             wname, bname = f"layers.{i}.0.weight", f"layers.{i}.0.bias"
             ld = shapes[wname][1]
             src = "enc" if i == 0 else f"x{i}"
             ncols = E if i == 0 else W
+            if pre_gemm and i == 0:
+                enc_jobs("L0", "g1", wname, bname, ld, 0)
+                continue
             tp.jobs.append(WJob(f"L{i}", blocks(tp.g_blocks, f"g{i + 1}"), blocks(H, src),
                                 rows_d(pid[wname], ld, nW), cols(src, 0, ncols), bias_d(pid[bname], nW),
                                 cost=(nW + len(blocks(H, src))) / 16))
             if ld > ncols:      # skip layer: the appended encoding columns
-                tp.jobs.append(WJob(f"L{i}e", blocks(tp.g_blocks, f"g{i + 1}"), blocks(H, "enc"),
-                                    rows_d(pid[wname], ld, nW), cols("enc", W, E), None, cost=(nW + nE) / 16))
+                if pre_gemm:
+                    enc_jobs(f"L{i}e", f"g{i + 1}", wname, None, ld, W)
+                else:
+                    tp.jobs.append(WJob(f"L{i}e", blocks(tp.g_blocks, f"g{i + 1}"), blocks(H, "enc"),
+                                        rows_d(pid[wname], ld, nW), cols("enc", W, E), None, cost=(nW + nE) / 16))
         _, nparams = fwd.param_offsets()
         raw_bias = [[(pid["color_layer.bias"], m) if m < nrgb else
                      ((pid["density_layer.bias"], 0) if m == nrgb else None) for m in range(32)]]
@@ -321,11 +350,11 @@ class TrainPlan:
         return tab
 
     def job_table(self) -> np.ndarray:
-        """int32 [njobs, 20]: nA, nB, with_bias, pad, a_blocks[8], b_blocks[8] (unused entries repeat the last)."""
+        """int32 [njobs, 20]: nA, nB, with_bias, b_src, a_blocks[8], b_blocks[8] (unused entries repeat the last)."""
         out = np.zeros((len(self.jobs), 20), dtype=np.int32)
         for ji, job in enumerate(self.jobs):
             nA, nB = len(job.a_blocks), len(job.b_blocks)
-            out[ji, 0:4] = (nA, nB, int(job.biasmap is not None), 0)
+            out[ji, 0:4] = (nA, nB, int(job.biasmap is not None), job.b_src)
             for w in range(8):
                 out[ji, 4 + w] = job.a_blocks[min(w, nA - 1)]
                 out[ji, 12 + w] = job.b_blocks[min(w, nB - 1)]
@@ -349,7 +378,7 @@ class TrainPlan:
         hdr[2] = len(self.jobs)
         hdr[3] = self.NH
         hdr[4] = self.NG
-        hdr[5] = self.NMASK
+        hdr[5] = self.NMASK | (self.NE << 16)      # NE: encoding fragment blocks per wave tile (pre-GEMM plans), else 0
         hdr[6] = JOB_FLOATS
         hdr[7] = self.fwd.param_offsets()[1]
         hdr[8] = bp.size
@@ -438,12 +467,31 @@ def emulate_train_tile(tp: TrainPlan, flat_params, enc, view, d_raw, valid, roun
             for j in range(8):
                 out[ks, :, j] = src[_LN, ks * 16 + _LH * 8 + j]
         return rnd(out)
-    regs = {"enc": natural(enc, plan.arch.xyz_dim // 16), "view": natural(view, 2)}
     HT = np.zeros((tp.NH, 2, 64, 8), np.float32)
     masks = np.zeros((tp.NMASK, 64, 4), np.uint32)
-    e0 = tp.h_blocks["enc"][0]
-    for b in range(plan.arch.xyz_dim // 32):
-        HT[e0 + b] = tblock(regs["enc"][2 * b], regs["enc"][2 * b + 1])
+    ET, pre_acc = None, None
+    if tp.pre_gemm:
+        # k_pre_gemm (unchanged) hands over X and the skip layer's accumulator images; the trunk kernel derives x1's T-blocks and the ReLU
+        # mask of layer 0 from X (x1 = bf16(relu(.)) > 0 <=> the pre-activation was positive, up to values that round to zero in bf16);
+        # the weight-gradient kernel reads the encoding as the B operand  [(hi, n), j] = enc[sample frag_sample(f, hi, j), feature 32 b + n]
+        from .mlp_pre_plan import PrePlan, emulate_pre_gemm
+        x, pre_acc = emulate_pre_gemm(PrePlan.build(plan.arch, split=False), flat_params, enc, round_bf16)
+        regs = {"X": x, "view": natural(view, 2)}
+        x1 = tp.h_blocks["x1"][0]
+        for t in range(plan.arch.net_width // TILE):
+            HT[x1 + t] = tblock(x[2 * t], x[2 * t + 1])
+            masks[0, :, t >> 1] |= pack_mask(x[2 * t], x[2 * t + 1]) << np.uint32(8 * (t & 1))
+        er = rnd(enc)
+        ET = np.zeros((tp.NE, 2, 64, 8), np.float32)
+        for b in range(tp.NE):
+            for f in range(2):
+                for j in range(8):
+                    ET[b, f, :, j] = er[Plan.drow(_LH, 8 * f + j), 32 * b + _LN]
+    else:
+        regs = {"enc": natural(enc, plan.arch.xyz_dim // 16), "view": natural(view, 2)}
+        e0 = tp.h_blocks["enc"][0]
+        for b in range(plan.arch.xyz_dim // 32):
+            HT[e0 + b] = tblock(regs["enc"][2 * b], regs["enc"][2 * b + 1])
     if "view" in tp.h_blocks:
         HT[tp.h_blocks["view"][0]] = tblock(regs["view"][0], regs["view"][1])
     ci = 0
@@ -452,7 +500,7 @@ def emulate_train_tile(tp: TrainPlan, flat_params, enc, view, d_raw, valid, roun
         nt = len(op.tiles)
         acc = np.zeros((nt, 64, 16), np.float32)
         for ti in range(nt):
-            acc[ti] = bias[op.first_tile + ti][_LH]
+            acc[ti] = pre_acc[ti] if op.pre else bias[op.first_tile + ti][_LH]
         for (t0, t1) in plan.panels(op):
             for ks in range(op.nk):
                 seg, ksl = plan.seg_of(op, ks)
@@ -515,11 +563,14 @@ def emulate_train_tile(tp: TrainPlan, flat_params, enc, view, d_raw, valid, roun
             for t in range(op.ntiles):
                 GT[op.gblock + t] = tblock(newreg[2 * t], newreg[2 * t + 1])
     assert ci == tp.n_bchunks_real
+    if tp.pre_gemm:
+        return HT, GT, raw, ET
     return HT, GT, raw
 
 
-def emulate_wgrad(tp: TrainPlan, HT_all, GT_all):
-    """HT_all [ntiles, NH, 2, 64, 8], GT_all [ntiles, NG, 2, 64, 8] -> flat gradient (all parameters)."""
+def emulate_wgrad(tp: TrainPlan, HT_all, GT_all, ET_all=None):
+    """HT_all [ntiles, NH, 2, 64, 8], GT_all [ntiles, NG, 2, 64, 8] (pre-GEMM plans: ET_all [ntiles, NE, 2, 64, 8], the encoding blocks as
+    the weight-gradient MFMA receives them) -> flat gradient (all parameters)."""
     _, nparams = tp.fwd.param_offsets()
     total = nparams + tp.n_scratch
     flat = np.zeros(total, np.float64)
@@ -533,7 +584,7 @@ def emulate_wgrad(tp: TrainPlan, HT_all, GT_all):
                 for f in range(2):
                     A = GT_all[wt, ab, f]
                     for bi, bb in enumerate(job.b_blocks):
-                        part[ai, bi] += _to_acc(_mfma(A, HT_all[wt, bb, f]))
+                        part[ai, bi] += _to_acc(_mfma(A, (ET_all if job.b_src else HT_all)[wt, bb, f]))
                     if job.biasmap is not None:
                         part[ai, BIAS_SLOT] += _to_acc(_mfma(A, ones))
         idx = otab[ji].ravel()
@@ -570,13 +621,15 @@ def emulate_train(tp: TrainPlan, flat_params, enc, view, d_raw, round_bf16=False
     """enc [S, xyz], view [S, 32], d_raw [S, 4] (S arbitrary; padded to wave tiles like the kernels do)."""
     S = enc.shape[0]
     nt = (S + 31) // 32
-    HTs, GTs, raws = [], [], []
+    HTs, GTs, raws, ETs = [], [], [], []
     for t in range(nt):
         idx = np.minimum(np.arange(t * 32, t * 32 + 32), S - 1)
         valid = np.arange(t * 32, t * 32 + 32) < S
-        HT, GT, raw = emulate_train_tile(tp, flat_params, enc[idx], view[idx], d_raw[idx], valid, round_bf16)
-        HTs.append(HT)
-        GTs.append(GT)
-        raws.append(raw)
-    flat, seen = emulate_wgrad(tp, np.stack(HTs), np.stack(GTs))
+        res = emulate_train_tile(tp, flat_params, enc[idx], view[idx], d_raw[idx], valid, round_bf16)
+        HTs.append(res[0])
+        GTs.append(res[1])
+        raws.append(res[2])
+        if tp.pre_gemm:
+            ETs.append(res[3])
+    flat, seen = emulate_wgrad(tp, np.stack(HTs), np.stack(GTs), np.stack(ETs) if ETs else None)
     return post_process(tp, flat_params, flat), seen, np.concatenate(raws)[:S]
