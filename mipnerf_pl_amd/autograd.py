@@ -98,7 +98,7 @@ class _MLPNative(torch.autograd.Function):
         B, N = enc.shape[0], enc.shape[1]
         M = B * N
         if enc.dtype != torch.bfloat16 or venc.dtype != torch.bfloat16 or venc.shape[-1] != 32:
-            raise TypeError("native MLP training path: enc [B,N,96] and viewenc [B,32] must be bfloat16")
+            raise TypeError("native MLP training path: enc [B,N,xyz_dim] and viewenc [B,32] must be bfloat16")
         enc = enc.contiguous()
         venc = venc.contiguous()
         sz = nctx.train_sizes(M)
@@ -110,6 +110,9 @@ class _MLPNative(torch.autograd.Function):
                                                   raw.data_ptr(), act.data_ptr(), masks.data_ptr(), ops._stream()),
                 "mlp_forward_train")
         ctx.save_for_backward(act, masks)
+        # wide encodings (the unbounded-scene model's two-kernel form): the weight-gradient kernel reads the ROW-MAJOR ENCODING itself -- the act
+        # buffer records its address -- so it must outlive the forward; the standard shapes transposed their 96 features into `act`
+        ctx.enc_keepalive = enc if enc.shape[-1] > 96 else None
         ctx.nctx, ctx.M, ctx.sizes, ctx.mlp = nctx, M, sz, mlp
         ctx.shapes = [p.shape for p in params]
         return raw

@@ -194,7 +194,7 @@ std::vector<int32_t> encode(const std::vector<int32_t>& flat, const std::vector<
 
 // ---- training tables: binary blob produced by mlp_train_plan.TrainPlan.blob(), linked in by train_tables.c ------
 struct TrainTables {
-    int n_bchunks, njobs, NH, NG, NMASK, job_floats, nparams, n_scratch;
+    int n_bchunks, njobs, NH, NG, NMASK, NE, job_floats, nparams, n_scratch;     // NE: encoding blocks per wave tile (pre-GEMM plans), else 0
     int off_extra_w, off_extra_b, off_view_w, off_view_b;
     const int32_t* bpack;    // [n_bchunks * 512] flat parameter index or -1
     const int32_t* jobs;     // [njobs * 20]
@@ -205,7 +205,7 @@ bool train_tables(TrainTables& T, int variant = 0) {
     if (variant < 0 || variant >= mip::plan::kNumVariants || !mip::kTrainTableBlobs[variant]) return false;
     const int32_t* h = reinterpret_cast<const int32_t*>(mip::kTrainTableBlobs[variant]);
     if (h[0] != 0x54524E31) return false;
-    T.n_bchunks = h[1]; T.njobs = h[2]; T.NH = h[3]; T.NG = h[4]; T.NMASK = h[5]; T.job_floats = h[6]; T.nparams = h[7];
+    T.n_bchunks = h[1]; T.njobs = h[2]; T.NH = h[3]; T.NG = h[4]; T.NMASK = h[5] & 0xffff; T.NE = h[5] >> 16; T.job_floats = h[6]; T.nparams = h[7];
     T.n_scratch = h[11]; T.off_extra_w = h[12]; T.off_extra_b = h[13]; T.off_view_w = h[14]; T.off_view_b = h[15];
     T.bpack = h + 16;
     T.jobs = T.bpack + h[8];
@@ -319,6 +319,10 @@ hipError_t launch_bf16_variant(mipnerf_ctx* c, const void* enc, const void* view
 
 // ... and its training kernels (variants whose row of the generated kLaunchTrainFwd table is not null)
 static inline bool has_bf16_train(const PlanDesc* P) { return mip::kLaunchTrainFwd[P->variant] != nullptr; }
+// round 5: the training form of the two-kernel bf16 MLP (wide encodings: the unbounded-scene model) -- k_pre_gemm + a trunk forward-with-save,
+// the standard dgrad, weight-gradient jobs that read the row-major encoding (mlp_train_plan.TrainPlan.build(arch, pre_gemm=True))
+static inline bool has_bf16_train_pre(const PlanDesc* P) { return mip::kLaunchTrainFwdPre[P->variant] != nullptr; }
+static inline bool has_bf16_train_any(const PlanDesc* P) { return has_bf16_train(P) || has_bf16_train_pre(P); }
 static inline bool has_bf16_pre(const PlanDesc* P) { return mip::kLaunchPreGemm[P->variant] != nullptr; }      // the two-kernel form
 static inline bool has_bf16(const PlanDesc* P) { return mip::kLaunchBf16[P->variant] != nullptr || has_bf16_pre(P); }
 // bytes of k_pre_gemm's two outputs for M samples: 16 KiB (X fragments) + 32 KiB (accumulator images) per wave tile, whole 256-sample tiles
@@ -361,7 +365,7 @@ mip::F32Net f32net_with_heads(const mipnerf_ctx* c) {
 }
 
 #define NEED_BF16_TRAIN(what)                                                                                               \
-    if (!has_bf16_train(c->P))                                                                                               \
+    if (!has_bf16_train_any(c->P))                                                                                           \
         return fail(MIPNERF_E_UNSUPPORTED, what ": no bf16 training kernels were generated for this architecture variant " \
                                                 "(gen_mlp_train.train_variants); train this shape in fp32 precision")
 
@@ -404,7 +408,7 @@ int mipnerf_num_variants(void) { return mip::plan::kNumVariants; }
 int mipnerf_variant_arch(int variant, mipnerf_config* cfg, int* has_bf16_training) {
     if (!cfg || variant < 0 || variant >= mip::plan::kNumVariants) return fail(MIPNERF_E_INVALID, "variant_arch: bad argument");
     variant_to_cfg(mip::plan::kPlans[variant], cfg);
-    if (has_bf16_training) *has_bf16_training = mip::kLaunchTrainFwd[variant] != nullptr;
+    if (has_bf16_training) *has_bf16_training = has_bf16_train_any(&mip::plan::kPlans[variant]);
     return MIPNERF_OK;
 }
 
@@ -522,11 +526,11 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
         c->grid_limit = cus;
     // ---- training tables (one blob per variant with generated bf16 training kernels) ----
-    if (has_bf16_train(P) && (!train_tables(c->tt, P->variant) || c->tt.nparams != off_total(c->tab))) {
+    if (has_bf16_train_any(P) && (!train_tables(c->tt, P->variant) || c->tt.nparams != off_total(c->tab))) {
         mipnerf_destroy(c);
         return fail(MIPNERF_E_INVALID, "mipnerf_create: embedded training tables are inconsistent with the compiled plan");
     }
-    if (has_bf16_train(P)) {
+    if (has_bf16_train_any(P)) {
         const TrainTables& tt = c->tt;
         const std::vector<int32_t> flat(tt.bpack, tt.bpack + (size_t)tt.n_bchunks * 512);
         const std::vector<int32_t> e_dg = encode(flat, c->tab.tensor_off);
@@ -553,7 +557,7 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
             return fail(MIPNERF_E_HIP, "mipnerf_create (training tables): %s", hipGetErrorString(er));
         }
     }
-    if (has_bf16_train(P)) {
+    if (has_bf16_train_any(P)) {
         const int rc = mipnerf_set_wgrad_splits(c, nullptr);
         if (rc) { mipnerf_destroy(c); return rc; }
     }
@@ -617,7 +621,7 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
     add(c->d_pack_bf16, nst, c->d_stream_bf16, true);
     add(c->d_pack_f32, nst, c->d_stream_f32, false);
     add(c->d_bias_idx, (int64_t)P.num_tiles * 32, c->d_bias, false);
-    if (has_bf16_train(&P)) {
+    if (has_bf16_train_any(&P)) {
         add(c->d_pack_dgrad, (int64_t)c->tt.n_bchunks * 512, c->d_stream_dgrad, true);
         add(c->d_pack_extraT, (int64_t)P.net_width * P.net_width, c->d_extra_wT, false);
     }
@@ -873,7 +877,9 @@ int mipnerf_mlp_train_sizes(const mipnerf_ctx* c, int64_t M, size_t* act_bytes, 
     if (!c || M < 1) return fail(MIPNERF_E_INVALID, "mlp_train_sizes: bad argument");
     NEED_BF16_TRAIN("mlp_train_sizes");
     const size_t n_wt = (size_t)((M + 255) / 256) * 8;          // wave tiles (32 samples) of whole workgroup tiles
-    if (act_bytes) *act_bytes = n_wt * c->tt.NH * 2048;
+    // pre-GEMM form: behind the T-blocks a 256-byte record of the encoding the forward ran on (the weight-gradient kernel reads it: the act
+    // buffer describes itself, mipnerf_mlp_wgrad needs no extra argument) and the two buffers between k_pre_gemm and the trunk kernel
+    if (act_bytes) *act_bytes = n_wt * c->tt.NH * 2048 + (has_bf16_train_pre(c->P) ? 256 + pre_x_bytes(M) + pre_acc_bytes(M) : 0);
     if (mask_bytes) *mask_bytes = n_wt * c->tt.NMASK * 1024;
     if (delta_bytes) *delta_bytes = n_wt * c->tt.NG * 2048;
     if (partial_bytes) *partial_bytes = (size_t)c->num_wgrad_wgs * c->tt.job_floats * 4;
@@ -886,6 +892,19 @@ static int mlp_forward_train_noise(mipnerf_ctx* c, int64_t M, int32_t N, const v
         return fail(MIPNERF_E_INVALID, "mlp_forward_train: bad argument");
     NEED_BF16_TRAIN("mlp_forward_train");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_forward_train: mipnerf_set_params has not been called");
+    if (has_bf16_train_pre(c->P)) {
+        // enc: bf16 row-major [M, xyz_dim] (what mipnerf_cast_ipe_360 writes); it must stay valid until the backward of this act buffer
+        const size_t n_wt = (size_t)((M + 255) / 256) * 8;
+        char* rec = (char*)act + n_wt * c->tt.NH * 2048;
+        char* pre_x = rec + 256;
+        char* pre_acc = pre_x + pre_x_bytes(M);
+        HIP_TRY(mip::kLaunchPreGemm[c->P->variant](c->d_pre_gemm_stream, c->d_pre_gemm_bias, enc, 0, pre_x, pre_acc, M, c->grid_limit, S(stream)));
+        HIP_TRY(mip::kLaunchTrainFwdPre[c->P->variant](c->d_pre_trunk_stream, c->d_pre_trunk_bias, pre_x, pre_acc, viewenc, rgb_sigma, raw, act, masks,
+                                                        M, N, c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, dnoise,
+                                                        c->cfg.density_noise, S(stream)));
+        HIP_TRY(mip::launch_wgrad_record_enc(rec, enc, M, c->P->xyz_dim * 2, S(stream)));
+        return MIPNERF_OK;
+    }
     HIP_TRY(launch_trainfwd_variant(c, enc, viewenc, rgb_sigma, raw, act, masks, M, N, nullptr, dnoise, S(stream)));
     return MIPNERF_OK;
 }
@@ -923,8 +942,9 @@ static int wgrad_tiles(mipnerf_ctx* c, int64_t n_wt, const void* act, const void
         e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1]; c->ev_used += 2;
         HIP_TRY(hipEventRecord(e0, S(stream)));
     }
+    const mip::WgradEnc* rec = has_bf16_train_pre(c->P) ? (const mip::WgradEnc*)((const char*)act + (size_t)n_wt * c->tt.NH * 2048) : nullptr;
     HIP_TRY(mip::launch_mlp_wgrad(act, delta, c->d_jobs, c->d_wgtab, c->num_wgrad_wgs, n_wt, c->tt.NH, c->tt.NG, partials,
-                                  S(stream)));
+                                  S(stream), rec));
     if (e1) HIP_TRY(hipEventRecord(e1, S(stream)));
     if (grad_flat) {
         if (!c->params_set) return fail(MIPNERF_E_INVALID, "mlp_wgrad: mipnerf_set_params has not been called");
@@ -1219,7 +1239,9 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
                        int32_t accumulate, float* out_scalars, const mipnerf_level_out* out, void* stream) {
     if (!c || !rays || !gt_rgb || !workspace || !grad_flat || !out_scalars || B < 1)
         return fail(MIPNERF_E_INVALID, "train_step: bad argument");
-    NEED_BF16_TRAIN("train_step");
+    if (!has_bf16_train(c->P))
+        return fail(MIPNERF_E_UNSUPPORTED, "train_step: the one-call step exists for the bounded model's generated shapes; this variant trains "
+                                           "through the per-stage entry points (mipnerf_mlp_forward_train / mipnerf_mlp_backward) or in fp32");
     if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->radii || !rays->near || !rays->far || !rays->lossmult)
         return fail(MIPNERF_E_INVALID, "train_step: a Rays field is null");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "train_step: mipnerf_set_params has not been called");

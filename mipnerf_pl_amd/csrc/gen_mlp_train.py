@@ -235,13 +235,13 @@ def emit_tile_body(e, prog, side, nchunks_total, prologue_lines, final_lines, ld
         e(f"        {ln}")
 
 
-def check_hazards(prog, side, prologue=()):
+def check_hazards(prog, side, prologue=(), preloaded=False):
     """Register-set discipline: op i reads the activation registers written by the previous op that writes any.
     Epilogue statements carry an `/*opN*/` tag; replay the tile in program order and assert that every B operand X[k] / Y[k]
     read by a slot of op i was last written by that op, and every register read by a transposing MFMA / tile_mask was
     written by the op that issues the statement."""
     import re
-    last = {}
+    last = {f"X[{k}]": -1 for k in range(16)} if preloaded else {}     # trunk plans (pre-GEMM form): X arrives preloaded ("op -1")
     wr = re.compile(r"epilogue_half<[^>]*>\(\w+, (?:[\w\[\]]+, )?([XY]\[\d+\])\);\s*/\*op(\d+)\*/")
     rd = re.compile(r"(?:TMFMA0|MFMA)\(\w+, ([XY]\[\d+\]), P[12]\);\s*/\*op(\d+)\*/")
     opidx = {}
@@ -291,7 +291,7 @@ def build_fwd_prog(tp: TrainPlan):
                 elif seg.regset == "enc":
                     b = ("lds", ksl * 1024)
                 else:
-                    b = ("lds", (a.xyz_dim // 16) * 1024 + ksl * 1024)
+                    b = ("lds", (0 if plan.pre_gemm else a.xyz_dim // 16) * 1024 + ksl * 1024)
                 for w in range(spk):
                     prog.slots.append(dict(acc=f"acc{pair}{w}", b=b, panel=len(prog.panels), ks=ks,
                                            first_of_ks=(w == 0), zero=False, opname=op.name))
@@ -324,9 +324,14 @@ def build_fwd_prog(tp: TrainPlan):
                             post_late.append(f"*reinterpret_cast<u32x4*>(mask_wave + {ml * 1024} + lane16) = u32x4{{{vals}}};")
                 else:
                     post.append(f"raw_r = {acc}[0]; raw_g = {acc}[1]; raw_b = {acc}[2];")
-            pre = [f"BIAS(acc{pair}0, {op.first_tile + t0});"]
-            if t1 is not None:
-                pre.append(f"BIAS(acc{pair}1, {op.first_tile + t1});")
+            if op.pre:      # skip layer of a trunk plan: the accumulators start from k_pre_gemm's partial sums (bias included), 4 KiB per tile
+                pre = [f"pre_load(acc{pair}0, pre_lane + {t0 * 4096});"]
+                if t1 is not None:
+                    pre.append(f"pre_load(acc{pair}1, pre_lane + {t1 * 4096});")
+            else:
+                pre = [f"BIAS(acc{pair}0, {op.first_tile + t0});"]
+                if t1 is not None:
+                    pre.append(f"BIAS(acc{pair}1, {op.first_tile + t1});")
             prog.panels.append(dict(first=first, n=len(prog.slots) - first, pair=pair, spk=spk,
                                     post=post + post_t + post_late, pre=pre))
     return prog
@@ -383,6 +388,8 @@ SELECTORS = [
 
 
 def gen_trainfwd(tp: TrainPlan, variant: int = 0) -> str:
+    if tp.pre_gemm:
+        return gen_trainfwd_pre(tp, variant)
     sfx = f"_v{variant}" if variant else ""
     plan = tp.fwd
     a = plan.arch
@@ -521,6 +528,148 @@ def gen_trainfwd(tp: TrainPlan, variant: int = 0) -> str:
     e("}")
     e("}  // namespace mip")
     return "\n".join(lines) + "\n"
+
+
+def gen_trainfwd_pre(tp: TrainPlan, variant: int) -> str:
+    """TRUNK forward-with-save of the two-kernel bf16 form (TrainPlan.build(arch, pre_gemm=True); round 5): k_pre_gemm (gen_pre_gemm.py,
+    unchanged) has computed layer 0 and the encoding half of the skip layer; this kernel starts from the preloaded register set
+    X = bf16(relu(layer 0)) -- whose eight T-blocks and ReLU mask row it writes first (x1 > 0 <=> the pre-activation was positive) --,
+    runs layers 1 .. D-1, head, view layer and colour like k_mlp_bf16_trainfwd (same panels, same epilogues, same T-block / mask
+    stores), and initialises the skip layer's accumulators from k_pre_gemm's fp32 partial sums.  The encoding's own T-blocks do not
+    exist: the weight-gradient kernel reads the encoding fragments (WJob.b_src = 1)."""
+    sfx = f"_pre_v{variant}"
+    plan = tp.fwd
+    a = plan.arch
+    assert plan.pre_gemm and a.net_width == 256
+    nchunks = len(plan.chunks)
+    nreal = plan.n_real_chunks
+    assert nchunks % GROUP == 0 and (nchunks // GROUP) % SLOTS == 0
+    enc_wave_bytes = 8192            # only the two view-encoding k-steps live there
+    nbias_bytes = plan.n_tiles * 128
+    ring_bytes = SLOTS * GROUP * CHUNK_BYTES
+    enc_off = (ring_bytes + nbias_bytes + 1023) // 1024 * 1024
+    lds_bytes = enc_off + WAVES * enc_wave_bytes
+    assert lds_bytes <= 160 * 1024
+    prog = build_fwd_prog(tp)
+    assert len(prog.slots) == nreal and (nchunks - nreal < GROUP or (nchunks - nreal == GROUP and nreal % GROUP == 0))
+    side_e, prologue_e = assign_lds_b(prog, nreal)
+    side = place_sides(prog, nreal, "fwd")
+    for c in range(nreal):
+        side[c] = side_e[c] + side[c]
+    check_hazards(prog, side, preloaded=True)
+    lines = []
+    e = lines.append
+    file_header(e, "trainfwd" + sfx, dict(kRingBytes=ring_bytes, kBiasBytes=nbias_bytes, kEncOff=enc_off,
+                                    kEncWaveBytes=enc_wave_bytes, kLdsBytes=lds_bytes,
+                                    kGroupBytes=GROUP * CHUNK_BYTES, kNumGroups=nchunks // GROUP,
+                                    kTileSamples=WAVES * 32, kNH=tp.NH, kNMask=tp.NMASK))
+    e(f"__global__ void __launch_bounds__({WAVES * 64})")
+    e("k_mlp_bf16_trainfwd_pre(const char* __restrict__ stream, const float* __restrict__ bias_tab, const char* __restrict__ pre_x,")
+    e("                        const char* __restrict__ pre_acc, const __bf16* __restrict__ viewenc, float4* __restrict__ rgb_sigma,")
+    e("                        float4* __restrict__ raw_out, char* __restrict__ HT, char* __restrict__ masks, int64_t M,")
+    e("                        int num_samples, int ntiles, float density_bias, float rgb_padding,")
+    e("                        const float* __restrict__ dnoise, float dnoise_scale) {")
+    e("    extern __shared__ __attribute__((aligned(16))) char smem[];")
+    e("    const int tid = threadIdx.x;")
+    e("    const int lane = tid & 63;")
+    e("    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);")
+    e("    const int hi = lane >> 5, n = lane & 31;")
+    e("    const unsigned lane16 = (unsigned)lane * 16u;")
+    e("    const char* ring_lane = smem + lane16;")
+    e("    const char* bias_lane = smem + kRingBytes + hi * 64;")
+    e("    char* encw = smem + kEncOff + wave * kEncWaveBytes;")
+    e("    const char* enc_lane = encw + lane16;")
+    for ln in SELECTORS:
+        e("    " + ln)
+    e("    for (int i = tid; i < kBiasBytes / 16; i += blockDim.x)")
+    e("        reinterpret_cast<float4*>(smem + kRingBytes)[i] = reinterpret_cast<const float4*>(bias_tab)[i];")
+    e("    __syncthreads();")
+    if SETPRIO:
+        e("    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // as the inference kernel (gen_mlp_bf16.SETPRIO)")
+    e("    if ((int)blockIdx.x < ntiles) issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
+    e("    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {")
+    e("        const bool has_next = tile + (int)gridDim.x < ntiles;")
+    e("        const int64_t wt = (int64_t)tile * 8 + wave;                 // wave tile (uniform)")
+    e("        const int64_t s = wt * 32 + n;")
+    e("        const int64_t sc = s < M ? s : M - 1;")
+    e("        const int64_t ray = sc / num_samples;")
+    e("        char* ht_wave = HT + wt * (int64_t)(kNH * 2048);")
+    e("        char* mask_wave = masks + wt * (int64_t)(kNMask * 1024);")
+    e("        issue_encodings<DMA, 0, 0>(nullptr, viewenc + ray * 32 + hi * 8, encw, lane16);")
+    e("        bf16x8 X[16], Y[16], " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ", E0, E1, E2;")
+    e("        // what k_pre_gemm left for this wave tile: X = bf16(relu(layer 0)) as 16 lane-linear fragments, the skip layer's accumulator images")
+    e("        const char* prex_lane = pre_x + wt * 16384 + lane16;")
+    e("        const char* pre_lane = pre_acc + wt * 32768 + lane16;")
+    for k in range(16):
+        e(f"        X[{k}] = PRE_LD(reinterpret_cast<const bf16x8*>(prex_lane + {k * 1024}));")
+    e("        f32x16 acc00, acc01, acc10, acc11;")
+    e("        unsigned mq0 = 0, mq1 = 0, mq2 = 0, mq3 = 0;")
+    e("        float raw_density = 0.0f, raw_r = 0.0f, raw_g = 0.0f, raw_b = 0.0f;")
+
+    def lda(c):
+        slot = (c // GROUP) % SLOTS
+        off = slot * GROUP * CHUNK_BYTES + (c % GROUP) * CHUNK_BYTES
+        return f"A{c % PREFETCH} = LDA({off});"
+    # tile prologue: T-blocks and ReLU mask of x1 (from the preloaded registers), T-block of the view features
+    pro = []
+    accs = ["acc10", "acc11"]
+    x1 = tp.h_blocks["x1"][0]
+    nW = a.net_width // 32
+    for t in range(nW):
+        acc = accs[t % 2]
+        pro.append(f"TMFMA0({acc}, X[{2 * t}], P1); MFMA({acc}, X[{2 * t + 1}], P2);")
+        pro.append(f"store_tfrag<0>({acc}, ht_wave + {(x1 + t) * 2048}, lane16); store_tfrag<8>({acc}, ht_wave + {(x1 + t) * 2048}, lane16);")
+        if t % 2 == 0:
+            pro.append(f"mq{t // 2} = tile_mask(X[{2 * t}], X[{2 * t + 1}]);")
+        else:
+            pro.append(f"mq{t // 2} |= tile_mask(X[{2 * t}], X[{2 * t + 1}]) << 8;")
+    vals = ", ".join(f"mq{q}" if q < (nW + 1) // 2 else "0u" for q in range(4))
+    pro.append(f"*reinterpret_cast<u32x4*>(mask_wave + 0 + lane16) = u32x4{{{vals}}};      // mask row 0 = layer 0")
+    acc = accs[nW % 2]
+    vb = tp.h_blocks["view"][0]
+    pro.append("E0 = LDB(0); E1 = LDB(1024);")
+    pro.append(f"TMFMA0({acc}, E0, P1); MFMA({acc}, E1, P2);")
+    pro.append(f"store_tfrag<0>({acc}, ht_wave + {vb * 2048}, lane16); store_tfrag<8>({acc}, ht_wave + {vb * 2048}, lane16);")
+    pro += prologue_e
+    pro += prog.panels[0]["pre"]
+    final = list(prog.panels[-1]["post"])
+    final += [
+        "if (hi == 0 && s < M) {",
+        "    const float noisy_density = dnoise ? raw_density + dnoise_scale * dnoise[s] : raw_density;   // mip_nerf.py:232-233",
+        "    rgb_sigma[s] = make_float4(rgb_activation(raw_r, rgb_padding), rgb_activation(raw_g, rgb_padding),",
+        "                               rgb_activation(raw_b, rgb_padding), density_activation(noisy_density, density_bias));",
+        "    raw_out[s] = make_float4(raw_r, raw_g, raw_b, raw_density);",
+        "}",
+    ]
+    emit_tile_body(e, prog, side, nchunks, pro, final, lda)
+    e("    }")
+    e("}")
+    e("}  // namespace trainfwd" + sfx)
+    e("")
+    e(f"hipError_t launch_mlp_bf16_trainfwd{sfx}(const void* stream_w, const float* bias_tab, const void* pre_x, const void* pre_acc, const void* viewenc,")
+    e("                                    float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,")
+    e("                                    float density_bias, float rgb_padding, int grid_limit, const float* dnoise, float dnoise_scale,")
+    e("                                    hipStream_t st) {")
+    e(f"    using namespace trainfwd{sfx};")
+    e("    const int ntiles = (int)((M + kTileSamples - 1) / kTileSamples);")
+    e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
+    e("    if (grid < 1) grid = 1;")
+    e("    static int attr_done[64] = {};")
+    e("    int dev = 0;")
+    e("    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;")
+    e("    if (!attr_done[dev]) {")
+    e("        hipError_t er = hipFuncSetAttribute((const void*)k_mlp_bf16_trainfwd_pre, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
+    e("        if (er != hipSuccess) return er;")
+    e("        attr_done[dev] = 1;")
+    e("    }")
+    e(f"    hipLaunchKernelGGL(k_mlp_bf16_trainfwd_pre, dim3(grid), dim3({WAVES * 64}), kLdsBytes, st, (const char*)stream_w, bias_tab,")
+    e("                       (const char*)pre_x, (const char*)pre_acc, (const __bf16*)viewenc, (float4*)rgb_sigma, (float4*)raw_out, (char*)HT,")
+    e("                       (char*)masks, M, num_samples, ntiles, density_bias, rgb_padding, dnoise, dnoise_scale);")
+    e("    return hipGetLastError();")
+    e("}")
+    e("}  // namespace mip")
+    return "\n".join(lines) + "\n"
+
 
 
 # =================================================================================================================
@@ -679,9 +828,16 @@ def train_variants():
     view layer so narrow that the colour head would read activations its epilogue has not written yet) simply has no bf16
     training kernels: it trains in fp32 mode, and the library says so."""
     from gen_mlp_bf16 import VARIANTS
+    from mipnerf_pl_amd import mlp_pre_plan
     out = []
     for vi, arch in enumerate(VARIANTS):
         try:
+            if mlp_pre_plan.supported(arch):
+                # two-kernel bf16 form (wide encoding): k_pre_gemm + a trunk forward-with-save, the standard dgrad, weight-gradient jobs
+                # over the encoding fragments (round 5)
+                tp = TrainPlan.build(arch, pre_gemm=True)
+                out.append((vi, tp, gen_trainfwd(tp, vi), gen_dgrad(tp, vi)))
+                continue
             if not arch.bf16_kernels:
                 raise NotImplementedError("fp32-only architecture variant")
             tp = TrainPlan.build(arch)
@@ -693,8 +849,9 @@ def train_variants():
     return out
 
 
-def gen_train_variants_header(trainable, n):
-    """Declarations + dispatch tables of the per-variant training launchers and table blobs (nullptr: no bf16 training kernels)."""
+def gen_train_variants_header(trainable, n, pre=()):
+    """Declarations + dispatch tables of the per-variant training launchers and table blobs (nullptr: no bf16 training kernels).
+    `pre`: the variants whose forward-with-save is the trunk of the two-kernel form (their row of kLaunchTrainFwd stays null)."""
     L = ["// AUTO-GENERATED by gen_mlp_train.py from gen_mlp_bf16.VARIANTS -- do not edit by hand.", "#pragma once", '#include "kernels.hpp"']
     for vi in trainable:
         sfx = f"_v{vi}" if vi else ""
@@ -704,20 +861,30 @@ def gen_train_variants_header(trainable, n):
           "                                       float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M, int num_samples,",
           "                                       float density_bias, float rgb_padding, int grid_limit, const RayInputs* rays,",
           "                                       const float* dnoise, float dnoise_scale, hipStream_t st);",
+          "typedef hipError_t (*LaunchTrainFwdPreFn)(const void* stream_w, const float* bias_tab, const void* pre_x, const void* pre_acc,",
+          "                                          const void* viewenc, float* rgb_sigma, float* raw_out, void* HT, void* masks, int64_t M,",
+          "                                          int num_samples, float density_bias, float rgb_padding, int grid_limit, const float* dnoise,",
+          "                                          float dnoise_scale, hipStream_t st);",
           "typedef hipError_t (*LaunchDgradFn)(const void* stream_wT, const float* d_raw, const void* masks, void* GT, int64_t M,",
           "                                    int grid_limit, hipStream_t st);"]
     for vi in trainable:
         if vi == 0:
             continue
-        L.append(f"hipError_t launch_mlp_bf16_trainfwd_v{vi}(const void*, const float*, const void*, const void*, float*, float*, void*, void*,")
-        L.append("                                        int64_t, int, float, float, int, const RayInputs*, const float*, float, hipStream_t);")
+        if vi in pre:
+            L.append(f"hipError_t launch_mlp_bf16_trainfwd_pre_v{vi}(const void*, const float*, const void*, const void*, const void*, float*, float*, void*, void*,")
+            L.append("                                            int64_t, int, float, float, int, const float*, float, hipStream_t);")
+        else:
+            L.append(f"hipError_t launch_mlp_bf16_trainfwd_v{vi}(const void*, const float*, const void*, const void*, float*, float*, void*, void*,")
+            L.append("                                        int64_t, int, float, float, int, const RayInputs*, const float*, float, hipStream_t);")
         L.append(f"hipError_t launch_mlp_bf16_dgrad_v{vi}(const void*, const float*, const void*, void*, int64_t, int, hipStream_t);")
 
-    def tab(fmt0, fmtv):
-        return ", ".join((fmt0 if vi == 0 else fmtv.format(vi)) if vi in trainable else "nullptr" for vi in range(n))
-    L.append(f"static const LaunchTrainFwdFn kLaunchTrainFwd[{n}] = {{{tab('launch_mlp_bf16_trainfwd', 'launch_mlp_bf16_trainfwd_v{}')}}};")
-    L.append(f"static const LaunchDgradFn kLaunchDgrad[{n}] = {{{tab('launch_mlp_bf16_dgrad', 'launch_mlp_bf16_dgrad_v{}')}}};")
-    L.append(f"static const unsigned char* const kTrainTableBlobs[{n}] = {{{tab('mip_train_tables', 'mip_train_tables_v{}')}}};")
+    def tab(fmt0, fmtv, which):
+        return ", ".join((fmt0 if vi == 0 else fmtv.format(vi)) if vi in which else "nullptr" for vi in range(n))
+    std = [vi for vi in trainable if vi not in pre]
+    L.append(f"static const LaunchTrainFwdFn kLaunchTrainFwd[{n}] = {{{tab('launch_mlp_bf16_trainfwd', 'launch_mlp_bf16_trainfwd_v{}', std)}}};")
+    L.append(f"static const LaunchTrainFwdPreFn kLaunchTrainFwdPre[{n}] = {{{tab('nullptr', 'launch_mlp_bf16_trainfwd_pre_v{}', list(pre))}}};")
+    L.append(f"static const LaunchDgradFn kLaunchDgrad[{n}] = {{{tab('launch_mlp_bf16_dgrad', 'launch_mlp_bf16_dgrad_v{}', trainable)}}};")
+    L.append(f"static const unsigned char* const kTrainTableBlobs[{n}] = {{{tab('mip_train_tables', 'mip_train_tables_v{}', trainable)}}};")
     L.append("}  // namespace mip")
     return "\n".join(L) + "\n"
 
@@ -727,10 +894,10 @@ def main():
     from gen_mlp_bf16 import VARIANTS
     tvs = train_variants()
     with open(os.path.join(outdir, "mlp_train_variants_gen.hpp"), "w") as f:
-        f.write(gen_train_variants_header([v[0] for v in tvs], len(VARIANTS)))
+        f.write(gen_train_variants_header([v[0] for v in tvs], len(VARIANTS), pre=[v[0] for v in tvs if v[1].pre_gemm]))
     for vi, tp, src_fwd, src_dgrad in tvs:
         sfx = f"_v{vi}" if vi else ""
-        with open(os.path.join(outdir, f"mlp_bf16_trainfwd_gen{sfx}.hip"), "w") as f:
+        with open(os.path.join(outdir, f"mlp_bf16_trainfwd_pre_gen{sfx}.hip" if tp.pre_gemm else f"mlp_bf16_trainfwd_gen{sfx}.hip"), "w") as f:
             f.write(src_fwd)
         with open(os.path.join(outdir, f"mlp_bf16_dgrad_gen{sfx}.hip"), "w") as f:
             f.write(src_dgrad)

@@ -118,14 +118,21 @@ hipError_t launch_resample_bwd(int64_t B, int N, const float* bins, const float*
 // ---- kernels_wgrad.hip -----------------------------------------------------------------------
 constexpr int kWgradJobFloats = 8 * 9 * 64 * 16;     // fp32 partials per (job, split): [wave][slot][lane][reg]
 struct WgradJob {                                     // one row of mlp_train_plan.TrainPlan.job_table()
-    int nA, nB, bias, pad;
+    int nA, nB, bias, b_src;                          // b_src 1: the B blocks are 32-feature column blocks of the row-major ENCODING (pre-GEMM plans)
     int a_blk[8];
     int b_blk[8];
+};
+struct WgradEnc {                                     // the encoding the b_src = 1 jobs contract against (null / 0 when the plan has none)
+    const void* enc;                                  // bf16 [M, row_elems] row-major
+    int64_t M;                                        // rows (samples); wave tiles reach past it, rows are clamped
+    int row_bytes;                                    // 2 * xyz_dim
 };
 int mlp_wgrad_lds_bytes();
 hipError_t launch_transpose_sq(int n, const float* in, float* out, hipStream_t st);
 hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs, const void* wg_tab, int num_wgs,
-                            int64_t n_wt, int NH, int NG, float* partials, hipStream_t st);
+                            int64_t n_wt, int NH, int NG, float* partials, hipStream_t st, const WgradEnc* enc_record = nullptr);
+// writes the WgradEnc record behind an act buffer's T-blocks (device memory: the forward may be part of a captured graph)
+hipError_t launch_wgrad_record_enc(void* record, const void* enc, int64_t M, int row_bytes, hipStream_t st);
 struct WgradPost {                                    // chain-rule step that replaces the bottleneck T-blocks (W == 0: none)
     int W, Wc, ldv;                                   // net_width, net_width_condition, in_features of the view layer
     int off_extra_w, off_extra_b, off_view_w, off_view_b;   // flat gradient offsets

@@ -65,6 +65,25 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* p) {
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 #endif
 
+// ---- b_src = 1 jobs (pre-GEMM plans, round 5): the B operand is a 32-feature column block of the ROW-MAJOR bf16 encoding [M, xyz_dim]
+// (what k_pre_gemm reads in the training forward): no transposed copy of the 672-wide encoding is ever written.
+// DMA: a block = 32 samples x 64 bytes; lane L of the first of its two DMAs moves the 16-byte piece (L & 3) of sample (L >> 2), the second
+// the samples 16 .. 31 -- the LDS image is row-major [32 samples][32 features].  Rows past M are clamped (their deltas are zero).
+// Operand read: fragment f of the weight-gradient MFMA's B operand wants, in lane (hi, n), feature column n of the block for the 8 samples
+// drow(hi, 8 f + j) -- the sample order of the delta T-blocks (mlp_train_plan.frag_sample).  ds_read_b64_tr_b16 transposes 4 x 4 within
+// 16-lane groups: lane i receives element (i & 3) of the 8-byte granules addressed by lanes (i >> 2) + 4 k, k = 0 .. 3 (probed:
+// profiles/r02n_ds_read_tr_probe.txt).  Lane i of group (hi, g = n >> 4) therefore ADDRESSES the granule (feature quad 4 g + (i & 3),
+// sample 16 f + 8 r + 4 hi + (i >> 2)) for read r in {0, 1} and RECEIVES feature 16 g + i of samples 16 f + 8 r + 4 hi + 0 .. 3.
+typedef short v4s16e __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_frag_enc(const char* blk, unsigned enc_lane_off, int f) {
+    const char* p = blk + enc_lane_off + f * (16 * 64);
+    const v4s16e lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16e*)(size_t)(p));
+    const v4s16e hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16e*)(size_t)(p + 8 * 64));
+    typedef short v8s16e __attribute__((ext_vector_type(8)));
+    const v8s16e v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 // Timing experiment ("store every other layer, recompute the skipped one here"): MLP_WGRAD_RECOMPUTE_PROBE=<bit mask of
 // job ids>.  The workgroups of those jobs run k_wgrad_recompute_body: a stage carries the instruction mix of the role-flipped recompute
 // job -- wave w owns activation block w of the SKIPPED layer: it forms relu(W[block w, :] a_prev) for the stage's 32 samples (16 k-steps:
@@ -190,7 +209,7 @@ __device__ __forceinline__ void k_wgrad_recompute_body(char* smem, const char* _
 
 __global__ void __launch_bounds__(512)
 k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const WgradJob* __restrict__ jobs,
-            const int4* __restrict__ wg_tab, int64_t n_wt, int NH, int NG, float* __restrict__ partials) {
+            const int4* __restrict__ wg_tab, int64_t n_wt, int NH, int NG, float* __restrict__ partials, const WgradEnc* __restrict__ Ep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -210,6 +229,12 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
     const int nst = (int)(hi - lo);
     const int a_blk = jp->a_blk[wave], b_blk = jp->b_blk[wave];
     const bool active = wave < nA;
+    const bool b_enc = jp->b_src != 0;                      // workgroup-uniform: this job's B blocks come from the row-major encoding
+    WgradEnc E = {nullptr, 1, 0};
+    if (b_enc) E = *Ep;                                     // (uniform scalar loads) the record the training forward left behind the T-blocks
+    // encoding jobs: DMA source offset of this lane (sample lane >> 2 of a 16-sample half, 16-byte piece lane & 3) and its operand-read offset
+    const unsigned enc_dma_piece = (unsigned)(lane & 3) * 16u;
+    const unsigned enc_lane_off = (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (4 * ((lane >> 4) & 1) + (lane & 3)) * 8);
 
     f32x16 acc[9];
 #pragma unroll
@@ -226,7 +251,34 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
     const int ndma = (has_a ? 2 : 0) + (has_b ? 2 : 0);
     auto issue = [&](int64_t wt, int stage) {
         char* st = smem + stage * kStageBytes;
-        if (has_b) dma_block(HT + (wt * NH + b_blk) * 2048, st + wave * 2048, lane16);
+        if (has_b) {
+            if (b_enc) {
+                // rows wt * 32 + (lane >> 2) [+ 16], clamped to the last sample; the row offset is per lane, the block's column offset uniform
+                const int64_t s0 = wt * 32 + (lane >> 2), s1 = s0 + 16;
+                const int64_t r0 = s0 < E.M ? s0 : E.M - 1, r1 = s1 < E.M ? s1 : E.M - 1;
+                const char* base = (const char*)E.enc + (int64_t)b_blk * 64;
+                // (two wave-uniform bases would need uniform rows: the clamp makes them per-lane, so both DMAs take a full 64-bit lane address)
+                const char* p0 = base + r0 * E.row_bytes + enc_dma_piece;
+                const char* p1 = base + r1 * E.row_bytes + enc_dma_piece;
+                char* dst = st + wave * 2048;
+                const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)dst;
+                unsigned keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\t"
+                    "s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, off" MIP_WGRAD_LOAD_POLICY "\n\t"
+                    "s_add_u32 m0, m0, 1024\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %2, off" MIP_WGRAD_LOAD_POLICY "\n\t"
+                    "s_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(p0), "v"(p1), "s"(lds_addr)
+                    : "memory");
+            } else {
+                dma_block(HT + (wt * NH + b_blk) * 2048, st + wave * 2048, lane16);
+            }
+        }
         if (has_a) dma_block(GT + (wt * NG + a_blk) * 2048, st + 16384 + wave * 2048, lane16);
     };
 
@@ -248,8 +300,9 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < nB) {
-                        const bf16x8 b0 = lds_frag(st + j * 2048);
-                        const bf16x8 b1 = lds_frag(st + j * 2048 + 1024);
+                        const char* sb = smem + (i % kStages) * kStageBytes + j * 2048;       // (without the lane-linear offset)
+                        const bf16x8 b0 = b_enc ? lds_frag_enc(sb, enc_lane_off, 0) : lds_frag(st + j * 2048);
+                        const bf16x8 b1 = b_enc ? lds_frag_enc(sb, enc_lane_off, 1) : lds_frag(st + j * 2048 + 1024);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
                     }
@@ -371,8 +424,16 @@ hipError_t launch_transpose_sq(int n, const float* in, float* out, hipStream_t s
 
 int mlp_wgrad_lds_bytes() { return kWgradLds; }
 
+__global__ void k_wgrad_record_enc(WgradEnc* rec, const void* enc, int64_t M, int row_bytes) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { rec->enc = enc; rec->M = M; rec->row_bytes = row_bytes; }
+}
+hipError_t launch_wgrad_record_enc(void* record, const void* enc, int64_t M, int row_bytes, hipStream_t st) {
+    hipLaunchKernelGGL(k_wgrad_record_enc, dim3(1), dim3(64), 0, st, (WgradEnc*)record, enc, M, row_bytes);
+    return hipGetLastError();
+}
+
 hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs, const void* wg_tab, int num_wgs,
-                            int64_t n_wt, int NH, int NG, float* partials, hipStream_t st) {
+                            int64_t n_wt, int NH, int NG, float* partials, hipStream_t st, const WgradEnc* enc) {
     static int attr_done[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -382,7 +443,7 @@ hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs
         attr_done[dev] = 1;
     }
     hipLaunchKernelGGL(k_mlp_wgrad, dim3(num_wgs), dim3(512), kWgradLds, st, (const char*)HT, (const char*)GT, jobs,
-                       (const int4*)wg_tab, n_wt, NH, NG, partials);
+                       (const int4*)wg_tab, n_wt, NH, NG, partials, enc);
     return hipGetLastError();
 }
 

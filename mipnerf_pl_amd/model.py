@@ -523,7 +523,7 @@ class MipNerf(torch.nn.Module):
 
     def set_precision(self, precision: str) -> "MipNerf":
         """Switch the arithmetic of all later calls: 'bf16' | 'fp32'.  The native context packs the weight streams of both precisions, so
-        nothing is rebuilt.  Typical use: `MipNerf(unbounded=True)` trains in fp32 (it has no bf16 training kernels) and renders in bf16
+        nothing is rebuilt.  Typical use: a model trained in one precision rendered in the other (e.g. fp32 parity training, bf16 rendering)
         (`model.eval(); model.set_precision('bf16')` -- about six times faster)."""
         if precision not in _PREC:
             raise ValueError(f"precision must be one of {sorted(_PREC)}")
@@ -543,9 +543,8 @@ class MipNerf(torch.nn.Module):
             if o.shape[0] == 0:
                 return self._forward_empty(o.device)
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                if self.unbounded and self.precision == L.PREC_BF16:
-                    raise NotImplementedError("MipNerf(unbounded=True, precision='bf16') is inference only (k_pre_gemm + trunk kernel); "
-                                              "train this model with precision='fp32', or call forward under torch.no_grad()")
+                # (round 5: MipNerf(unbounded=True, precision='bf16') trains through this route too -- k_pre_gemm + a trunk forward-with-save,
+                # the standard dgrad, weight-gradient jobs over the row-major encoding; the one-call train_step_native stays bounded-only)
                 from .autograd import mipnerf_forward_train
                 return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
             return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
@@ -579,7 +578,8 @@ class MipNerf(torch.nn.Module):
         if self.precision != L.PREC_BF16:
             raise NotImplementedError("train_step_native is the bf16 path; fp32 parity mode trains through autograd")
         if self.unbounded:
-            raise NotImplementedError("the unbounded-scene model has bf16 INFERENCE kernels only; it trains through autograd in fp32 precision")
+            raise NotImplementedError("the one-call native step implements the bounded model; MipNerf(unbounded=True) trains through autograd "
+                                      "(`loss.backward()` on forward's outputs), in bf16 or fp32 precision")
         if not self.stop_resample_grad:
             raise NotImplementedError("stop_resample_grad=False trains through autograd in fp32 precision (the one-call native step "
                                       "implements the shipped stop-gradient resampler)")

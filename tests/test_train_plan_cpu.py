@@ -172,3 +172,41 @@ def test_generators_schedule_narrow_layers_without_hazards(arch_kw):
     assert "namespace v9" in src and "epilogue_half" in src
     tpv = TrainPlan.build(a)
     assert "launch_mlp_bf16_trainfwd_v9" in GT.gen_trainfwd(tpv, 9) and "launch_mlp_bf16_dgrad_v9" in GT.gen_dgrad(tpv, 9)
+
+
+def test_pre_gemm_training_plan_emulation_matches_oracle():
+    """round 5: the training form of the two-kernel bf16 MLP (TrainPlan.build(arch, pre_gemm=True): k_pre_gemm + trunk forward-with-save
+    starting from the preloaded register set, the standard dgrad stream, weight-gradient jobs over 32-feature column blocks of the
+    encoding) emulated in numpy == the oracle's autograd gradients for the 672-wide unbounded-scene architecture; every parameter is
+    fed by at most one partial position, the trunk kernel's generated schedule passes the hazard replay (gen_mlp_train asserts it)."""
+    import synthetic_inputs as syn
+    from mipnerf_pl_amd.mlp_plan import Arch
+    from mipnerf_pl_amd.mlp_train_plan import TrainPlan, emulate_train
+    arch = Arch(xyz_dim=672, feat_per_deg=42, bf16_kernels=False)
+    tp = TrainPlan.build(arch, pre_gemm=True)
+    assert tp.pre_gemm and tp.NE == 21 and "enc" not in tp.h_blocks and tp.NH == 69
+    enc_jobs = [j for j in tp.jobs if j.b_src == 1]
+    assert [len(j.b_blocks) for j in enc_jobs] == [8, 8, 5, 8, 8, 5] and sum(j.biasmap is not None for j in enc_jobs) == 1
+    params = syn.make_params(seed=5, density_gain=6.0, xyz_dim=672)
+    names = [n for n, _ in arch.param_shapes()]
+    flat = np.concatenate([params[n].ravel() for n in names])
+    rng = np.random.default_rng(0)
+    S = 45                                       # 1.4 wave tiles: the padded samples carry zero deltas
+    enc = rng.uniform(-1, 1, (S, 672)).astype(np.float32)
+    v27 = rng.uniform(-1, 1, (S, 27)).astype(np.float32)
+    view = np.zeros((S, 32), np.float32)
+    view[:, :27] = v27
+    d_raw = rng.normal(0, 1e-2, (S, 4)).astype(np.float32)
+    g, seen, raw = emulate_train(tp, flat, enc, view, d_raw)
+    _, nparams = tp.fwd.param_offsets()
+    assert int(seen[:nparams].max()) == 1
+    rr, dd = orc.mlp_forward(params, enc[:, None, :], v27)
+    assert np.abs(raw[:, :3] - rr[:, 0]).max() <= 5e-6 and np.abs(raw[:, 3] - dd[:, 0, 0]).max() <= 2e-5
+    og = orc.mlp_backward(params, enc[:, None, :], v27, d_raw[:, None, :3], d_raw[:, None, 3:])
+    offs, _ = tp.fwd.param_offsets()
+    for i, n in enumerate(names):
+        a = g[offs[i]:offs[i] + params[n].size].reshape(params[n].shape)
+        assert np.abs(a - og[n]).max() <= 5e-6 * max(np.abs(og[n]).max(), 1e-20), n
+    # the job table tells the kernel which jobs read the encoding
+    jt = tp.job_table()
+    assert [int(r[3]) for r in jt] == [j.b_src for j in tp.jobs]
