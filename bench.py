@@ -736,6 +736,12 @@ def run_fp32_c4(args, e):
                            "finite": bool(torch.isfinite(bout[-1][0]).all()), "traffic": unbounded_bf16_traffic(M)}
         except Exception as ex:  # noqa: BLE001
             unb["bf16"] = {"error": f"{type(ex).__name__}: {ex}"}
+        # ... and TRAINING this model (round 5): one optimisation step through autograd (training_step + backward + torch Adam, what the
+        # reference's Lightning loop does) on 4096 rays x (128 + 128) samples, bf16 kernels against the fp32 path
+        try:
+            unb["train"] = run_train_unbounded(args, e)
+        except Exception as ex:  # noqa: BLE001
+            unb["train"] = {"error": f"{type(ex).__name__}: {ex}"}
     except Exception as ex:  # noqa: BLE001  (an extra must not take the record down)
         unb = {"error": f"{type(ex).__name__}: {ex}"}
     return {"unbounded": unb, "value": round(B * N * 2 * e.world * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warm,
@@ -747,6 +753,45 @@ def run_fp32_c4(args, e):
             "config": {"workload": (f"BASELINE.json configs[3] shape: MipNerf.forward inference, {B} rays x ({N} coarse + {N} fine) samples per GPU, "
                                     f"per-ray near/far, fp32 parity mode"), "mode": "fp32", "rays_per_gpu": B, "samples_per_level": N,
                        "parallelism": f"ray-split x{e.world} (no data-path collective)"}}
+
+
+def run_train_unbounded(args, e):
+    import torch
+    import synthetic_inputs as syn
+    from mipnerf_pl_amd import Rays
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    B, N = 4096, 128
+    R = Rays(*[torch.from_numpy(a).to(e.dev) for a in syn.synthetic_rays(B, seed=100 + e.rank, unbounded=True)])
+    gt = torch.rand(B, 3, device=e.dev)
+    params = syn.make_params(seed=0, density_gain=40.0, xyz_dim=672)
+    out = {"workload": f"MipNerf(unbounded=True) training step through autograd, {B} rays x ({N} + {N}) samples, randomized, torch Adam",
+           "flop_per_sample": 3 * 1810432 - 2 * 2 * 672 * 256}          # forward + wgrad + dgrad (no dgrad into the encoding: 2 x 672 x 256 MACs less)
+    for precision, steps in (("fp32", 3), ("bf16", 10)):
+        hp = dict(DEFAULT_HPARAMS)
+        hp.update({"nerf.num_samples": N, "nerf.unbounded": True})
+        system = MipNeRFSystem(hp, precision=precision)
+        system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        system = system.to(e.dev)
+        (opt,), (sch,) = system.configure_optimizers()
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = system.training_step((R, gt), 0)
+            loss.backward()
+            opt.step()
+            sch["scheduler"].step()
+            return loss
+        step()
+        step()
+        dt, loss = timed(e, step, 0, steps)
+        ms = dt / steps * 1e3
+        tf = out["flop_per_sample"] * B * N * 2 / (ms * 1e-3) / 1e12
+        out[precision] = {"ms_per_step": round(ms, 3), "steps": steps, "value": round(B * N * 2 * e.world / (ms * 1e-3), 1), "achieved_tflops": round(tf, 1),
+                          "frac_of_peak": round(tf / PEAK_TFLOPS[precision], 4), "loss_finite": bool(torch.isfinite(loss.detach()))}
+        del system, opt
+        torch.cuda.empty_cache()
+    out["speedup_bf16_over_fp32"] = round(out["fp32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 2)
+    return out
 
 
 def cpu_baseline(args, rays_np, params):

@@ -451,7 +451,7 @@ def unpack_mask(word, t):
     return out
 
 
-def emulate_train_tile(tp: TrainPlan, flat_params, enc, view, d_raw, valid, round_bf16=False):
+def emulate_train_tile(tp: TrainPlan, flat_params, enc, view, d_raw, valid, round_bf16=False, return_masks=False):
     """One wave tile (32 samples): forward-with-save + dgrad exactly as the generated kernels move data.
     enc [32, xyz], view [32, 32] (padded), d_raw [32, 4], valid [32] bool.
     Returns HT [NH, 2, 64, 8], GT [NG, 2, 64, 8], raw [32, 4]."""
@@ -563,6 +563,8 @@ def emulate_train_tile(tp: TrainPlan, flat_params, enc, view, d_raw, valid, roun
             for t in range(op.ntiles):
                 GT[op.gblock + t] = tblock(newreg[2 * t], newreg[2 * t + 1])
     assert ci == tp.n_bchunks_real
+    if return_masks:
+        return HT, GT, raw, ET, masks
     if tp.pre_gemm:
         return HT, GT, raw, ET
     return HT, GT, raw

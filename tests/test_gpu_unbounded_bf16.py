@@ -342,17 +342,24 @@ def test_mlp_training_kernels_vs_emulation_and_oracle(G, shape):
     og = orc.mlp_backward(params, enc, v27, d_raw[..., :3], d_raw[..., 3:])
     offs, _ = tp.fwd.param_offsets()
     worst_em, worst_cos = 0.0, 1.0
+    per = {}
     for i, (k, p) in enumerate(model.mlp.named_parameters()):
         got = p.grad.detach().cpu().numpy().astype(np.float64).ravel()
         em = g_em[offs[i]:offs[i] + got.size].astype(np.float64)
         ref = og[k].astype(np.float64).ravel()
-        worst_em = max(worst_em, float(np.linalg.norm(got - em) / max(np.linalg.norm(em), 1e-30)))
+        per[k] = float(np.linalg.norm(got - em) / max(np.linalg.norm(em), 1e-30))
+        worst_em = max(worst_em, per[k])
         if np.linalg.norm(ref) > 0:
             worst_cos = min(worst_cos, float(got @ ref / max(np.linalg.norm(got) * np.linalg.norm(ref), 1e-30)))
     e_raw = G.maxdiff(raw.detach().reshape(-1, 4), raw_em)
-    G.record(f"unbounded bf16 training kernels {B}x{N}", worst_rel_l2_vs_emulation=worst_em, worst_cos_vs_fp32=worst_cos, raw_vs_emulation=e_raw)
-    # the bounds of the standard model's kernels (tests/test_gpu_train.py): vs the emulation only the accumulation order differs
-    assert worst_em <= 1e-2, worst_em
+    G.record(f"unbounded bf16 training kernels {B}x{N}", worst_rel_l2_vs_emulation=worst_em, worst_cos_vs_fp32=worst_cos, raw_vs_emulation=e_raw,
+             **{"em_" + k: v for k, v in per.items()})
+    # vs the emulation only the fp32 accumulation order differs.  That moves ~2.5e-5 of the bf16 activations by one ulp, and about one in twenty
+    # of those moves flips a ReLU bit further down -- one flipped bit changes that sample's delta in every layer below it, i.e. ~1 % of a
+    # gradient tensor at 100-600 samples (measured: 1 x 5 samples 2e-7 -- the dataflow is exact --, 3 x 43: ONE mask bit in 5 wave tiles ->
+    # 1.05e-2, 9 x 64 1.14e-2, 40 x 70 3.9e-3; scripts/micro/dbg_train360.py lists the flips tile by tile; the standard model's cases
+    # happened to meet none: 3-4e-4).  Bound: 3 x that.
+    assert worst_em <= (1e-5 if B * N <= 8 else 3e-2), worst_em
     assert e_raw <= 2e-2 * max(1.0, float(np.abs(raw_em).max()))
     assert worst_cos >= 0.97, worst_cos
 
@@ -382,7 +389,16 @@ def test_training_step_bf16_vs_fp32_autograd_path(G):
     whole = float(a @ b / (a.norm() * b.norm()))
     G.record("unbounded training step bf16 vs fp32", loss_fp32=l32, loss_bf16=l16, worst_cos=min(cos.values()), whole_cos=whole)
     assert abs(l16 - l32) <= 1e-3 * max(1.0, abs(l32))
-    assert whole >= 0.995 and min(cos.values()) >= 0.99, (whole, sorted(cos.items(), key=lambda kv: kv[1])[:3])
+    # measured: whole gradient 0.99936, every tensor >= 0.9936 except the encoding-fed first layer, 0.981 -- the tensor that is lowest in the
+    # standard model too (0.9917): its delta has come through all eight dgrad layers in bf16 and is contracted against oscillating features
+    # that do not average the noise out; by degree of the features it multiplies it falls from the low degrees to the top ones
+    w0_16, w0_32 = g16["layers.0.0.weight"].reshape(256, 2, 16, 21), g32["layers.0.0.weight"].reshape(256, 2, 16, 21)
+    low = float((w0_16[:, :, :6] * w0_32[:, :, :6]).sum() / (w0_16[:, :, :6].norm() * w0_32[:, :, :6].norm()))
+    G.record("unbounded training step bf16 vs fp32, first layer by degree", deg0to5=low,
+             **{f"deg{l}": float((w0_16[:, :, l] * w0_32[:, :, l]).sum() / (w0_16[:, :, l].norm() * w0_32[:, :, l].norm()).clamp_min(1e-30)) for l in range(16)})
+    others = {k: v for k, v in cos.items() if k != "layers.0.0.weight"}
+    assert whole >= 0.998 and min(others.values()) >= 0.99, (whole, sorted(cos.items(), key=lambda kv: kv[1])[:3])
+    assert cos["layers.0.0.weight"] >= 0.97 and low >= 0.985, (cos["layers.0.0.weight"], low)
     (opt,), (sch,) = system.configure_optimizers()
     system.zero_grad(set_to_none=True)
     first = None
