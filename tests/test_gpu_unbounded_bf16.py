@@ -27,9 +27,9 @@ def G():
     return gpu_util
 
 
-def _model(params, N, precision):
+def _model(params, N, precision, **kw):
     from mipnerf_pl_amd import MipNerf
-    m = MipNerf(num_samples=N, unbounded=True, precision=precision)
+    m = MipNerf(num_samples=N, unbounded=True, precision=precision, **kw)
     m.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
     return m.to(DEV)
 
@@ -245,9 +245,11 @@ def test_forward_on_a_trained_unbounded_field_vs_the_360_oracle(G, name, precisi
     for k in sorted(params):
         h.update(np.ascontiguousarray(params[k]).tobytes())
     assert h.hexdigest() == str(g["field_sha256"])
-    assert float(g["frac_empty"]) >= 0.15 and float(g["frac_opaque"]) >= 0.2 and float(g["frac_between"]) >= 0.05
+    assert float(g["frac_empty"]) >= 0.15 and float(g["frac_opaque"]) >= 0.15 and float(g["frac_between"]) >= 0.05
     rays = syn.Rays(*[g["rays_" + k] for k in syn.Rays._fields])
-    model = _model(params, int(g["num_samples"]), precision)
+    # density_bias: the field was trained from a transparent start (scripts/make_golden_360.py: -4 instead of the default -1, which is opaque
+    # before the first step on rays that reach t = 20) -- a constructor argument of the reference (mip_nerf.py:129)
+    model = _model(params, int(g["num_samples"]), precision, density_bias=float(g["density_bias"]))
     with torch.no_grad():
         ret = model(G.to_dev(rays), False, True)
     acc_ref = g["l1_acc"]
