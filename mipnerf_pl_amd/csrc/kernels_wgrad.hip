@@ -207,31 +207,23 @@ __device__ __forceinline__ void k_wgrad_recompute_body(char* smem, const char* _
 #endif
 }  // namespace
 
-__global__ void __launch_bounds__(512)
-k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const WgradJob* __restrict__ jobs,
-            const int4* __restrict__ wg_tab, int64_t n_wt, int NH, int NG, float* __restrict__ partials, const WgradEnc* __restrict__ Ep) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// One workgroup's share of one job.  ENC = false: the B blocks are T-blocks of the saved-activation buffer (every job of the standard
+// shapes; exactly the code of rounds 1-4).  ENC = true (round 5, pre-GEMM plans): 32-feature column blocks of the row-major encoding.
+// Two instantiations behind one workgroup-uniform branch, so the encoding path costs the standard jobs nothing (as one body with the
+// choice inside the unrolled operand loop, the standard training step ran 12 % slower: 4.73 instead of 4.20 ms).
+template <bool ENC>
+__device__ __forceinline__ void wgrad_body(char* smem, const char* __restrict__ HT, const char* __restrict__ GT, const WgradJob* jp, const int4 wg,
+                                           int64_t n_wt, int NH, int NG, float* __restrict__ partials, const WgradEnc* __restrict__ Ep, int lane,
+                                           int wave) {
     const unsigned lane16 = (unsigned)lane * 16u;
-    const int4 wg = wg_tab[blockIdx.x];                     // job, split, nsplits, partial slot
-    const WgradJob* jp = jobs + wg.x;                       // uniform: scalar loads
-#if defined(MIP_WGRAD_RECOMPUTE_PROBE) && MIP_WGRAD_RECOMPUTE_PROBE
-    if ((MIP_WGRAD_RECOMPUTE_PROBE >> wg.x) & 1) {          // timing experiment, workgroup-uniform
-        k_wgrad_recompute_body(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, lane, wave);
-        return;
-    }
-#endif
     const int nA = jp->nA, nB = jp->nB;
     const bool with_bias = jp->bias != 0;
     const int64_t lo = n_wt * wg.y / wg.z, hi = n_wt * (wg.y + 1) / wg.z;
     const int nst = (int)(hi - lo);
     const int a_blk = jp->a_blk[wave], b_blk = jp->b_blk[wave];
     const bool active = wave < nA;
-    const bool b_enc = jp->b_src != 0;                      // workgroup-uniform: this job's B blocks come from the row-major encoding
     WgradEnc E = {nullptr, 1, 0};
-    if (b_enc) E = *Ep;                                     // (uniform scalar loads) the record the training forward left behind the T-blocks
+    if (ENC) E = *Ep;                                       // (uniform scalar loads) the record the training forward left behind the T-blocks
     // encoding jobs: DMA source offset of this lane (sample lane >> 2 of a 16-sample half, 16-byte piece lane & 3) and its operand-read offset
     const unsigned enc_dma_piece = (unsigned)(lane & 3) * 16u;
     const unsigned enc_lane_off = (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (4 * ((lane >> 4) & 1) + (lane & 3)) * 8);
@@ -252,12 +244,12 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
     auto issue = [&](int64_t wt, int stage) {
         char* st = smem + stage * kStageBytes;
         if (has_b) {
-            if (b_enc) {
-                // rows wt * 32 + (lane >> 2) [+ 16], clamped to the last sample; the row offset is per lane, the block's column offset uniform
+            if (ENC) {
+                // rows wt * 32 + (lane >> 2) [+ 16], clamped to the last sample (their deltas are zero); the clamp makes the row per-lane,
+                // so both DMAs take a full 64-bit lane address
                 const int64_t s0 = wt * 32 + (lane >> 2), s1 = s0 + 16;
                 const int64_t r0 = s0 < E.M ? s0 : E.M - 1, r1 = s1 < E.M ? s1 : E.M - 1;
                 const char* base = (const char*)E.enc + (int64_t)b_blk * 64;
-                // (two wave-uniform bases would need uniform rows: the clamp makes them per-lane, so both DMAs take a full 64-bit lane address)
                 const char* p0 = base + r0 * E.row_bytes + enc_dma_piece;
                 const char* p1 = base + r1 * E.row_bytes + enc_dma_piece;
                 char* dst = st + wave * 2048;
@@ -294,15 +286,15 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
             const int nxt = i + kStages - 1;
             issue(lo + (nxt < nst ? nxt : nst - 1), nxt % kStages);
             if (active) {
-                const char* st = smem + (i % kStages) * kStageBytes + lane16;
+                const char* sb = smem + (i % kStages) * kStageBytes;      // (stage base without the lane-linear offset)
+                const char* st = sb + lane16;
                 const bf16x8 a0 = lds_frag(st + 16384 + wave * 2048);
                 const bf16x8 a1 = lds_frag(st + 16384 + wave * 2048 + 1024);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < nB) {
-                        const char* sb = smem + (i % kStages) * kStageBytes + j * 2048;       // (without the lane-linear offset)
-                        const bf16x8 b0 = b_enc ? lds_frag_enc(sb, enc_lane_off, 0) : lds_frag(st + j * 2048);
-                        const bf16x8 b1 = b_enc ? lds_frag_enc(sb, enc_lane_off, 1) : lds_frag(st + j * 2048 + 1024);
+                        const bf16x8 b0 = ENC ? lds_frag_enc(sb + j * 2048, enc_lane_off, 0) : lds_frag(st + j * 2048);
+                        const bf16x8 b1 = ENC ? lds_frag_enc(sb + j * 2048, enc_lane_off, 1) : lds_frag(st + j * 2048 + 1024);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
                     }
@@ -327,6 +319,25 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(512)
+k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const WgradJob* __restrict__ jobs,
+            const int4* __restrict__ wg_tab, int64_t n_wt, int NH, int NG, float* __restrict__ partials, const WgradEnc* __restrict__ Ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int4 wg = wg_tab[blockIdx.x];                     // job, split, nsplits, partial slot
+    const WgradJob* jp = jobs + wg.x;                       // uniform: scalar loads
+#if defined(MIP_WGRAD_RECOMPUTE_PROBE) && MIP_WGRAD_RECOMPUTE_PROBE
+    if ((MIP_WGRAD_RECOMPUTE_PROBE >> wg.x) & 1) {          // timing experiment, workgroup-uniform
+        k_wgrad_recompute_body(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, lane, wave);
+        return;
+    }
+#endif
+    if (jp->b_src != 0) wgrad_body<true>(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, Ep, lane, wave);      // workgroup-uniform
+    else wgrad_body<false>(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, Ep, lane, wave);
 }
 
 // grad[idx] = sum over the job's splits of the partial at `pos`, for every position that feeds a parameter

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -f gpurun_out/parity.jsonl
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6 | tee gpurun_out/${T}_smoke.txt
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/${T}_pytest_gpu_tail.txt
+timeout 1500 python -m pytest tests ${PYTEST_X:--x} -q -m gpu 2>&1 | tail -${PYTEST_TAIL:-8} > gpurun_out/${T}_pytest_gpu_tail.txt
 tail -3 gpurun_out/${T}_pytest_gpu_tail.txt
 cp gpurun_out/parity.jsonl gpurun_out/${T}_parity.jsonl
 timeout 900 python bench.py > gpurun_out/${T}_bench.out 2> gpurun_out/${T}_bench.err
