@@ -102,8 +102,12 @@ def test_forward_bf16_vs_fp32_and_vs_per_stage_route(G, randomized, B):
     G.record(f"unbounded bf16 forward vs fp32 B={B} randomized={randomized}", **errs)
     # the coarse level sees the same fence posts: colours within the bf16 tolerance of the standard model's full-size test (3e-2 max,
     # PSNR >= 55 dB); the fine level's fence posts move with the coarse weights, so it is held by PSNR only
-    assert errs["l0_rgb"] <= 3e-2 and errs["l0_acc"] <= 3e-2
-    assert errs["psnr_fine_rgb_db"] >= 50.0                  # measured 55-66 dB
+    # Bounds = 2 x the maxima measured over the six cases (l0 rgb 2.4e-3, l0 acc 3.6e-3) and the measured minimum - 2 dB for the fine level
+    # (55.1 ... 65.7 dB).  This is bf16 HIP against fp32 HIP on a FOG of random weights -- white noise in space at 16 undamped degrees --, where
+    # the 1e-2 shifts of the resampled fence posts show in the colour: the standard model's numpy model measures the same 55 dB on such rays
+    # (scripts/analysis/bf16_360_error_budget.py).  The level that matters is held by the trained-field test below: 70 dB against the oracle.
+    assert errs["l0_rgb"] <= 4.8e-3 and errs["l0_acc"] <= 7.2e-3, errs
+    assert errs["psnr_fine_rgb_db"] >= 53.0, errs
     for lvl in range(2):
         assert all(bool(torch.isfinite(t).all()) for t in got[lvl])
     # per-stage route of the coarse level: row-major bf16 encodings -> mipnerf_mlp_forward -> compositing; the forward call wrote the same
