@@ -51,12 +51,14 @@ CFG = dict(batch=1024, num_samples=64, steps=400, lr_init=2e-3, lr_final=2e-5, m
 
 
 def _scene():
-    cache = os.environ.get("SCENE360_CACHE", "/tmp/scene360_rays.npz")
+    """every training ray of the procedural unbounded scene + its ground-truth colour; rendered once (float64 quadrature, ~25 min) and kept as
+    tests/golden/scene360_rays.npz, which the GPU quality test of the unbounded model's training also reads"""
+    cache = os.path.join(OUT, "scene360_rays.npz")
     if os.path.exists(cache):
         z = np.load(cache)
         return orc.Rays(*[z["rays_" + k] for k in orc.Rays._fields]), z["rgb"]
     R, rgb = fx.scene360_rays()
-    np.savez(cache, rgb=rgb, **{"rays_" + k: getattr(R, k) for k in orc.Rays._fields})
+    np.savez_compressed(cache, rgb=rgb.astype(F32), **{"rays_" + k: np.asarray(getattr(R, k), F32) for k in orc.Rays._fields})
     return R, rgb
 
 
