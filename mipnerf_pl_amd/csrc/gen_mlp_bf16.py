@@ -69,8 +69,9 @@ VARIANTS = [
     # handles since the trunk kernels of round 4 (an extra GROUP_BEGIN at the tile end).  Training: fp32 forward + GEMM backward
     # (the bf16 training schedule is generated for one view layer, mlp_train_plan.py).
     Arch(net_depth_condition=2),
-    # a 512-wide trunk with a 256-wide view layer (fp32 only: the bf16 kernels hold a layer's activations in registers, <= 256 wide)
-    Arch(net_width=512, net_width_condition=256, bf16_kernels=False),
+    # a 512-wide trunk with a 256-wide view layer.  Round 5: bf16 INFERENCE kernel too -- 4-wave workgroups at one wave per SIMD (waves_of below).
+    # Training: fp32 forward + GEMM backward.
+    Arch(net_width=512, net_width_condition=256),
 ]
 
 
@@ -278,6 +279,11 @@ __device__ __forceinline__ void pre_load(f32x16& acc, const char* p) {
 template <bool DMA>
 __device__ __forceinline__ void issue_group(const char* __restrict__ stream, char* smem, int group, int slot,
                                             int wave, unsigned lane16) {
+#ifdef MIP_OPAQUE_STREAM_BASE
+    // long streams (the 512-wide trunk: 288 groups): without this the compiler hoists one loop-invariant 64-bit base PER GROUP out of the tile
+    // loop and spills ~530 SGPRs to VGPR lanes; an opaque copy makes each base two scalar adds at its point of use
+    asm volatile("" : "+s"(stream));
+#endif
     const char* gbase = stream + ((size_t)group * kGroupBytes + (size_t)wave * 4096);   // uniform
     char* lbase = smem + slot * kGroupBytes + wave * 4096;                              // uniform
     if (DMA) {
@@ -445,8 +451,20 @@ def _shadow_fits(plan: Plan) -> bool:
     return len(tail) == 3 and all(op.nk * len(op.tiles) // 2 >= 18 for op in tail)
 
 
+def waves_of(arch: Arch) -> int:
+    """Wavefronts per workgroup.  A layer's input AND output activations live in registers (2 x width/16 k-step fragments of 4 VGPRs): up to 256
+    wide that is 128 of the 256 registers a wave has at two waves per SIMD; a 512-wide trunk needs 256 for the activations alone, so its kernel
+    runs ONE wave per SIMD (4-wave workgroups of 128 samples, one per CU) with the 512-register budget of that occupancy (arch + acc VGPRs)."""
+    return WAVES if max(arch.net_width, arch.net_width_condition) <= 256 else 4
+
+
 def gen_kernel(plan: Plan, variant: int = 0) -> str:
     pre = plan.pre_gemm        # trunk of the two-kernel form (mlp_pre_plan.py): X preloaded, skip-layer accumulators from k_pre_gemm
+    WAVES = waves_of(plan.arch)                 # (shadow the module defaults: everything below is per kernel)
+    GROUP = 4 * WAVES
+    wide = WAVES != globals()["WAVES"]
+    WG_PER_CU = 1 if wide else 8 // WAVES
+    nreg = max(plan.arch.net_width, plan.arch.net_width_condition) // 16      # k-step fragments of one activation register set
     sfx = f"_pre_v{variant}" if pre else ("" if variant == 0 else f"_v{variant}")
     nchunks = len(plan.chunks)
     assert nchunks % GROUP == 0, "stream must be a whole number of ring groups"
@@ -463,7 +481,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     panels, slots = build_schedule(plan)
     nreal = len(slots)
     # padding: inside the last ring group, or exactly one whole group of zeros, begun by an extra GROUP_BEGIN at the tile end (trunk plans; two view layers)
-    assert nreal == plan.n_real_chunks and (nchunks - nreal < GROUP or (nchunks - nreal == GROUP and nreal % GROUP == 0))
+    # (4-wave kernels: the stream is padded to mlp_plan.RING_MULTIPLE = 64 chunks = four of their groups; every unentered padding group gets its GROUP_BEGIN)
+    assert nreal == plan.n_real_chunks and (nchunks - nreal < GROUP or (nchunks - nreal == GROUP and nreal % GROUP == 0) or wide)
     lines = []
     e = lines.append
     e("// AUTO-GENERATED by gen_mlp_bf16.py from mlp_plan.py -- do not edit by hand.")
@@ -482,6 +501,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e("typedef __attribute__((ext_vector_type(16))) float f32x16;")
     if pre and PRE_NT:
         e("#define PRE_LD(ptr) __builtin_nontemporal_load(ptr)")
+    if wide:
+        e("#define MIP_OPAQUE_STREAM_BASE 1")
     e(f"constexpr int kRingBytes = {ring_bytes};")
     e(f"constexpr int kBiasBytes = {nbias_bytes};")
     e(f"constexpr int kEncOff = {enc_off};")
@@ -493,7 +514,7 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e(KERNEL_PREAMBLE.replace("BARRIER_INSN", "s_nop 0" if ABLATE_BARRIER else "s_barrier")
       .replace("WAIT_INSN", "s_waitcnt lgkmcnt(0)" if ABLATE_WAIT else "s_waitcnt vmcnt(0) lgkmcnt(0)"))
     e("template <bool DMA, bool IPE>")
-    e(f"__global__ void __launch_bounds__({WAVES * 64}, 2)")
+    e(f"__global__ void __launch_bounds__({WAVES * 64}, {1 if wide else 2})")
     e("k_mlp_bf16(const char* __restrict__ stream, const float* __restrict__ bias_tab,")
     if pre:
         e("           const char* __restrict__ pre_x, const char* __restrict__ pre_acc,")
@@ -543,7 +564,7 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         e("        } else {")
         e(f"            issue_encodings<DMA, {nenc}, 0>(enc + sc * {a.xyz_dim} + hi * 8, viewenc + ray * 32 + hi * 8, encw, lane16);")
         e("        }")
-    e("        bf16x8 X[16], Y[16], " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ", E0, E1, E2;")
+    e(f"        bf16x8 X[{nreg}], Y[{nreg}], " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ", E0, E1, E2;")
     if pre:
         e("        // what k_pre_gemm left for this wave tile: X = bf16(relu(layer 0)) as 16 lane-linear fragments, the skip layer's accumulator images")
         e(f"        const int64_t wt = (int64_t)tile * {WAVES} + wave;")

@@ -146,9 +146,9 @@ class Plan:
         register set X preloaded from memory (bf16(relu(layer 0))) and the skip layer's accumulators initialised from the GEMM's fp32
         partial sums (Op.pre) instead of the bias."""
         a = arch or Arch()
-        wmax = 256 if (a.bf16_kernels or pre_gemm) else 512      # the bf16 kernels keep a whole layer in registers; the fp32 kernel in LDS
+        wmax = 256 if pre_gemm else 512      # (above 256 the bf16 kernel runs one wave per SIMD: gen_mlp_bf16.waves_of)
         if a.net_width % TILE or a.net_width_condition % TILE or a.net_width > wmax or a.net_width_condition > wmax:
-            raise NotImplementedError("MFMA kernels need widths that are multiples of 32 and <= 256 (<= 512 for fp32-only variants)")
+            raise NotImplementedError("MFMA kernels need widths that are multiples of 32 and <= 512 (<= 256 for the two-kernel trunk form)")
         if a.xyz_dim % KSTEP or a.view_dim > 32 or a.num_rgb > 4 or a.num_density != 1:
             raise NotImplementedError("unsupported encoding / head size for the MFMA kernels")
         if a.net_depth >= 2 and (a.net_depth - 1) % a.skip_index == 0 and a.net_depth - 1 > 0:

@@ -132,6 +132,8 @@ class TrainPlan:
             raise NotImplementedError("training kernels are generated for net_depth_condition == 1")
         if a.xyz_dim % TILE:
             raise NotImplementedError("training kernels need xyz_dim to be a multiple of 32")
+        if max(a.net_width, a.net_width_condition) > 256:
+            raise NotImplementedError("training kernels are generated for widths <= 256 (two waves per SIMD; the 512-wide trunk has an inference kernel only)")
         tp = TrainPlan(fwd, pre_gemm=pre_gemm)
         D, W, Wc, E = a.net_depth, a.net_width, a.net_width_condition, a.xyz_dim
         nW, nC, nE = W // TILE, Wc // TILE, E // TILE

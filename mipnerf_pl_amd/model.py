@@ -440,8 +440,9 @@ class MipNerf(torch.nn.Module):
     uniform in inverse depth, fine-level resampling over the inverse-depth fence posts, conical frustums lifted to
     FULL-covariance Gaussians, contracted into the radius-2 ball, encoded with the off-axis IPE on 21 directions -- 42 features
     per degree, so the MLP's first layer / skip concat are 42 * (max_deg_point - min_deg_point) wide (672 for 16 degrees).  Default
-    precision fp32 (forward, rendering and training through autograd); precision='bf16' is INFERENCE only (two MLP kernels,
-    csrc/gen_pre_gemm.py; about six times faster).  `disparity` / `disable_integration` do not apply."""
+    precision fp32 (forward, rendering and training through autograd); precision='bf16' runs the MLP as two kernels (csrc/gen_pre_gemm.py +
+    a trunk kernel; forward about seven times faster) and, since round 5, TRAINS through autograd on bf16 kernels too (forward-with-save,
+    dgrad, weight-gradient jobs over the encoding; 7.4 ms against 51 ms per 4096-ray step).  `disparity` / `disable_integration` do not apply."""
 
     def __init__(self, num_samples: int = 128, num_levels: int = 2, resample_padding: float = 0.01,
                  stop_resample_grad: bool = True, use_viewdirs: bool = True, disparity: bool = False,
@@ -482,8 +483,8 @@ class MipNerf(torch.nn.Module):
                 raise NotImplementedError("unbounded=True samples in inverse depth and always integrates (disparity / disable_integration do not apply)")
             if not stop_resample_grad:
                 raise NotImplementedError("unbounded=True implements the shipped stop-gradient resampler")
-            # fp32 unless asked otherwise.  precision='bf16' is INFERENCE only: the 672-wide encoding runs as k_pre_gemm + a trunk kernel
-            # (csrc/gen_pre_gemm.py); there are no bf16 training kernels for this shape (forward under autograd raises)
+            # fp32 unless asked otherwise.  precision='bf16': the 672-wide encoding runs as k_pre_gemm + a trunk kernel (csrc/gen_pre_gemm.py),
+            # in inference and (round 5) under autograd; the one-call native step (train_step_native) stays the bounded model's
             precision = precision or os.environ.get("MIPNERF_PRECISION", "fp32")
         mlp_view_dim = deg_view * 3 * 2
         mlp_view_dim = mlp_view_dim + 3 if append_identity else mlp_view_dim

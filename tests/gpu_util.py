@@ -46,6 +46,7 @@ BF16_MEASURED = {
     "variant var_d6s3_48x64": dict(rgb=4.9e-3, distance=5.4e-2, acc=8.6e-3, weights=4.0e-2, t_samples=3.3e-2),
     "variant var_dc2_48x64": dict(rgb=6.4e-3, distance=4.1e-2, acc=1.2e-2, weights=2.7e-2, t_samples=3.6e-2),
     "variant var_noview_48x64": dict(rgb=7.7e-4, distance=9.2e-3, acc=4.2e-4, weights=7.7e-3, t_samples=1.2e-2),
+    "variant var_w512_24x64": dict(rgb=3.0e-3, distance=1.1e-2, acc=4.5e-3, weights=5.3e-3, t_samples=9.8e-3),     # round 5: 60.1 dB
     "variant var_w100c40_48x64": dict(rgb=2.2e-3, distance=2.0e-2, acc=1.9e-3, weights=2.6e-2, t_samples=2.5e-2),
     "variant var_w128_48x64": dict(rgb=2.1e-3, distance=0.0, acc=3.5e-3, weights=2.8e-3, t_samples=1.1e-2),
     "variant var_w200c72_48x64": dict(rgb=7.4e-4, distance=1.2e-2, acc=5.5e-5, weights=8.0e-3, t_samples=7.6e-3),
