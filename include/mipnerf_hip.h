@@ -78,12 +78,13 @@ typedef struct mipnerf_config {
                                  /* density_randn tensor is given (mip_nerf.py:232-233)     */
     int32_t unbounded;           /* 0 ; 1 => the unbounded-scene (mip-NeRF 360) path: fence posts uniform in inverse depth,  */
                                  /* contracted full-covariance Gaussians, off-axis IPE with 42 features per degree (what     */
-                                 /* models/mip.py:106-124, 292-319, 424-447 aim at).  fp32 (forward + training) or bf16      */
-                                 /* INFERENCE (mipnerf_forward / mipnerf_mlp_forward: the 672-wide encoding runs as          */
-                                 /* k_pre_gemm + a trunk kernel, csrc/gen_pre_gemm.py); no bf16 training kernels             */
+                                 /* models/mip.py:106-124, 292-319, 424-447 aim at).  fp32 or bf16 (the 672-wide encoding    */
+                                 /* runs as k_pre_gemm + a trunk kernel, csrc/gen_pre_gemm.py): mipnerf_forward,             */
+                                 /* mipnerf_mlp_forward and the per-stage training entry points (mipnerf_mlp_forward_train / */
+                                 /* _dgrad / _backward); mipnerf_train_step is the bounded model's                           */
 } mipnerf_config;
 
-#define MIPNERF_MAX_SAMPLES 512
+#define MIPNERF_MAX_SAMPLES 1024
 #define MIPNERF_NUM_PARAM_TENSORS 24 /* 2 x (8 trunk + density + extra + 1 view + color)   */
 
 /* The 7 fields of the reference `Rays` namedtuple (datasets/datasets.py:13-16), SoA. */

@@ -14,7 +14,7 @@ OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_WORKSPACE = 0, 1, 2, 3, 4
 PREC_FP32, PREC_BF16 = 0, 1
 FLAG_WHITE_BKGD, FLAG_DISPARITY = 1, 2
 NUM_PARAM_TENSORS = 24
-MAX_SAMPLES = 512
+MAX_SAMPLES = 1024
 
 
 class Config(C.Structure):

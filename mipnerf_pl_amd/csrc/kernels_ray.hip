@@ -203,9 +203,9 @@ __global__ void __launch_bounds__(64 * kRaysPerBlock)
 k_piecewise_constant_pdf(int64_t B, int N, const float* __restrict__ bins, const float* __restrict__ weights,
                          int n_draws, const float* __restrict__ u_rand, float padding,
                          float u_step, float u_jitter, float* __restrict__ out) {
-    __shared__ float s_w[kRaysPerBlock][kPdfMaxBins + 2];
-    __shared__ float s_cdf[kRaysPerBlock][kPdfMaxBins + 2];
-    __shared__ float s_bins[kRaysPerBlock][kPdfMaxBins + 2];
+    __shared__ float s_w[kRaysPerBlock][PdfRow<K>::kBins + 2];
+    __shared__ float s_cdf[kRaysPerBlock][PdfRow<K>::kBins + 2];
+    __shared__ float s_bins[kRaysPerBlock][PdfRow<K>::kBins + 2];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int64_t b = (int64_t)blockIdx.x * kRaysPerBlock + wv;
@@ -233,9 +233,9 @@ k_composite_resample(int64_t B, int N, const float4* __restrict__ rgb_sigma, con
                      const float* __restrict__ dirs, int white_bkgd, float* __restrict__ comp_rgb, float* __restrict__ distance,
                      float* __restrict__ acc_out, float* __restrict__ weights, const float* __restrict__ bins,
                      const float* __restrict__ u_rand, float padding, float u_step, float u_jitter, float* __restrict__ t_new) {
-    __shared__ float s_w[kRaysPerBlock][kPdfMaxBins + 2];
-    __shared__ float s_cdf[kRaysPerBlock][kPdfMaxBins + 2];
-    __shared__ float s_bins[kRaysPerBlock][kPdfMaxBins + 2];
+    __shared__ float s_w[kRaysPerBlock][PdfRow<K>::kBins + 2];
+    __shared__ float s_cdf[kRaysPerBlock][PdfRow<K>::kBins + 2];
+    __shared__ float s_bins[kRaysPerBlock][PdfRow<K>::kBins + 2];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int64_t b = (int64_t)blockIdx.x * kRaysPerBlock + wv;
@@ -328,12 +328,13 @@ hipError_t launch_volumetric_rendering(int64_t B, int N, const float* rgb_sigma,
     hipLaunchKernelGGL((k_volumetric_rendering<KK>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd,  \
                        comp_rgb, distance, acc, weights)
     switch (K) {
-        // the K buckets EVERY per-ray kernel uses (1, 2, 4, 8 samples per lane): a ray's sums associate by K, so one set of buckets lets
-        // the fused launches (k_composite_resample, k_composite_train) reproduce the per-stage kernels bit for bit at every N <= 512
+        // the K buckets EVERY per-ray kernel uses (1, 2, 4, 8, 16 samples per lane): a ray's sums associate by K, so one set of buckets lets
+        // the fused launches (k_composite_resample, k_composite_train) reproduce the per-stage kernels bit for bit at every N <= 1024
         case 1: MIP_VR(1); break;
         case 2: MIP_VR(2); break;
         case 3: case 4: MIP_VR(4); break;
         case 5: case 6: case 7: case 8: MIP_VR(8); break;
+        case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: MIP_VR(16); break;
         default: return hipErrorInvalidValue;
     }
 #undef MIP_VR
@@ -364,6 +365,7 @@ hipError_t launch_piecewise_constant_pdf(int64_t B, int N, const float* bins, co
         case 2: MIP_PDF(2); break;
         case 3: case 4: MIP_PDF(4); break;
         case 5: case 6: case 7: case 8: MIP_PDF(8); break;
+        case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: MIP_PDF(16); break;
         default: return hipErrorInvalidValue;
     }
 #undef MIP_PDF
@@ -389,6 +391,7 @@ hipError_t launch_composite_resample(int64_t B, int N, const float* rgb_sigma, c
         case 2: MIP_CR(2); break;
         case 3: case 4: MIP_CR(4); break;
         case 5: case 6: case 7: case 8: MIP_CR(8); break;
+        case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: MIP_CR(16); break;
         default: return hipErrorInvalidValue;
     }
 #undef MIP_CR

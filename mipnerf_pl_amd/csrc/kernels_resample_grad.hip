@@ -94,18 +94,19 @@ k_cast_ipe_bwd(int64_t B, int N, int min_deg, int ndeg, int disable_integration,
 // One wavefront per ray; mirrors k_piecewise_constant_pdf<K, BLUR = true> (kernels_ray.hip) up to the CDF, then walks the
 // reference's autograd backwards: t'_j = b0 + (u_j - c0)/(c1 - c0) (b1 - b0) -> cdf -> cumsum -> pdf = v / sum v -> v = blur + pad ->
 // blur = (max(w_{i-1}, w_i) + max(w_i, w_{i+1})) / 2 with torch.maximum's tie rule (half each).
-constexpr int kMaxBins = 512;
+constexpr int kMaxBins = 1024;     // N <= 1024 (MIPNERF_MAX_SAMPLES); LDS rows: 512 entries for K <= 8, 1024 for the K = 16 bucket
+template <int K> struct GradRow { static constexpr int kBins = K <= 8 ? 512 : kMaxBins; };
 template <int K>
 __global__ void __launch_bounds__(64)
 k_resample_bwd(int64_t B, int N, const float* __restrict__ bins, const float* __restrict__ weights,
                const float* __restrict__ u_rand, float padding, float u_step, float u_jitter,
                const float* __restrict__ d_t_new, float* __restrict__ d_weights) {
-    __shared__ float s_w[kMaxBins + 2];
-    __shared__ float s_cdf[kMaxBins + 2];
-    __shared__ float s_bins[kMaxBins + 2];
-    __shared__ float s_g0[kMaxBins + 2];     // gradient w.r.t. cdf[i] from the draws whose lower entry is i
-    __shared__ float s_g1[kMaxBins + 2];     // ... w.r.t. cdf[i + 1] from the same draws
-    __shared__ float s_dv[kMaxBins + 2];
+    __shared__ float s_w[GradRow<K>::kBins + 2];
+    __shared__ float s_cdf[GradRow<K>::kBins + 2];
+    __shared__ float s_bins[GradRow<K>::kBins + 2];
+    __shared__ float s_g0[GradRow<K>::kBins + 2];     // gradient w.r.t. cdf[i] from the draws whose lower entry is i
+    __shared__ float s_g1[GradRow<K>::kBins + 2];     // ... w.r.t. cdf[i + 1] from the same draws
+    __shared__ float s_dv[GradRow<K>::kBins + 2];
     const int lane = threadIdx.x;
     const int64_t b = blockIdx.x;
     const float* wb = weights + b * (int64_t)N;
@@ -280,6 +281,7 @@ hipError_t launch_resample_bwd(int64_t B, int N, const float* bins, const float*
         case 2: MIP_RB(2); break;
         case 3: case 4: MIP_RB(4); break;
         case 5: case 6: case 7: case 8: MIP_RB(8); break;
+        case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: MIP_RB(16); break;
         default: return hipErrorInvalidValue;
     }
 #undef MIP_RB

@@ -198,9 +198,9 @@ k_composite_train(int64_t B, int N, const float4* __restrict__ rgb_sigma, const 
                   int white_bkgd, float* __restrict__ comp_rgb, float* __restrict__ distance, float* __restrict__ acc_out,
                   float* __restrict__ weights, float* __restrict__ ray_loss, float g_const, float* __restrict__ d_w,
                   const float* __restrict__ u_rand, float padding, float u_step, float u_jitter, float* __restrict__ t_new) {
-    __shared__ float s_w[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? kPdfMaxBins + 2 : 1];
-    __shared__ float s_cdf[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? kPdfMaxBins + 2 : 1];
-    __shared__ float s_bins[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? kPdfMaxBins + 2 : 1];
+    __shared__ float s_w[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? PdfRow<K>::kBins + 2 : 1];
+    __shared__ float s_cdf[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? PdfRow<K>::kBins + 2 : 1];
+    __shared__ float s_bins[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? PdfRow<K>::kBins + 2 : 1];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int64_t b = (int64_t)blockIdx.x * kRaysPerBlock + wv;
@@ -247,11 +247,12 @@ hipError_t launch_composite_train(int64_t B, int N, const float* rgb_sigma, cons
         else hipLaunchKernelGGL((k_composite_train<KK, false>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd, comp_rgb, distance, acc, \
                                 weights, ray_loss, g_const, d_w, u_rand, padding, u_step, u_jitter, t_new);                               \
     } while (0)
-    switch (K) {      // the K buckets every stand-alone per-ray kernel uses (1, 2, 4, 8), so the fused route gives the same bits at every N <= 512
+    switch (K) {      // the K buckets every stand-alone per-ray kernel uses (1, 2, 4, 8, 16), so the fused route gives the same bits at every N <= 1024
         case 1: MIP_CT(1); break;
         case 2: MIP_CT(2); break;
         case 3: case 4: MIP_CT(4); break;
         case 5: case 6: case 7: case 8: MIP_CT(8); break;
+        case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: MIP_CT(16); break;
         default: return hipErrorInvalidValue;
     }
 #undef MIP_CT
@@ -278,6 +279,7 @@ hipError_t launch_volumetric_rendering_bwd(int64_t B, int N, const float* rgb_si
         case 2: MIP_VB(2); break;
         case 3: case 4: MIP_VB(4); break;
         case 5: case 6: case 7: case 8: MIP_VB(8); break;
+        case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: MIP_VB(16); break;
         default: return hipErrorInvalidValue;
     }
 #undef MIP_VB
@@ -294,6 +296,7 @@ hipError_t launch_distloss(int64_t B, int N, const float* weights, const float* 
         case 2: MIP_DL(2); break;
         case 3: case 4: MIP_DL(4); break;
         case 5: case 6: case 7: case 8: MIP_DL(8); break;
+        case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: MIP_DL(16); break;
         default: return hipErrorInvalidValue;
     }
 #undef MIP_DL

@@ -183,8 +183,11 @@ __device__ __forceinline__ void composite_ray(bool active, int lane, int N, cons
 //   BLUR = true : weights are blur-pooled and `padding` added first (resample path)
 //   BLUR = false: weights used as given
 // ------------------------------------------------------------------------------------------
-constexpr int kPdfMaxBins = 512;      // N <= 512
+constexpr int kPdfMaxBins = 1024;     // N <= 1024 = 64 lanes x 16 samples (MIPNERF_MAX_SAMPLES)
 constexpr int kRaysPerBlock = 4;
+// LDS row length of a kernel instantiated for K samples per lane: the K <= 8 buckets keep their 512-entry rows (24 KiB per block: six blocks per CU);
+// only the K = 16 bucket (512 < N <= 1024) pays for 1024-entry rows
+template <int K> struct PdfRow { static constexpr int kBins = K <= 8 ? 512 : kPdfMaxBins; };
 
 // s_w / s_bins hold the ray's weights [N] and bins [N+1] (staged by the caller, block barrier done); every wave of the block
 // must call this (it contains block barriers); out_row = nullptr: no stores (a wave shadowing the last ray)

@@ -328,10 +328,10 @@ def test_constructor_scalars_forward(G, name, precision):
                 assert e <= bound[k.split("_", 1)[1]], f"{name} {precision} {k}: {e}"
 
 
-@pytest.mark.parametrize("B,N", [(1, 1), (1, 2), (2, 3), (3, 5), (7, 63), (5, 65), (2, 257), (1, 512), (129, 7)])
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 2), (2, 3), (3, 5), (7, 63), (5, 65), (2, 257), (1, 512), (129, 7), (2, 513), (1, 1024)])
 @pytest.mark.parametrize("randomized", [False, True])
 def test_extreme_shapes_vs_oracle(G, B, N, randomized):
-    """Sample counts from 1 to 512 (below / across / above a wavefront, odd, not a multiple of 4) and single-ray batches: the
+    """Sample counts from 1 to 1024 = MIPNERF_MAX_SAMPLES (below / across / above a wavefront, odd, not a multiple of 4) and single-ray batches: the
     whole forward in fp32 mode against the oracle with the randomized draws injected, bf16 against its usual bounds."""
     params = orc.make_params(seed=21, density_gain=30.0)
     rays = orc.synthetic_rays(B, seed=100 + B + N, multiscale=True)
@@ -378,7 +378,7 @@ def test_whole_frame_in_one_call_equals_chunks(G, N):
     assert bool(torch.isfinite(full[1][0]).all())
 
 
-@pytest.mark.parametrize("N", [32, 64, 100, 128, 160, 192, 256, 300, 512])     # round 5: every K bucket (1, 2, 4, 8 samples per lane)
+@pytest.mark.parametrize("N", [32, 64, 100, 128, 160, 192, 256, 300, 512, 640, 1024])     # round 5: every K bucket (1, 2, 4, 8, 16 samples per lane)
 @pytest.mark.parametrize("randomized", [False, True])
 def test_fused_small_kernels_equal_per_stage_kernels(G, N, randomized):
     """Round 3: mipnerf_forward runs pos_enc + the coarse fence posts as one launch (k_ray_prologue) and the coarse level's

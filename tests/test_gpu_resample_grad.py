@@ -107,7 +107,7 @@ def sorted_t(B, N, seed):
 
 
 # ---- pieces ----------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,N", [(5, 7), (3, 64), (4, 130), (2, 257)])
+@pytest.mark.parametrize("B,N", [(5, 7), (3, 64), (4, 130), (2, 257), (2, 600), (1, 1024)])       # 600 / 1024: the K = 16 bucket (round 5)
 def test_distloss_and_compositing_gradient_wrt_t(B, N):
     from mipnerf_pl_amd.autograd import distloss, render_from_raw
     g = torch.Generator(device=DEV).manual_seed(B * 10 + N)
@@ -155,7 +155,7 @@ def test_cast_ipe_backward(B, N, noint):
 
 
 @pytest.mark.parametrize("B,N,randomized,padding", [(7, 9, False, 0.01), (5, 64, True, 0.01), (4, 128, False, 0.01),
-                                                     (3, 200, True, 0.05), (3, 16, False, 0.0)])
+                                                     (3, 200, True, 0.05), (3, 16, False, 0.0), (2, 800, True, 0.01)])
 def test_resample_backward(B, N, randomized, padding):
     from mipnerf_pl_amd.autograd import _ResampleT
     g = torch.Generator(device=DEV).manual_seed(N)

@@ -154,7 +154,7 @@ def test_mlp_bf16(G, stage):
     assert e_f32_r <= 2e-2 and e_f32_d <= 0.4
 
 
-@pytest.mark.parametrize("N", [64, 100, 128, 256, 300])
+@pytest.mark.parametrize("N", [64, 100, 128, 256, 300, 513, 700, 1024])       # 513+: the K = 16 bucket (round 5: N <= 1024)
 @pytest.mark.parametrize("white", [True, False])
 def test_volumetric_rendering(G, N, white):
     from mipnerf_pl_amd import ops
@@ -178,7 +178,7 @@ def test_volumetric_rendering(G, N, white):
     assert abs(float(out[3][1, N // 2]) - 1.0) < 1e-6
 
 
-@pytest.mark.parametrize("N", [64, 100, 128, 256])
+@pytest.mark.parametrize("N", [64, 100, 128, 256, 513, 1024])
 @pytest.mark.parametrize("randomized", [False, True])
 def test_resample_along_rays(G, N, randomized):
     from mipnerf_pl_amd import ops

@@ -519,7 +519,7 @@ def test_fp32_native_mlp_backward_matches_reference_golden(G):
     G.record("fp32_native_mlp_bwd_vs_reference_golden", worst=worst)
 
 
-@pytest.mark.parametrize("B,N,white", [(37, 100, False), (300, 32, True), (1, 1, True), (2, 3, False), (5, 65, True), (1, 512, False)])
+@pytest.mark.parametrize("B,N,white", [(37, 100, False), (300, 32, True), (1, 1, True), (2, 3, False), (5, 65, True), (1, 512, False), (2, 1000, True)])
 def test_native_train_step_ragged_shapes_randomized(G, B, N, white):
     """mipnerf_train_step vs the autograd path on ragged sizes (rays not a multiple of the 256-sample tile, N not a
     multiple of 32) with the SAME stratified / resampling draws injected into both."""
@@ -721,7 +721,7 @@ def test_training_step_other_boundary_settings_vs_reference(G):
 
 
 @pytest.mark.parametrize("B,N,randomized", [(37, 32, True), (50, 64, False), (21, 100, True), (64, 128, True), (11, 160, True), (9, 256, False), (5, 300, True),
-                                            (3, 512, False)])      # round 5: 160 / 300 / 512 run FUSED too (K buckets 4 and 8)
+                                            (3, 512, False), (2, 700, True)])      # round 5: 160 / 300 / 512 / 700 run FUSED too (K buckets 4, 8, 16)
 def test_native_train_step_fused_tail_equals_per_stage_kernels(G, B, N, randomized):
     """Round 3: mipnerf_train_step runs pos_enc + the coarse fence posts as one launch and, per level, compositing + distloss
     (+ the next level's fence posts) as one launch (k_composite_train) instead of three; option 4 = 0 restores one launch per
