@@ -791,6 +791,32 @@ def run_train_unbounded(args, e):
         del system, opt
         torch.cuda.empty_cache()
     out["speedup_bf16_over_fp32"] = round(out["fp32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 2)
+    # round 5: the same step as ONE captured hipGraph (mipnerf_train_step's unbounded branch + device-side Adam / MipLRDecay + weight re-pack)
+    from mipnerf_pl_amd.train_graph import GraphedTrainStep
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({"nerf.num_samples": N, "nerf.unbounded": True})
+    system = MipNeRFSystem(hp, precision="bf16")
+    system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    system = system.to(e.dev)
+    system.fused_adam = True
+    (opt,), (sch,) = system.configure_optimizers()
+    g = GraphedTrainStep(system, opt, B, e.dev, use_graph=True)
+    for dst, src in zip(g.rays, R):
+        dst.copy_(src)
+    g.gt.copy_(gt)
+    g()
+    g()
+    steps = 10
+    dt, sc = timed(e, g, 0, steps)
+    ms = dt / steps * 1e3
+    tf = out["flop_per_sample"] * B * N * 2 / (ms * 1e-3) / 1e12
+    out["bf16_graph"] = {"ms_per_step": round(ms, 3), "steps": steps, "value": round(B * N * 2 * e.world / (ms * 1e-3), 1), "achieved_tflops": round(tf, 1),
+                         "frac_of_peak": round(tf / PEAK_TFLOPS["bf16"], 4), "loss_finite": bool(torch.isfinite(sc[0])), "hip_graph": g._graphs is not None,
+                         "hip_graph_capture_error": g.capture_error,
+                         "workload": "the same step through mipnerf_train_step (one call) + device-side Adam, one captured hipGraph"}
+    out["speedup_bf16_graph_over_fp32"] = round(out["fp32"]["ms_per_step"] / ms, 2)
+    del system, opt, g
+    torch.cuda.empty_cache()
     return out
 
 

@@ -1221,8 +1221,12 @@ static int mlp_backward_f32_impl(mipnerf_ctx* c, int64_t M, int32_t N, const flo
 // ---- the whole training step of the hot path in one call ---------------------------------------------------------
 // MipNeRFSystem.training_step (nerf_system.py:95-111) = MipNerf.forward(randomized) + loss, followed by what
 // loss.backward() does to the 24 MLP parameters -- native kernels only, no autograd graph, graph-capturable.
+// the one-call step covers the bounded model's generated shapes and (round 5) the unbounded-scene model's two-kernel bf16 form
+static inline bool has_train_step(const mipnerf_ctx* c) {
+    return has_bf16_train(c->P) || (c->cfg.unbounded && has_bf16_train_pre(c->P));
+}
 size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
-    if (!c || B < 1 || !has_bf16_train(c->P)) return 0;
+    if (!c || B < 1 || !has_train_step(c)) return 0;
     const size_t N = c->cfg.num_samples, M = (size_t)B * N, L = c->cfg.num_levels;
     size_t act, masks, delta, partials;
     if (mipnerf_mlp_train_sizes(c, (int64_t)M, &act, &masks, &delta, &partials)) return 0;
@@ -1230,7 +1234,8 @@ size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* c, int64_t B) {
                        align256(M * c->P->xyz_dim * 2) + 2 * align256(M * 16) +                                    // enc, rgb_sigma, raw
                        align256(masks) + align256(B * 4) + align256(B * N * 4) + align256(B * 3 * 4);   // masks, ray_loss, d_w, g_rgb
     // act and delta: one contiguous run of wave tiles over ALL levels (one weight-gradient launch over both levels)
-    return 256 + L * per_level + align256(B * 32 * 2) + align256(L * act) + align256(L * delta) + align256(partials) + align256(M * 16) + 256;
+    if (c->cfg.unbounded) per_level += align256(B * (N + 1) * 4) + 256;      // inverse-depth fence posts; every level's act region starts aligned
+    return 256 + L * per_level + align256(B * 32 * 2) + align256(L * align256(act)) + align256(L * delta) + align256(partials) + align256(M * 16) + 256;
 }
 
 int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, const float* gt_rgb, const float* t_rand,
@@ -1239,9 +1244,8 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
                        int32_t accumulate, float* out_scalars, const mipnerf_level_out* out, void* stream) {
     if (!c || !rays || !gt_rgb || !workspace || !grad_flat || !out_scalars || B < 1)
         return fail(MIPNERF_E_INVALID, "train_step: bad argument");
-    if (!has_bf16_train(c->P))
-        return fail(MIPNERF_E_UNSUPPORTED, "train_step: the one-call step exists for the bounded model's generated shapes; this variant trains "
-                                           "through the per-stage entry points (mipnerf_mlp_forward_train / mipnerf_mlp_backward) or in fp32");
+    if (!has_train_step(c))
+        return fail(MIPNERF_E_UNSUPPORTED, "train_step: no bf16 training kernels for this variant; it trains in fp32 precision");
     if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->radii || !rays->near || !rays->far || !rays->lossmult)
         return fail(MIPNERF_E_INVALID, "train_step: a Rays field is null");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "train_step: mipnerf_set_params has not been called");
@@ -1256,9 +1260,11 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     if (rc) return rc;
     TrainWs ws;
     ws.base = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-    struct Lvl { float *t, *w, *rgb, *dist, *acc, *rgb_sigma, *raw, *ray_loss, *d_w, *g_rgb; void *enc, *act, *masks; } lv[2];
+    const bool unb = cfg.unbounded != 0;       // inverse-depth fence posts, contracted off-axis IPE, the two-kernel MLP form (mipnerf_forward's unbounded branch)
+    struct Lvl { float *t, *t_inv, *w, *rgb, *dist, *acc, *rgb_sigma, *raw, *ray_loss, *d_w, *g_rgb; void *enc, *act, *masks; } lv[2];
     for (int l = 0; l < L; ++l) {
         lv[l].t = ws.take<float>(B * (N + 1) * 4); lv[l].w = ws.take<float>(B * N * 4); lv[l].rgb = ws.take<float>(B * 3 * 4);
+        lv[l].t_inv = unb ? ws.take<float>(B * (N + 1) * 4) : nullptr;
         lv[l].dist = ws.take<float>(B * 4); lv[l].acc = ws.take<float>(B * 4);
         lv[l].enc = ws.take<char>(M * c->P->xyz_dim * 2);
         lv[l].rgb_sigma = ws.take<float>(M * 16); lv[l].raw = ws.take<float>(M * 16);
@@ -1268,9 +1274,12 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     void* viewenc = ws.take<char>(B * 32 * 2);
     // T-blocks of the activations and of the deltas: level l owns wave tiles [l * n_wt, (l + 1) * n_wt) of one contiguous run,
     // so that ONE weight-gradient launch (+ one reduction) covers every level (padding tiles carry delta = 0)
-    char* act_all = ws.take<char>((size_t)L * act_b);
+    // (two-kernel form: a level's region also holds the encoding record and k_pre_gemm's two outputs behind its T-blocks, and every level
+    // gets its own weight-gradient launch -- the kernel reads ONE encoding per launch)
+    const size_t act_stride = unb ? align256(act_b) : act_b;
+    char* act_all = ws.take<char>((size_t)L * act_stride);
     char* delta_all = ws.take<char>((size_t)L * delta_b);
-    for (int l = 0; l < L; ++l) lv[l].act = act_all + (size_t)l * act_b;
+    for (int l = 0; l < L; ++l) lv[l].act = act_all + (size_t)l * act_stride;
     float* partials = ws.take<float>(part_b);
     float* d_raw = ws.take<float>(M * 16);
     const int disparity = (cfg.disparity || (flags & MIPNERF_FLAG_DISPARITY)) ? 1 : 0;
@@ -1279,7 +1288,7 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     // option 4 (fuse_small): pos_enc + coarse fence posts in one launch; per level compositing + distloss (+ the next level's
     // fence posts) in one launch instead of three -- same per-ray device functions, same bits
     const bool fuse_tail = c->fuse_small != 0;        // every N <= MIPNERF_MAX_SAMPLES (round 5: one set of K buckets in all per-ray kernels)
-    if (c->fuse_small) {
+    if (c->fuse_small && !unb) {
         HIP_TRY(mip::launch_ray_prologue(B, cfg.deg_view, rays->viewdirs, viewenc, 32, true, N, rays->near, rays->far, t_rand, disparity,
                                          lv[0].t, S(stream)));
     } else if ((rc = mipnerf_pos_enc(B, cfg.deg_view, rays->viewdirs, viewenc, 32, MIPNERF_PREC_BF16, stream))) {
@@ -1287,12 +1296,26 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
     }
     for (int l = 0; l < L; ++l) {
         const float* dnoise = density_randn ? density_randn + (size_t)l * M : nullptr;      // this level's draws (mip_nerf.py:232-233)
-        if (l == 0) {
+        if (unb) {
+            // the fine level inverts the coarse weights' PDF over the INVERSE-DEPTH fence posts, then t = 1 / t_inv (as mipnerf_forward)
+            if (l == 0) {
+                HIP_TRY(mip::launch_sample_along_rays_360(B, N, rays->near, rays->far, t_rand, lv[0].t_inv, lv[0].t, S(stream)));
+            } else {
+                if (!fuse_tail && (rc = mipnerf_resample_along_rays(B, N, lv[l - 1].t_inv, lv[l - 1].w, u_rand, cfg.resample_padding,
+                                                                    lv[l].t_inv, stream))) return rc;
+                HIP_TRY(mip::launch_reciprocal((int64_t)B * (N + 1), lv[l].t_inv, lv[l].t, S(stream)));
+            }
+        } else if (l == 0) {
             if (!c->fuse_small && (rc = mipnerf_sample_along_rays(B, N, rays->near, rays->far, t_rand, disparity, lv[0].t, stream))) return rc;
         } else if (!fuse_tail) {
             if ((rc = mipnerf_resample_along_rays(B, N, lv[l - 1].t, lv[l - 1].w, u_rand, cfg.resample_padding, lv[l].t, stream))) return rc;
         }
-        if (c->fused_ipe && max_deg_span_is_16(cfg)) {      // encoding computed inside the forward-with-save kernel
+        if (unb) {      // row-major bf16 rows of the 672-wide encoding: k_pre_gemm reads them, and so does this level's weight-gradient launch
+            HIP_TRY(mip::launch_cast_ipe_360(B, N, cfg.min_deg_point, cfg.max_deg_point, 1, lv[l].t, rays->origins, rays->directions, rays->radii,
+                                             lv[l].enc, true, nullptr, nullptr, S(stream), false));
+            if ((rc = mlp_forward_train_noise(c, (int64_t)M, N, lv[l].enc, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act, lv[l].masks, dnoise,
+                                              stream))) return rc;
+        } else if (c->fused_ipe && max_deg_span_is_16(cfg)) {      // encoding computed inside the forward-with-save kernel
             const mip::RayInputs ri = {lv[l].t, rays->origins, rays->directions, rays->radii, cfg.min_deg_point,
                                        cfg.disable_integration};
             HIP_TRY(launch_trainfwd_variant(c, nullptr, viewenc, lv[l].rgb_sigma, lv[l].raw, lv[l].act, lv[l].masks, (int64_t)M, N, &ri,
@@ -1308,7 +1331,8 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
         if (fuse_tail) {
             HIP_TRY(mip::launch_composite_train(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].rgb, lv[l].dist, lv[l].acc,
                                                 lv[l].w, lv[l].ray_loss, k * distloss_mult / (float)B, lv[l].d_w, u_rand,
-                                                cfg.resample_padding, l + 1 < L ? lv[l + 1].t : nullptr, S(stream)));
+                                                cfg.resample_padding, l + 1 < L ? (unb ? lv[l + 1].t_inv : lv[l + 1].t) : nullptr, S(stream),
+                                                unb ? lv[l].t_inv : nullptr));
             continue;
         }
         if ((rc = mipnerf_volumetric_rendering(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].rgb, lv[l].dist,
@@ -1326,10 +1350,12 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
         if ((rc = mipnerf_volumetric_rendering_bwd(B, N, lv[l].rgb_sigma, lv[l].t, rays->directions, white, lv[l].g_rgb, nullptr,
                                                    nullptr, lv[l].d_w, cfg.rgb_padding, d_raw, stream))) return rc;
         if ((rc = mipnerf_mlp_dgrad(c, (int64_t)M, d_raw, lv[l].masks, delta_all + (size_t)l * delta_b, stream))) return rc;
+        if (unb && (rc = wgrad_tiles(c, (int64_t)(((M + 255) / 256) * 8), lv[l].act, delta_all + (size_t)l * delta_b, partials, grad_flat,
+                                     (accumulate || l < L - 1) ? 1 : 0, stream))) return rc;
     }
     // one weight-gradient pass over the wave tiles of all levels (the sum over levels is part of the sample contraction)
-    if ((rc = wgrad_tiles(c, (int64_t)L * (int64_t)(((M + 255) / 256) * 8), act_all, delta_all, partials, grad_flat, accumulate ? 1 : 0,
-                          stream))) return rc;
+    if (!unb && (rc = wgrad_tiles(c, (int64_t)L * (int64_t)(((M + 255) / 256) * 8), act_all, delta_all, partials, grad_flat, accumulate ? 1 : 0,
+                                  stream))) return rc;
     if (out)      // optional copies of what MipNerf.forward returns (async device-to-device)
         for (int l = 0; l < L; ++l) {
             const mipnerf_level_out& o = out[l];

@@ -28,10 +28,11 @@ hipError_t launch_integrated_pos_enc(int64_t M, int min_deg, int max_deg, const 
 hipError_t launch_pos_enc(int64_t B, int deg, const float* viewdirs, void* out, int ld, bool bf16, hipStream_t st);
 hipError_t launch_composite_train(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs, int white_bkgd,
                                   float* comp_rgb, float* distance, float* acc, float* weights, float* ray_loss, float g_const,
-                                  float* d_w, const float* u_rand, float padding, float* t_new, hipStream_t st);   // hipErrorNotSupported: K not in {1,2,4}
+                                  float* d_w, const float* u_rand, float padding, float* t_new, hipStream_t st,
+                                  const float* bins = nullptr);   // bins: what the sampler inverts over (nullptr = t; unbounded scenes: the inverse depths)
 hipError_t launch_composite_resample(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs, int white_bkgd,
                                      float* comp_rgb, float* distance, float* acc, float* weights, const float* bins,
-                                     const float* u_rand, float padding, float* t_new, hipStream_t st);   // hipErrorNotSupported: K = ceil(N/64) not in {1,2,4}
+                                     const float* u_rand, float padding, float* t_new, hipStream_t st);   // hipErrorInvalidValue: N > 1024
 hipError_t launch_ray_prologue(int64_t B, int deg, const float* viewdirs, void* venc, int ld, bool venc_bf16, int N, const float* nearp,
                                const float* farp, const float* t_rand, int disparity, float* t_out, hipStream_t st);
 hipError_t launch_volumetric_rendering(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs,

@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(64 * kRaysPerBlock)
 k_composite_train(int64_t B, int N, const float4* __restrict__ rgb_sigma, const float* __restrict__ t, const float* __restrict__ dirs,
                   int white_bkgd, float* __restrict__ comp_rgb, float* __restrict__ distance, float* __restrict__ acc_out,
                   float* __restrict__ weights, float* __restrict__ ray_loss, float g_const, float* __restrict__ d_w,
-                  const float* __restrict__ u_rand, float padding, float u_step, float u_jitter, float* __restrict__ t_new) {
+                  const float* __restrict__ u_rand, float padding, float u_step, float u_jitter, float* __restrict__ t_new,
+                  const float* __restrict__ bins) {
     __shared__ float s_w[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? PdfRow<K>::kBins + 2 : 1];
     __shared__ float s_cdf[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? PdfRow<K>::kBins + 2 : 1];
     __shared__ float s_bins[RESAMPLE ? kRaysPerBlock : 1][RESAMPLE ? PdfRow<K>::kBins + 2 : 1];
@@ -219,7 +220,9 @@ k_composite_train(int64_t B, int N, const float4* __restrict__ rgb_sigma, const 
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (i0 + k < N) s_w[wv][i0 + k] = w[k];
-        for (int j = lane; j <= N; j += 64) s_bins[wv][j] = tb[j];
+        // the sampler's bins: this level's fence posts, or (unbounded scenes) their inverse depths
+        const float* binb = bins ? bins + bb * (int64_t)(N + 1) : tb;
+        for (int j = lane; j <= N; j += 64) s_bins[wv][j] = binb[j];
         __syncthreads();
         const int n_draws = N + 1;
         pdf_ray<K, true>(lane, N, s_w[wv], s_cdf[wv], s_bins[wv], n_draws, u_rand ? u_rand + bb * (int64_t)n_draws : nullptr, padding, u_step,
@@ -231,7 +234,7 @@ static inline unsigned gridf(int64_t n, int block) { return (unsigned)((n + bloc
 
 hipError_t launch_composite_train(int64_t B, int N, const float* rgb_sigma, const float* t, const float* dirs, int white_bkgd,
                                   float* comp_rgb, float* distance, float* acc, float* weights, float* ray_loss, float g_const,
-                                  float* d_w, const float* u_rand, float padding, float* t_new, hipStream_t st) {
+                                  float* d_w, const float* u_rand, float padding, float* t_new, hipStream_t st, const float* bins) {
     if (N > kPdfMaxBins || N < 1) return hipErrorInvalidValue;
     const dim3 grid(gridf(B, kRaysPerBlock)), block(64 * kRaysPerBlock);
     const float4* c = reinterpret_cast<const float4*>(rgb_sigma);
@@ -243,9 +246,9 @@ hipError_t launch_composite_train(int64_t B, int N, const float* rgb_sigma, cons
 #define MIP_CT(KK)                                                                                                                   \
     do {                                                                                                                             \
         if (t_new) hipLaunchKernelGGL((k_composite_train<KK, true>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd, comp_rgb, distance, \
-                                      acc, weights, ray_loss, g_const, d_w, u_rand, padding, u_step, u_jitter, t_new);                    \
+                                      acc, weights, ray_loss, g_const, d_w, u_rand, padding, u_step, u_jitter, t_new, bins);              \
         else hipLaunchKernelGGL((k_composite_train<KK, false>), grid, block, 0, st, B, N, c, t, dirs, white_bkgd, comp_rgb, distance, acc, \
-                                weights, ray_loss, g_const, d_w, u_rand, padding, u_step, u_jitter, t_new);                               \
+                                weights, ray_loss, g_const, d_w, u_rand, padding, u_step, u_jitter, t_new, bins);                         \
     } while (0)
     switch (K) {      // the K buckets every stand-alone per-ray kernel uses (1, 2, 4, 8, 16), so the fused route gives the same bits at every N <= 1024
         case 1: MIP_CT(1); break;

@@ -484,7 +484,7 @@ class MipNerf(torch.nn.Module):
             if not stop_resample_grad:
                 raise NotImplementedError("unbounded=True implements the shipped stop-gradient resampler")
             # fp32 unless asked otherwise.  precision='bf16': the 672-wide encoding runs as k_pre_gemm + a trunk kernel (csrc/gen_pre_gemm.py),
-            # in inference and (round 5) under autograd; the one-call native step (train_step_native) stays the bounded model's
+            # in inference and (round 5) in training: under autograd and in the one-call native step (train_step_native)
             precision = precision or os.environ.get("MIPNERF_PRECISION", "fp32")
         mlp_view_dim = deg_view * 3 * 2
         mlp_view_dim = mlp_view_dim + 3 if append_identity else mlp_view_dim
@@ -545,7 +545,7 @@ class MipNerf(torch.nn.Module):
                 return self._forward_empty(o.device)
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 # (round 5: MipNerf(unbounded=True, precision='bf16') trains through this route too -- k_pre_gemm + a trunk forward-with-save,
-                # the standard dgrad, weight-gradient jobs over the row-major encoding; the one-call train_step_native stays bounded-only)
+                # the standard dgrad, weight-gradient jobs over the row-major encoding -- and through the one-call train_step_native)
                 from .autograd import mipnerf_forward_train
                 return mipnerf_forward_train(self, rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
             return self._forward_native(rays, randomized, white_bkgd, t_rand, u_rand, density_randn)
@@ -578,9 +578,6 @@ class MipNerf(torch.nn.Module):
         distloss_c, distloss_f, psnr_fine, outputs or None).  bf16 precision only."""
         if self.precision != L.PREC_BF16:
             raise NotImplementedError("train_step_native is the bf16 path; fp32 parity mode trains through autograd")
-        if self.unbounded:
-            raise NotImplementedError("the one-call native step implements the bounded model; MipNerf(unbounded=True) trains through autograd "
-                                      "(`loss.backward()` on forward's outputs), in bf16 or fp32 precision")
         if not self.stop_resample_grad:
             raise NotImplementedError("stop_resample_grad=False trains through autograd in fp32 precision (the one-call native step "
                                       "implements the shipped stop-gradient resampler)")

@@ -142,12 +142,88 @@ def test_train_in_fp32_render_in_bf16(G):
         m32.set_precision("fp16")
 
 
-def test_one_call_native_step_is_the_bounded_model_only(G):
-    params = syn.make_params(seed=17, density_gain=40.0, xyz_dim=672)
-    m16 = _model(params, 64, "bf16")
-    rays = G.to_dev(syn.synthetic_rays(8, seed=2, unbounded=True))
+@pytest.mark.parametrize("B,N,white", [(37, 100, False), (300, 32, True), (5, 65, True), (2, 3, False), (3, 600, True)])
+def test_one_call_native_step_equals_the_autograd_route(G, B, N, white):
+    """Round 5: mipnerf_train_step for the unbounded-scene model (inverse-depth fence posts, contracted off-axis IPE rows, k_pre_gemm + trunk
+    forward-with-save, per-level weight-gradient launches over the row-major encoding) against the autograd route on the SAME kernels with
+    the same draws injected: loss and every gradient agree to summation order (ragged ray counts, N not a multiple of 32, the K = 16 bucket)."""
+    from mipnerf_pl_amd.autograd import distloss
+    params = syn.make_params(seed=B, density_gain=40.0, xyz_dim=672)
+    rays = G.to_dev(syn.synthetic_rays(B, seed=B + 1, unbounded=True))
+    gt = torch.rand(B, 3, device=DEV)
+    t_rand, u_rand = torch.rand(B, N + 1, device=DEV), torch.rand(B, N + 1, device=DEV)
+    res = {}
+    for native in (False, True):
+        model = _model(params, N, "bf16")
+        if native:
+            scal, outs = model.train_step_native(rays, gt, True, white, t_rand=t_rand, u_rand=u_rand, return_outputs=True)
+            loss = float(scal[0])
+            fine = outs[1]
+        else:
+            ret = model(rays, True, white, t_rand=t_rand, u_rand=u_rand)
+            mask = rays.lossmult
+            mse = [(mask * (r[0] - gt) ** 2).sum() / mask.sum() for r in ret]
+            dl = [distloss(r[3], r[4]) for r in ret]
+            tot = 0.1 * (mse[0] + 0.01 * dl[0]) + mse[1] + 0.01 * dl[1]
+            tot.backward()
+            loss = float(tot.detach())
+            fine = tuple(x.detach() for x in ret[1])
+        res[native] = (loss, torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone(), fine)
+    (l0, g0, f0), (l1, g1, f1) = res[False], res[True]
+    for a, b in zip(f0, f1):
+        assert G.maxdiff(a, b) <= 2e-6, G.maxdiff(a, b)      # same forward kernels on the same inputs (the activations run fused / stand-alone)
+    eg = G.maxdiff(g0, g1) / float(g0.abs().max())
+    G.record(f"unbounded native_train_step B={B} N={N}", loss_autograd=l0, loss_native=l1, grad_rel=eg)
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)) and eg <= 2e-5, (l0, l1, eg)
+    # fused tail (compositing + distloss + the next level's inverse-depth fence posts in one launch) == one launch per stage, bit for bit
+    grads = []
+    for fuse in (1, 0):
+        model = _model(params, N, "bf16")
+        model.mlp.native(torch.device(DEV)).set_option(4, fuse)
+        scal, _ = model.train_step_native(rays, gt, True, white, t_rand=t_rand, u_rand=u_rand)
+        grads.append((scal.clone(), torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    # fp32 precision has no one-call step (it trains through autograd)
     with pytest.raises(NotImplementedError):
-        m16.train_step_native(rays, torch.zeros(8, 3, device=DEV), True, True)
+        _model(params, N, "fp32").train_step_native(rays, gt, True, white)
+
+
+def test_graphed_train_step_of_the_unbounded_model(G):
+    """The unbounded model's whole optimisation step from ONE captured hipGraph (train_graph.GraphedTrainStep: draws, mipnerf_train_step,
+    device-side Adam + MipLRDecay, re-pack of the k_pre_gemm / trunk weight streams): graph == the same launches issued eagerly bit for
+    bit, and it trains."""
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    from mipnerf_pl_amd.train_graph import GraphedTrainStep
+    B, N = 192, 64
+    params = syn.make_params(seed=23, density_gain=6.0, xyz_dim=672)
+    rays = G.to_dev(syn.synthetic_rays(B, seed=9, unbounded=True))
+    gt = torch.rand(B, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(4))
+    res = {}
+    for mode in ("graph", "eager"):
+        hp = dict(DEFAULT_HPARAMS)
+        hp.update({'nerf.num_samples': N, 'nerf.unbounded': True, 'train.randomized': False, 'optimizer.lr_init': 1e-3, 'optimizer.lr_final': 1e-5,
+                   'optimizer.max_steps': 20, 'optimizer.lr_delay_steps': 4})
+        system = MipNeRFSystem(hp, precision="bf16")
+        system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+        system = system.to(DEV)
+        system.fused_adam = True
+        (opt,), (sch,) = system.configure_optimizers()
+        step = GraphedTrainStep(system, opt, B, torch.device(DEV), use_graph=(mode == "graph"))
+        for dst, src in zip(step.rays, rays):
+            dst.copy_(src)
+        step.gt.copy_(gt)
+        losses = []
+        for it in range(6):
+            losses.append(float(step()[0]))
+            sch["scheduler"].step()
+        assert step.capture_error is None
+        with torch.no_grad():
+            out = system.mip_nerf(rays, False, True)[1][0].clone()      # uses the re-packed weight streams
+        res[mode] = (losses, torch.cat([p.detach().reshape(-1) for p in system.mip_nerf.parameters()]).clone(), out)
+    assert res["graph"][0] == res["eager"][0], (res["graph"][0], res["eager"][0])
+    assert torch.equal(res["graph"][1], res["eager"][1]) and torch.equal(res["graph"][2], res["eager"][2])
+    assert res["graph"][0][-1] < res["graph"][0][0], res["graph"][0]
+    G.record("unbounded graphed_train_step", first_loss=res["graph"][0][0], last_loss=res["graph"][0][-1])
 
 
 # ---- round 5 (VERDICT r04 #1): this path against the 360 ORACLE, not against the repo's own fp32 kernels ----------------------------
