@@ -124,16 +124,18 @@ struct WgradJob {                                     // one row of mlp_train_pl
     int b_blk[8];
 };
 struct WgradEnc {                                     // the encoding the b_src = 1 jobs contract against (null / 0 when the plan has none)
-    const void* enc;                                  // bf16 [M, row_elems] row-major
+    const void* enc;                                  // bf16 [M, row_elems] row-major -- or (row_bytes == 0) the MFMA B-operand FRAGMENTS k_cast_ipe_360_tile
+                                                      // writes for k_pre_gemm: [wave tile][frag_ksteps][64 lanes][8 bf16], whole 256-sample tiles
     int64_t M;                                        // rows (samples); wave tiles reach past it, rows are clamped
-    int row_bytes;                                    // 2 * xyz_dim
+    int row_bytes;                                    // 2 * xyz_dim; 0 = fragment layout
+    int frag_ksteps;                                  // fragment layout: k-steps per wave tile (xyz_dim / 16)
 };
 int mlp_wgrad_lds_bytes();
 hipError_t launch_transpose_sq(int n, const float* in, float* out, hipStream_t st);
 hipError_t launch_mlp_wgrad(const void* HT, const void* GT, const WgradJob* jobs, const void* wg_tab, int num_wgs,
                             int64_t n_wt, int NH, int NG, float* partials, hipStream_t st, const WgradEnc* enc_record = nullptr);
 // writes the WgradEnc record behind an act buffer's T-blocks (device memory: the forward may be part of a captured graph)
-hipError_t launch_wgrad_record_enc(void* record, const void* enc, int64_t M, int row_bytes, hipStream_t st);
+hipError_t launch_wgrad_record_enc(void* record, const void* enc, int64_t M, int row_bytes, hipStream_t st, int frag_ksteps = 0);
 struct WgradPost {                                    // chain-rule step that replaces the bottleneck T-blocks (W == 0: none)
     int W, Wc, ldv;                                   // net_width, net_width_condition, in_features of the view layer
     int off_extra_w, off_extra_b, off_view_w, off_view_b;   // flat gradient offsets

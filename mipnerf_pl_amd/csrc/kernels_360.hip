@@ -260,7 +260,9 @@ hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int c
     const int L = max_deg - min_deg;
     if (frag && (!bf16 || (2 * kBasis360N * L) % 16 != 0)) return hipErrorInvalidValue;
     if (enc && !means && (kBasis360N * L) % 8 == 0) {         // only the encoding: the tiled kernel (one Gaussian per sample, vector stores)
-        const int64_t wgs = (B * (int64_t)N + kFragSamples - 1) / kFragSamples;
+        // fragments: whole 256-sample workgroup tiles of the MLP kernels (samples past the end repeat the last one: finite values that the
+        // weight-gradient kernel of the training step multiplies by zero deltas)
+        const int64_t wgs = frag ? ((B * (int64_t)N + 255) / 256) * (256 / kFragSamples) : (B * (int64_t)N + kFragSamples - 1) / kFragSamples;
         if (wgs > 0x7fffffff) return hipErrorInvalidValue;
         const dim3 g((unsigned)wgs);
         if (frag) hipLaunchKernelGGL((k_cast_ipe_360_tile<__bf16, true>), g, block, 0, st, B, N, min_deg, L, contracted, t, origins, dirs, radii, (__bf16*)enc);

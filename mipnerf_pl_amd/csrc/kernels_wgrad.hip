@@ -75,10 +75,12 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_
 // profiles/r02n_ds_read_tr_probe.txt).  Lane i of group (hi, g = n >> 4) therefore ADDRESSES the granule (feature quad 4 g + (i & 3),
 // sample 16 f + 8 r + 4 hi + (i >> 2)) for read r in {0, 1} and RECEIVES feature 16 g + i of samples 16 f + 8 r + 4 hi + 0 .. 3.
 typedef short v4s16e __attribute__((ext_vector_type(4)));
+// ROW = bytes between consecutive samples of the LDS image: 64 (row-major rows) or 16 (the fragment image, see wgrad_body).
+template <int ROW>
 __device__ __forceinline__ bf16x8 lds_frag_enc(const char* blk, unsigned enc_lane_off, int f) {
-    const char* p = blk + enc_lane_off + f * (16 * 64);
+    const char* p = blk + enc_lane_off + f * (16 * ROW);
     const v4s16e lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16e*)(size_t)(p));
-    const v4s16e hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16e*)(size_t)(p + 8 * 64));
+    const v4s16e hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16e*)(size_t)(p + 8 * ROW));
     typedef short v8s16e __attribute__((ext_vector_type(8)));
     const v8s16e v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return __builtin_bit_cast(bf16x8, v);
@@ -211,7 +213,10 @@ __device__ __forceinline__ void k_wgrad_recompute_body(char* smem, const char* _
 // shapes; exactly the code of rounds 1-4).  ENC = true (round 5, pre-GEMM plans): 32-feature column blocks of the row-major encoding.
 // Two instantiations behind one workgroup-uniform branch, so the encoding path costs the standard jobs nothing (as one body with the
 // choice inside the unrolled operand loop, the standard training step ran 12 % slower: 4.73 instead of 4.20 ms).
-template <bool ENC>
+// ENC = 2 (the one-call training step of the unbounded model): the encoding arrives as the B-operand FRAGMENTS k_pre_gemm reads fastest
+// ([wave tile][k-step][lane (hi, n)][8 features]); a 32-feature block = two consecutive k-steps = 2 KiB that land lane-linear like a T-block.
+// In that LDS image the granule (feature quad q of the block, sample s) sits at (q >> 2) * 1024 + ((q >> 1) & 1) * 512 + s * 16 + (q & 1) * 8.
+template <int ENC>
 __device__ __forceinline__ void wgrad_body(char* smem, const char* __restrict__ HT, const char* __restrict__ GT, const WgradJob* jp, const int4 wg,
                                            int64_t n_wt, int NH, int NG, float* __restrict__ partials, const WgradEnc* __restrict__ Ep, int lane,
                                            int wave) {
@@ -222,11 +227,13 @@ __device__ __forceinline__ void wgrad_body(char* smem, const char* __restrict__ 
     const int nst = (int)(hi - lo);
     const int a_blk = jp->a_blk[wave], b_blk = jp->b_blk[wave];
     const bool active = wave < nA;
-    WgradEnc E = {nullptr, 1, 0};
+    WgradEnc E = {nullptr, 1, 0, 0};
     if (ENC) E = *Ep;                                       // (uniform scalar loads) the record the training forward left behind the T-blocks
     // encoding jobs: DMA source offset of this lane (sample lane >> 2 of a 16-sample half, 16-byte piece lane & 3) and its operand-read offset
     const unsigned enc_dma_piece = (unsigned)(lane & 3) * 16u;
-    const unsigned enc_lane_off = (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (4 * ((lane >> 4) & 1) + (lane & 3)) * 8);
+    const unsigned enc_lane_off =
+        ENC == 2 ? (unsigned)(((lane >> 4) & 1) * 1024 + ((lane >> 1) & 1) * 512 + (lane & 1) * 8 + (4 * (lane >> 5) + ((lane & 15) >> 2)) * 16)
+                 : (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (4 * ((lane >> 4) & 1) + (lane & 3)) * 8);
 
     f32x16 acc[9];
 #pragma unroll
@@ -244,7 +251,9 @@ __device__ __forceinline__ void wgrad_body(char* smem, const char* __restrict__ 
     auto issue = [&](int64_t wt, int stage) {
         char* st = smem + stage * kStageBytes;
         if (has_b) {
-            if (ENC) {
+            if (ENC == 2) {
+                dma_block((const char*)E.enc + (wt * E.frag_ksteps + 2 * b_blk) * 1024, st + wave * 2048, lane16);
+            } else if (ENC == 1) {
                 // rows wt * 32 + (lane >> 2) [+ 16], clamped to the last sample (their deltas are zero); the clamp makes the row per-lane,
                 // so both DMAs take a full 64-bit lane address
                 const int64_t s0 = wt * 32 + (lane >> 2), s1 = s0 + 16;
@@ -293,8 +302,10 @@ __device__ __forceinline__ void wgrad_body(char* smem, const char* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < nB) {
-                        const bf16x8 b0 = ENC ? lds_frag_enc(sb + j * 2048, enc_lane_off, 0) : lds_frag(st + j * 2048);
-                        const bf16x8 b1 = ENC ? lds_frag_enc(sb + j * 2048, enc_lane_off, 1) : lds_frag(st + j * 2048 + 1024);
+                        const bf16x8 b0 = ENC == 2 ? lds_frag_enc<16>(sb + j * 2048, enc_lane_off, 0)
+                                                   : (ENC == 1 ? lds_frag_enc<64>(sb + j * 2048, enc_lane_off, 0) : lds_frag(st + j * 2048));
+                        const bf16x8 b1 = ENC == 2 ? lds_frag_enc<16>(sb + j * 2048, enc_lane_off, 1)
+                                                   : (ENC == 1 ? lds_frag_enc<64>(sb + j * 2048, enc_lane_off, 1) : lds_frag(st + j * 2048 + 1024));
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
                     }
@@ -336,8 +347,12 @@ k_mlp_wgrad(const char* __restrict__ HT, const char* __restrict__ GT, const Wgra
         return;
     }
 #endif
-    if (jp->b_src != 0) wgrad_body<true>(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, Ep, lane, wave);      // workgroup-uniform
-    else wgrad_body<false>(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, Ep, lane, wave);
+    if (jp->b_src != 0) {                                   // workgroup-uniform
+        if (Ep->row_bytes == 0) wgrad_body<2>(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, Ep, lane, wave);
+        else wgrad_body<1>(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, Ep, lane, wave);
+    } else {
+        wgrad_body<0>(smem, HT, GT, jp, wg, n_wt, NH, NG, partials, Ep, lane, wave);
+    }
 }
 
 // grad[idx] = sum over the job's splits of the partial at `pos`, for every position that feeds a parameter
@@ -435,11 +450,11 @@ hipError_t launch_transpose_sq(int n, const float* in, float* out, hipStream_t s
 
 int mlp_wgrad_lds_bytes() { return kWgradLds; }
 
-__global__ void k_wgrad_record_enc(WgradEnc* rec, const void* enc, int64_t M, int row_bytes) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { rec->enc = enc; rec->M = M; rec->row_bytes = row_bytes; }
+__global__ void k_wgrad_record_enc(WgradEnc* rec, const void* enc, int64_t M, int row_bytes, int frag_ksteps) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { rec->enc = enc; rec->M = M; rec->row_bytes = row_bytes; rec->frag_ksteps = frag_ksteps; }
 }
-hipError_t launch_wgrad_record_enc(void* record, const void* enc, int64_t M, int row_bytes, hipStream_t st) {
-    hipLaunchKernelGGL(k_wgrad_record_enc, dim3(1), dim3(64), 0, st, (WgradEnc*)record, enc, M, row_bytes);
+hipError_t launch_wgrad_record_enc(void* record, const void* enc, int64_t M, int row_bytes, hipStream_t st, int frag_ksteps) {
+    hipLaunchKernelGGL(k_wgrad_record_enc, dim3(1), dim3(64), 0, st, (WgradEnc*)record, enc, M, row_bytes, frag_ksteps);
     return hipGetLastError();
 }
 
