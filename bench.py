@@ -755,7 +755,7 @@ def run_fp32_c4(args, e):
                        "parallelism": f"ray-split x{e.world} (no data-path collective)"}}
 
 
-def run_train_unbounded(args, e):
+def run_train_unbounded(args, e, which=("fp32", "bf16", "bf16_graph")):
     import torch
     import synthetic_inputs as syn
     from mipnerf_pl_amd import Rays
@@ -767,6 +767,8 @@ def run_train_unbounded(args, e):
     out = {"workload": f"MipNerf(unbounded=True) training step through autograd, {B} rays x ({N} + {N}) samples, randomized, torch Adam",
            "flop_per_sample": 3 * 1810432 - 2 * 2 * 672 * 256}          # forward + wgrad + dgrad (no dgrad into the encoding: 2 x 672 x 256 MACs less)
     for precision, steps in (("fp32", 3), ("bf16", 10)):
+        if precision not in which:
+            continue
         hp = dict(DEFAULT_HPARAMS)
         hp.update({"nerf.num_samples": N, "nerf.unbounded": True})
         system = MipNeRFSystem(hp, precision=precision)
@@ -790,7 +792,10 @@ def run_train_unbounded(args, e):
                           "frac_of_peak": round(tf / PEAK_TFLOPS[precision], 4), "loss_finite": bool(torch.isfinite(loss.detach()))}
         del system, opt
         torch.cuda.empty_cache()
-    out["speedup_bf16_over_fp32"] = round(out["fp32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 2)
+    if "fp32" in out and "bf16" in out:
+        out["speedup_bf16_over_fp32"] = round(out["fp32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 2)
+    if "bf16_graph" not in which:
+        return out
     # round 5: the same step as ONE captured hipGraph (mipnerf_train_step's unbounded branch + device-side Adam / MipLRDecay + weight re-pack)
     from mipnerf_pl_amd.train_graph import GraphedTrainStep
     hp = dict(DEFAULT_HPARAMS)
@@ -814,7 +819,8 @@ def run_train_unbounded(args, e):
                          "frac_of_peak": round(tf / PEAK_TFLOPS["bf16"], 4), "loss_finite": bool(torch.isfinite(sc[0])), "hip_graph": g._graphs is not None,
                          "hip_graph_capture_error": g.capture_error,
                          "workload": "the same step through mipnerf_train_step (one call) + device-side Adam, one captured hipGraph"}
-    out["speedup_bf16_graph_over_fp32"] = round(out["fp32"]["ms_per_step"] / ms, 2)
+    if "fp32" in out:
+        out["speedup_bf16_graph_over_fp32"] = round(out["fp32"]["ms_per_step"] / ms, 2)
     del system, opt, g
     torch.cuda.empty_cache()
     return out

@@ -81,7 +81,7 @@ typedef struct mipnerf_config {
                                  /* models/mip.py:106-124, 292-319, 424-447 aim at).  fp32 or bf16 (the 672-wide encoding    */
                                  /* runs as k_pre_gemm + a trunk kernel, csrc/gen_pre_gemm.py): mipnerf_forward,             */
                                  /* mipnerf_mlp_forward and the per-stage training entry points (mipnerf_mlp_forward_train / */
-                                 /* _dgrad / _backward); mipnerf_train_step is the bounded model's                           */
+                                 /* _dgrad / _backward) and, in bf16, mipnerf_train_step                                     */
 } mipnerf_config;
 
 #define MIPNERF_MAX_SAMPLES 1024
@@ -353,7 +353,9 @@ int mipnerf_adam_step_scheduled(int64_t n, float* param, const float* grad, floa
  * dm = 0.01, mse masked by rays.lossmult unless disable_multiscale_loss), backward of compositing / activations / MLP.
  * grad_flat [612,740] = d loss / d parameters in state_dict order (accumulate = 0 overwrites).  out_scalars [6] =
  * loss, mse_coarse, mse_fine, distloss_coarse, distloss_fine, psnr_fine.  `out` (may be NULL, or hold NULL fields)
- * receives copies of what MipNerf.forward returns.  No autograd graph, no allocation, one stream: graph-capturable. */
+ * receives copies of what MipNerf.forward returns.  No autograd graph, no allocation, one stream: graph-capturable.
+ * Every variant with bf16 training kernels, including (round 5) the unbounded-scene model's two-kernel form: inverse-depth
+ * fence posts, encodings as fragments, one weight-gradient launch per level; grad_flat then has that variant's numel. */
 size_t mipnerf_train_workspace_bytes(const mipnerf_ctx* ctx, int64_t num_rays);
 int mipnerf_train_step(mipnerf_ctx* ctx, int64_t num_rays, const mipnerf_rays* rays, const float* gt_rgb,
                        const float* t_rand, const float* u_rand, const float* density_randn, uint32_t flags,
