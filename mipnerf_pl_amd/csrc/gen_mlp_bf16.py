@@ -66,8 +66,8 @@ VARIANTS = [
     Arch(xyz_dim=672, feat_per_deg=42, bf16_kernels=False),
     # two view layers (mlp_net_depth_condition = 2, mip_nerf.py:62-69).  Round 5: bf16 INFERENCE kernel too -- its stream is 39 ring
     # groups + one whole group of zero padding (the ring phase must be tile-invariant: an even number of groups), which the generator
-    # handles since the trunk kernels of round 4 (an extra GROUP_BEGIN at the tile end).  Training: fp32 forward + GEMM backward
-    # (the bf16 training schedule is generated for one view layer, mlp_train_plan.py).
+    # handles since the trunk kernels of round 4 (an extra GROUP_BEGIN at the tile end).  bf16 TRAINING kernels too: the plan saves one more
+    # activation set / delta set / mask row per extra view layer (mlp_train_plan.py).
     Arch(net_depth_condition=2),
     # a 512-wide trunk with a 256-wide view layer.  Round 5: bf16 INFERENCE kernel too -- 4-wave workgroups at one wave per SIMD (waves_of below).
     # Training: fp32 forward + GEMM backward.

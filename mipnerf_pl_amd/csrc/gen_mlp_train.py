@@ -405,7 +405,8 @@ def gen_trainfwd(tp: TrainPlan, variant: int = 0) -> str:
     lds_bytes = enc_off + WAVES * enc_wave_bytes
     assert lds_bytes <= 160 * 1024
     prog = build_fwd_prog(tp)
-    assert len(prog.slots) == nreal and nchunks - nreal < GROUP
+    # padding: inside the last ring group, or exactly one whole group of zeros (two view layers: 39 groups + 1), begun by an extra GROUP_BEGIN at the tile end
+    assert len(prog.slots) == nreal and (nchunks - nreal < GROUP or (nchunks - nreal == GROUP and nreal % GROUP == 0))
     side_e, prologue_e = assign_lds_b(prog, nreal)
     side = place_sides(prog, nreal, "fwd")
     for c in range(nreal):

@@ -251,7 +251,7 @@ hipError_t launch_sample_along_rays_360(int64_t B, int N, const float* nearp, co
     return hipGetLastError();
 }
 
-// frag: bf16 only, (2 * 21 * L) % 16 == 0 -- the fragment layout of enc360_index; the kernel stores whole 64-sample workgroup tiles (two wave tiles), so the buffer must cover ceil(M / 64) * 64 rows
+// frag: bf16 only, (2 * 21 * L) % 16 == 0 -- the fragment layout of enc360_index; the kernel stores whole 256-sample tiles of the MLP kernels (64-sample workgroups, samples past the end repeat the last one), so the buffer must cover ceil(M / 256) * 256 rows
 hipError_t launch_cast_ipe_360(int64_t B, int N, int min_deg, int max_deg, int contracted, const float* t, const float* origins,
                                const float* dirs, const float* radii, void* enc, bool bf16, float* means, float* covs,
                                hipStream_t st, bool frag) {

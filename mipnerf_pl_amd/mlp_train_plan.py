@@ -128,8 +128,8 @@ class TrainPlan:
         matrices that multiply the encoding get weight-gradient jobs whose B blocks are the encoding FRAGMENTS (WJob.b_src = 1)."""
         fwd = Plan.build(arch or Arch(), pre_gemm=pre_gemm)
         a = fwd.arch
-        if a.net_depth_condition != 1:
-            raise NotImplementedError("training kernels are generated for net_depth_condition == 1")
+        if a.net_depth_condition < 1 or (a.net_depth_condition != 1 and pre_gemm):
+            raise NotImplementedError("training kernels need at least one view layer (exactly one in the two-kernel form)")
         if a.xyz_dim % TILE:
             raise NotImplementedError("training kernels need xyz_dim to be a multiple of 32")
         if max(a.net_width, a.net_width_condition) > 256:
@@ -153,8 +153,11 @@ class TrainPlan:
         for i in range(1, D + 1):
             hadd(f"x{i}", nW, DLAYOUT)
         views = bool(a.use_viewdirs)       # False: MLP.forward(x, None) -- colour head on the trunk output, no bottleneck / view layer
-        if views:
+        nV = a.net_depth_condition if views else 0     # view layers (mip_nerf.py:62-69); "hv" = the output of the LAST one (the colour head's input),
+        if views:                                      # hv0 .. hv{nV-2} the ones before it (round 5: two view layers train in bf16 too)
             hadd("view", 1, NATURAL)
+            for i in range(nV - 1):
+                hadd(f"hv{i}", nC, DLAYOUT)
             hadd("hv", nC, DLAYOUT)
         tp.NH = hid
         gid = 0
@@ -165,11 +168,13 @@ class TrainPlan:
             gid += n
         gadd("raw", 1, NATURAL)
         if views:
-            gadd("gv", nC, DLAYOUT)
+            for i in range(nV - 1, 0, -1):
+                gadd(f"gv{i}", nC, DLAYOUT)      # delta at the pre-activation of view layer i
+            gadd("gv", nC, DLAYOUT)              # ... of view layer 0 (the one that reads the bottleneck + view directions)
         for i in range(D, 0, -1):
             gadd(f"g{i}", nW, DLAYOUT)
         tp.NG = gid
-        tp.NMASK = D + (1 if views else 0)
+        tp.NMASK = D + nV                        # mask row D + i = ReLU bits of view layer i
         # ---- what the forward-with-save kernel stores per op ---------------------------------------------
         for op in fwd.ops:
             if op.name.startswith("layer"):
@@ -177,28 +182,35 @@ class TrainPlan:
                 tp.fwd_out.append((tp.h_blocks[f"x{i + 1}"][0], i))
             elif op.name == "head":
                 tp.fwd_out.append((None, None))      # bottleneck: linear, never stored (see post_process)
-            elif op.name == "view0":
-                tp.fwd_out.append((tp.h_blocks["hv"][0], D))
+            elif op.name.startswith("view"):
+                i = int(op.name[4:])
+                tp.fwd_out.append((tp.h_blocks["hv" if i == nV - 1 else f"hv{i}"][0], D + i))
             else:
                 tp.fwd_out.append((None, None))
         # ---- dgrad ops -------------------------------------------------------------------------------------
         G = {k: v[0] for k, v in tp.g_blocks.items()}
         nrgb = a.num_rgb
+        cur, other = "Y", "X"
         if views:
             tp.bops.append(BOp("dcolor", [BSeg("raw", NATURAL, 1, pid["color_layer.weight"], Wc, 0, 0, nrgb)],
-                               nC, 0, D, "Y", G["gv"]))
-            tp.bops.append(BOp("dview", [BSeg("Y", DLAYOUT, Wc // KSTEP, pid["view_layers.0.0.weight"],
-                                              W + a.view_dim, 0, 0, Wc)], nW, 0, None, "X", None))
-            tp.bops.append(BOp("dhead", [BSeg("X", DLAYOUT, W // KSTEP, pid["extra_layer.weight"], W, 0, 0, W),
+                               nC, 0, D + nV - 1, "Y", G["gv" if nV == 1 else f"gv{nV - 1}"]))
+            for i in range(nV - 1, 0, -1):       # through view layer i (Wc -> Wc): delta at the pre-activation of view layer i - 1
+                tp.bops.append(BOp(f"dview{i}", [BSeg(cur, DLAYOUT, Wc // KSTEP, pid[f"view_layers.{i}.0.weight"], Wc, 0, 0, Wc)],
+                                   nC, 0, D + i - 1, other, G["gv" if i == 1 else f"gv{i - 1}"]))
+                cur, other = other, cur
+            tp.bops.append(BOp("dview", [BSeg(cur, DLAYOUT, Wc // KSTEP, pid["view_layers.0.0.weight"],
+                                              W + a.view_dim, 0, 0, Wc)], nW, 0, None, other, None))
+            cur, other = other, cur
+            tp.bops.append(BOp("dhead", [BSeg(cur, DLAYOUT, W // KSTEP, pid["extra_layer.weight"], W, 0, 0, W),
                                          BSeg("raw", NATURAL, 1, pid["density_layer.weight"], W, -nrgb, nrgb, nrgb + 1)],
-                               nW, 0, D - 1, "Y", G[f"g{D}"]))
+                               nW, 0, D - 1, other, G[f"g{D}"]))
+            cur, other = other, cur
         else:
             # both heads read the trunk output: delta_D = (d_rgb W_color + d_density W_density) * relu'(x_D); two k-steps on the
             # same d_raw register, one per weight tensor
             tp.bops.append(BOp("dhead", [BSeg("raw", NATURAL, 1, pid["color_layer.weight"], Wc, 0, 0, nrgb),
                                          BSeg("raw", NATURAL, 1, pid["density_layer.weight"], W, -nrgb, nrgb, nrgb + 1)],
                                nW, 0, D - 1, "Y", G[f"g{D}"]))
-        cur, other = "Y", "X"
         shapes = dict(a.param_shapes())
         for i in range(D - 1, 0, -1):
             ld = shapes[f"layers.{i}.0.weight"][1]
@@ -283,6 +295,10 @@ class TrainPlan:
             vw = pid["view_layers.0.0.weight"]
             tp.jobs.append(WJob("viewd", blocks(tp.g_blocks, "gv"), blocks(H, "view"), rows_d(vw, W + a.view_dim, nC),
                                 cols("view", W, a.view_dim), None, cost=(nC + 1) / 16))
+            for i in range(1, nV):               # view layer i: delta_i x (output of view layer i - 1)
+                src = f"hv{i - 1}"
+                tp.jobs.append(WJob(f"view{i}", blocks(tp.g_blocks, f"gv{i}"), blocks(H, src), rows_d(pid[f"view_layers.{i}.0.weight"], Wc, nC),
+                                    cols(src, 0, Wc), bias_d(pid[f"view_layers.{i}.0.bias"], nC), cost=(2 * nC) / 16))
             raw_rows_color = [[(pid["color_layer.weight"], m, Wc) if m < nrgb else None for m in range(32)]]
             tp.jobs.append(WJob("color", blocks(tp.g_blocks, "raw"), blocks(H, "hv"), raw_rows_color,
                                 cols("hv", 0, Wc), None, cost=(1 + nC) / 16))

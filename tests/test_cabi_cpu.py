@@ -129,11 +129,11 @@ def test_architecture_variants_exported(lib):
         assert (cfg.net_depth, cfg.net_width, cfg.net_depth_condition, cfg.net_width_condition, cfg.skip_index,
                 bool(cfg.use_viewdirs)) == (arch.net_depth, arch.net_width, arch.net_depth_condition, arch.net_width_condition,
                                             arch.skip_index, arch.use_viewdirs)
-        # bf16 training kernels for every variant that has bf16 kernels, ONE view layer and widths <= 256 (mlp_train_plan.py; round 5: two view
-        # layers and the 512-wide trunk have a bf16 inference kernel, train in fp32)
+        # bf16 training kernels for every variant that has bf16 kernels and widths <= 256 (mlp_train_plan.py; round 5: two view layers train in
+        # bf16 too; the 512-wide trunk has a bf16 inference kernel and trains in fp32)
         # ... or the two-kernel form's training kernels (round 5: the wide-encoding variant of the unbounded-scene model)
         from mipnerf_pl_amd import mlp_pre_plan
-        assert has_train.value == int((arch.bf16_kernels and arch.net_depth_condition == 1 and arch.net_width <= 256)
+        assert has_train.value == int((arch.bf16_kernels and arch.net_width <= 256)
                                        or mlp_pre_plan.supported(arch))
         assert bool(cfg.unbounded) == (arch.feat_per_deg == 42) and (cfg.max_deg_point - cfg.min_deg_point) * arch.feat_per_deg == arch.xyz_dim
         plan = Plan.build(arch)

@@ -102,7 +102,8 @@ def test_embedded_tables_equal_python_plan(tp):
 
 VARIANT_CASES = [(1, dict(net_width=128, net_width_condition=128), (40, 37, 9, 296)),
                  (2, dict(net_width_condition=256, use_viewdirs=False), (67, 65, 8, 912)),
-                 (3, dict(net_depth=6, skip_index=3), None)]
+                 (3, dict(net_depth=6, skip_index=3), None),
+                 (5, dict(net_depth_condition=2), (76, 73, 10, None))]        # round 5: two view layers (one more saved activation set / delta set / mask row)
 
 
 @pytest.mark.parametrize("vi,arch_kw,shape", VARIANT_CASES)
@@ -113,7 +114,7 @@ def test_variant_plan_emulates_and_is_embedded(vi, arch_kw, shape):
     from mipnerf_pl_amd import _lib as L
     from mipnerf_pl_amd.mlp_plan import Arch
     tpv = TrainPlan.build(Arch(**arch_kw))
-    assert shape is None or (tpv.NH, tpv.NG, tpv.NMASK, tpv.n_bchunks_real) == shape
+    assert shape is None or (tpv.NH, tpv.NG, tpv.NMASK) == shape[:3] and shape[3] in (None, tpv.n_bchunks_real)
     views = arch_kw.get("use_viewdirs", True)
     S = 70
     rng = np.random.default_rng(5)
@@ -126,7 +127,8 @@ def test_variant_plan_emulates_and_is_embedded(vi, arch_kw, shape):
     flat, seen, raw = emulate_train(tpv, np.concatenate([v.ravel() for v in params.values()]), enc, view, d_raw)
     assert seen.max() == 1
     og = orc.mlp_backward(params, enc[:, None, :], venc if views else None, d_raw[:, None, :3], d_raw[:, None, 3:],
-                          skip_index=arch_kw.get("skip_index", 4), net_depth=arch_kw.get("net_depth", 8))
+                          skip_index=arch_kw.get("skip_index", 4), net_depth=arch_kw.get("net_depth", 8),
+                          net_depth_condition=arch_kw.get("net_depth_condition", 1))
     off = 0
     for k, v in og.items():
         got = flat[off:off + v.size]
@@ -151,7 +153,8 @@ def test_generator_schedule_passes_hazard_check(tmp_path):
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     for f in ("mlp_bf16_trainfwd_gen.hip", "mlp_bf16_dgrad_gen.hip", "mlp_bf16_trainfwd_gen_v1.hip", "mlp_bf16_dgrad_gen_v1.hip",
-              "mlp_bf16_trainfwd_gen_v2.hip", "mlp_bf16_dgrad_gen_v2.hip", "mlp_bf16_trainfwd_gen_v3.hip", "mlp_bf16_dgrad_gen_v3.hip"):
+              "mlp_bf16_trainfwd_gen_v2.hip", "mlp_bf16_dgrad_gen_v2.hip", "mlp_bf16_trainfwd_gen_v3.hip", "mlp_bf16_dgrad_gen_v3.hip",
+              "mlp_bf16_trainfwd_gen_v5.hip", "mlp_bf16_dgrad_gen_v5.hip"):
         gen = open(os.path.join(tmp_path, f)).read()
         committed = open(os.path.join(REPO, "mipnerf_pl_amd", "csrc", f)).read()
         assert gen == committed, f"{f} is stale: re-run python -m mipnerf_pl_amd.build"
