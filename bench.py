@@ -755,6 +755,37 @@ def run_fp32_c4(args, e):
                        "parallelism": f"ray-split x{e.world} (no data-path collective)"}}
 
 
+def run_variants(args, e):
+    """The other generated MLP shapes that got bf16 kernels in round 5 (two view layers; the 512-wide trunk at one wave per SIMD): MLP.forward =
+    one kernel launch, 524,288 samples, bf16 encodings resident, against the same shape's fp32 kernel; FLOP = 2 x the torch weights' MACs."""
+    import torch
+    from mipnerf_pl_amd import MipNerf
+    B, N = 4096, 128
+    out = {"workload": f"MLP.forward (one kernel) of {B * N} samples per architecture variant, random-init weights, bf16 vs fp32"}
+    torch.manual_seed(0)
+    v = torch.rand(B, 27, device=e.dev) * 2 - 1
+    for name, kw in (("two_view_layers", dict(mlp_net_depth_condition=2)), ("w512_c256", dict(mlp_net_width=512, mlp_net_width_condition=256))):
+        rec = {}
+        for prec, dt_ in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+            m = MipNerf(num_samples=N, precision=prec, **kw).to(e.dev)
+            macs = sum(p.numel() for n_, p in m.mlp.named_parameters() if n_.endswith("weight"))
+            x = (torch.rand(B, N, 96, device=e.dev) * 2 - 1).to(dt_)
+            with torch.no_grad():
+                m.mlp(x, v)
+                steps = 5
+                dt, _ = timed(e, lambda: m.mlp(x, v), 1, steps)
+            ms = dt / steps * 1e3
+            tf = 2 * macs * B * N / (ms * 1e-3) / 1e12
+            rec[prec] = {"ms_per_launch": round(ms, 4), "achieved_tflops": round(tf, 1), "frac_of_peak": round(tf / PEAK_TFLOPS[prec], 4)}
+            del m, x
+        rec["speedup_bf16_over_fp32"] = round(rec["fp32"]["ms_per_launch"] / rec["bf16"]["ms_per_launch"], 2)
+        out[name] = rec
+    # (the record's `value`: samples per second through the 512-wide trunk's bf16 kernel on this rank x ranks)
+    out["value"] = round(B * N * e.world / (out["w512_c256"]["bf16"]["ms_per_launch"] * 1e-3), 1)
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_train_unbounded(args, e, which=("fp32", "bf16", "bf16_graph")):
     import torch
     import synthetic_inputs as syn
@@ -962,6 +993,8 @@ def main():
         recs["fp32"] = sub("fp32", run_fp32_c4)
     if args.mode == "all" and args.rays == 4096 and args.samples == 128:      # the default (driver) invocation
         recs["trained_field"] = sub("trained_field", run_trained_field)
+        if not args.no_fp32 and args.precision == "bf16":
+            recs["variants"] = sub("variants", run_variants)
     ceiling = None
     if args.mode in ("all", "inference") and args.precision == "bf16" and e.world == 1 and args.ceiling_seconds > 0:
         try:

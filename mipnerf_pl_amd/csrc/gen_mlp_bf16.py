@@ -462,7 +462,7 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     pre = plan.pre_gemm        # trunk of the two-kernel form (mlp_pre_plan.py): X preloaded, skip-layer accumulators from k_pre_gemm
     WAVES = waves_of(plan.arch)                 # (shadow the module defaults: everything below is per kernel)
     GROUP = 4 * WAVES
-    wide = WAVES != globals()["WAVES"]
+    wide = max(plan.arch.net_width, plan.arch.net_width_condition) > 256      # one wave per SIMD, 512-register budget
     WG_PER_CU = 1 if wide else 8 // WAVES
     nreg = max(plan.arch.net_width, plan.arch.net_width_condition) // 16      # k-step fragments of one activation register set
     sfx = f"_pre_v{variant}" if pre else ("" if variant == 0 else f"_v{variant}")
