@@ -310,6 +310,217 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     return "\n".join(L) + "\n"
 
 
+# ---- third form (round 5 experiment, MLP_PRE_FORM=once): every encoding k-step from HBM ONCE -------------------------------------------------
+# 4-wave workgroups at ONE wave per SIMD (the 512-register budget the 512-wide trunk's kernel uses, gen_mlp_bf16.waves_of): a wave owns 32
+# samples and ALL 16 output tiles of both matrices (256 accumulator registers, which the compiler keeps in acc VGPRs), so a k-step's B operand
+# is loaded once and feeds 16 MFMAs.  Stream order [k-step][matrix][tile] (PrePlan split order), one ring group = one k-step = 16 chunks; every
+# wave consumes every chunk, so there is a ring barrier per 16 of its MFMAs (as in the 512-wide trunk's kernel) and the stream is fetched once
+# per 128 samples instead of once per 256.  Built (146 VGPRs + 256 acc VGPRs, 0 scratch), parity-green (MIPNERF_LIB=<that build> pytest
+# tests/test_gpu_unbounded_bf16.py) and NOT faster: 7.975 / 7.977 / 8.059 ms per 8192 x (256 + 256) forward with a 7-slot ring against
+# 7.954 / 7.976 / 7.986 of the default form in three alternating rounds, 8.21-8.30 with a 3-slot ring (profiles/r05t_pre_gemm_once_ab.txt):
+# the second read of the encoding is not what bounds k_pre_gemm.  Kept as a knob; the default stays the two-pass form.
+ONCE_DEPTH = int(os.environ.get("MLP_PRE_ONCE_DEPTH", "14"))      # B operands in flight + 1; must divide the 42 k-steps
+ONCE_SLOTS = int(os.environ.get("MLP_PRE_ONCE_SLOTS", "3"))       # ring slots of 16 KiB; must divide the 42 groups
+
+
+def gen_gemm_once(p: PrePlan, vi: int) -> str:
+    a = p.arch
+    nk, nt = p.nk, p.ntiles
+    assert p.split, "the once-form consumes the [k-step][matrix][tile] stream"
+    W4 = 4                                   # waves per workgroup
+    G = 2 * nt                               # chunks per ring group = one k-step of both matrices
+    nchunks = len(p.chunks)
+    assert nchunks == p.n_real_chunks == nk * G and nk % ONCE_SLOTS == 0 and nk % ONCE_DEPTH == 0 and ONCE_DEPTH < nk
+    ngroups, depth, slots = nk, ONCE_DEPTH, ONCE_SLOTS
+    ring_bytes = slots * G * CHUNK
+    bias_bytes = 2 * nt * 128
+    lds_bytes = ring_bytes + bias_bytes
+    nacc = 2 * nt
+    nslots = nk * nacc
+
+    def lda(c):
+        return f"A{c % PREFETCH} = LDA({((c // G) % slots) * G * CHUNK + (c % G) * CHUNK});"
+
+    body = []
+    E = lambda kind, x: body.append((kind, x))
+    for t in range(nacc):
+        E("stmt", f"BIAS(acc{t}, {t});")
+    E("stmt", "PIN();")
+    for c in range(nslots):
+        step, t = divmod(c, nacc)
+        E("stmt", f"MFMA(acc{t}, A{c % PREFETCH}, EB{step % depth});")
+        lc = c + PREFETCH
+        if lc % G == 0:
+            E("gb", (lc // G) % ngroups)
+        E("stmt", lda(lc % nslots))
+        if t == nacc - 1:
+            E("ld", step + depth - 1)
+        E("stmt", "PIN();")
+    for t in range(nt):
+        E("stmt", f"epilogue_half<true, 0>(acc{t}, xo);  STORE_X({2 * t}, xo);")
+        E("stmt", f"epilogue_half<true, 8>(acc{t}, xo);  STORE_X({2 * t + 1}, xo);")
+        E("stmt", "PIN();")
+    for t in range(nt):
+        E("stmt", f"STORE_ACC({t}, acc{nt + t});")
+        E("stmt", "PIN();")
+    # counted vmcnt, as in gen_gemm: DMA(g) is issued inside barrier g - (slots - 1); younger = the DMAs of the groups behind it (4 chunk
+    # loads per wave each) + the B-operand loads since
+    ahead = slots - 1
+    seq = [(k, x) for k, x in body if k in ("gb", "ld")] * 3
+    gb_pos = [i for i, (k, x) in enumerate(seq) if k == "gb"]
+    vmk = {}
+    for i in gb_pos[ngroups + 2:]:
+        g = seq[i][1]
+        prev = [j for j in gb_pos if j < i]
+        j2 = prev[-ahead]
+        assert seq[j2][1] == (g - ahead) % ngroups
+        younger = sum(1 for j in range(j2 + 1, i) if seq[j][0] == "ld") + 4 * (ahead - 1)
+        vmk[g] = min(vmk.get(g, 63), younger)
+    assert len(vmk) == ngroups, vmk
+    vmk = {g: max(0, min(k, 4 * (ahead - 1) + depth - 1) - VM_MARGIN) for g, k in vmk.items()}
+
+    L = []
+    e = L.append
+    e("// AUTO-GENERATED by gen_pre_gemm.py (MLP_PRE_FORM=once) from mlp_pre_plan.py -- do not edit by hand.")
+    e(f"// k_pre_gemm of architecture variant {vi}, every encoding k-step read once: 4-wave workgroups, one wave per SIMD, 16 accumulator tiles per wave")
+    e("#include <hip/hip_runtime.h>")
+    e('#include "kernels.hpp"')
+    e('#include "raymath.hpp"')
+    e("namespace mip {")
+    e(f"namespace pre_v{vi} {{")
+    e("typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;")
+    e("typedef __attribute__((ext_vector_type(16))) float f32x16;")
+    e("#define MIP_OPAQUE_STREAM_BASE 1")
+    e(f"constexpr int kRingBytes = {ring_bytes};")
+    e(f"constexpr int kBiasBytes = {bias_bytes};")
+    e(f"constexpr int kLdsBytes = {lds_bytes};")
+    e(f"constexpr int kGroupBytes = {G * CHUNK};")
+    e(f"constexpr int kNumGroups = {ngroups};")
+    e(f"constexpr int kTileSamples = {W4 * 32};")
+    e(f"constexpr int kXyzDim = {a.xyz_dim};")
+    e(f"constexpr int kNk = {nk};")
+    e(gb.KERNEL_PREAMBLE.replace("BARRIER_INSN", "s_barrier").replace("WAIT_INSN", "s_waitcnt vmcnt(0) lgkmcnt(0)"))
+    e('#define RING_BARRIER(K) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\\n\\ts_barrier" ::"n"(K) : "memory")')
+    e("#define ST16(p, v) __builtin_nontemporal_store((v), (p))" if NT_STORES else "#define ST16(p, v) *(p) = (v)")
+    e("#define STORE_X(k, v) ST16(reinterpret_cast<bf16x8*>(xo_base + (k) * 1024 + lane16), (v))")
+    e("#define STORE_ACC(t, acc)                                                                                                  \\")
+    e("    do {                                                                                                                   \\")
+    e("        ST16(reinterpret_cast<f32x4_*>(ao_base + (t) * 4096 + lane16), __builtin_shufflevector(acc, acc, 0, 1, 2, 3));                  \\")
+    e("        ST16(reinterpret_cast<f32x4_*>(ao_base + ((t) * 4096 + 1024) + lane16), __builtin_shufflevector(acc, acc, 4, 5, 6, 7));           \\")
+    e("        ST16(reinterpret_cast<f32x4_*>(ao_base + ((t) * 4096 + 2048) + lane16), __builtin_shufflevector(acc, acc, 8, 9, 10, 11));         \\")
+    e("        ST16(reinterpret_cast<f32x4_*>(ao_base + ((t) * 4096 + 3072) + lane16), __builtin_shufflevector(acc, acc, 12, 13, 14, 15));       \\")
+    e("    } while (0)")
+    e("template <bool FRAG>")
+    e("__device__ __forceinline__ const char* bbase_of(const char* enc, int64_t wt, int64_t M) {")
+    e("    if (FRAG) return enc + wt * (int64_t)(kNk * 1024);")
+    e("    const int64_t s0 = wt * 32;")
+    e("    return enc + (s0 < M ? s0 : M - 1) * (int64_t)(kXyzDim * 2);")
+    e("}")
+    e("template <bool FRAG>")
+    e("__device__ __forceinline__ unsigned boff_of(int64_t wt, int lane, int64_t M) {")
+    e("    if (FRAG) return (unsigned)lane * 16u;")
+    e("    const int64_t s0 = wt * 32, s = s0 + (lane & 31);")
+    e("    const int64_t r0 = s0 < M ? s0 : M - 1, r = s < M ? s : M - 1;")
+    e("    return (unsigned)((r - r0) * (kXyzDim * 2) + (lane >> 5) * 16);")
+    e("}")
+    e("template <bool FRAG>")
+    e(f"__global__ void __launch_bounds__({W4 * 64}, 1)")
+    e("k_pre_gemm(const char* __restrict__ stream, const float* __restrict__ bias_tab, const char* __restrict__ enc,")
+    e("           char* __restrict__ pre_x, char* __restrict__ pre_acc, int64_t M, int ntiles, int nwg) {")
+    e("    constexpr bool DMA = true;")
+    e("    extern __shared__ __attribute__((aligned(16))) char smem[];")
+    e("    const int tid = (int)__builtin_amdgcn_workitem_id_x();")
+    e("    const int lane = tid & 63;")
+    e("    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);")
+    e("    const int hi = lane >> 5, n = lane & 31;")
+    e("    const unsigned lane16 = (unsigned)lane * 16u;")
+    e("    const char* ring_lane = smem + lane16;")
+    e("    const char* bias_lane = smem + kRingBytes + hi * 64;")
+    e(f"#define WT_OF(tl) ((int64_t)(tl) * {W4} + wave)")
+    e(f"    for (int i = tid; i < kBiasBytes / 16; i += {W4 * 64})")
+    e("        reinterpret_cast<float4*>(smem + kRingBytes)[i] = reinterpret_cast<const float4*>(bias_tab)[i];")
+    e("    __syncthreads();")
+    e("    int tile = (int)__builtin_amdgcn_workgroup_id_x();")
+    e("    if (tile >= ntiles) return;")
+    e("    constexpr int kBStep = FRAG ? 1024 : 32;")
+    e("    const char* bsrc = bbase_of<FRAG>(enc, WT_OF(tile), M);")
+    e("    const char* bnext = bsrc;")
+    e("    unsigned boff0 = boff_of<FRAG>(WT_OF(tile), lane, M), boff0_next = boff0;")
+    e("    bf16x8 " + ", ".join(f"A{i}" for i in range(PREFETCH)) + ", " + ", ".join(f"EB{i}" for i in range(depth)) + ", xo;")
+    e("    f32x16 " + ", ".join(f"acc{t}" for t in range(nacc)) + ";")
+    for g in range(ahead):
+        e(f"    issue_group<DMA>(stream, smem, {g}, {g}, wave, lane16);")
+    e("    const char* bp = bsrc;")
+    e("    unsigned bo = boff0;")
+    e('#define LOAD_B(reg) do { reg = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(bp + bo)); bo += kBStep; asm volatile("" : "+v"(bo)); } while (0)')
+    for d in range(depth - 1):
+        e(f"    LOAD_B(EB{d});")
+    e(f"    RING_BARRIER({vmk[0]});")
+    e(f"    issue_group<DMA>(stream, smem, {ahead}, {ahead % slots}, wave, lane16);")
+    for c in range(PREFETCH):
+        e(f"    {lda(c)}")
+    e("    for (;;) {")
+    e("        const int tnext = tile + nwg;")
+    e("        const bool has_next = tnext < ntiles;")
+    e("        bnext = has_next ? bbase_of<FRAG>(enc, WT_OF(tnext), M) : bsrc;")
+    e("        boff0_next = has_next ? boff_of<FRAG>(WT_OF(tnext), lane, M) : boff0;")
+    e("        char* xo_base = pre_x + WT_OF(tile) * 16384;")
+    e("        char* ao_base = pre_acc + WT_OF(tile) * 32768;")
+    for kind, x in body:
+        if kind == "stmt":
+            e(f"        {x}")
+        elif kind == "ld":
+            if x == nk:
+                e("        bp = bnext; bo = boff0_next;    // from here on the next tile's operands")
+            e(f"        LOAD_B(EB{x % depth});")
+        else:
+            g = x
+            e(f"        RING_BARRIER({vmk[g]});      // group {g} readable, the slot of group {(g - 1) % ngroups} free")
+            g2 = g + ahead
+            if g2 < ngroups:
+                e(f"        issue_group<DMA>(stream, smem, {g2}, {g2 % slots}, wave, lane16);")
+            else:
+                e(f"        if (has_next) issue_group<DMA>(stream, smem, {g2 - ngroups}, {g2 % slots}, wave, lane16);")
+    e("        if (!has_next) break;")
+    e("        tile = tnext;")
+    e("        bsrc = bnext;")
+    e("        boff0 = boff0_next;")
+    e("    }")
+    e('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+    e("#undef LOAD_B")
+    e("#undef WT_OF")
+    e("}")
+    e(f"}}  // namespace pre_v{vi}")
+    e("")
+    e(f"hipError_t launch_pre_gemm_v{vi}(const void* stream_w, const float* bias_tab, const void* enc, int frag, void* pre_x, void* pre_acc,")
+    e("                              int64_t M, int grid_limit, hipStream_t st) {")
+    e(f"    using namespace pre_v{vi};")
+    e("    // whole 256-sample tiles of the trunk kernel: an even number of 128-sample tiles (pre_x / pre_acc are sized for them)")
+    e("    const int64_t nt64 = ((M + 255) / 256) * 2;")
+    e("    if (nt64 < 1 || nt64 > 0x7fffffff) return hipErrorInvalidValue;")
+    e("    const int ntiles = (int)nt64;")
+    e("    int grid = ntiles < grid_limit ? ntiles : grid_limit;")
+    e("    if (grid < 1) grid = 1;")
+    e("    static int attr_done[64] = {};")
+    e("    int dev = 0;")
+    e("    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;")
+    e("    if (!attr_done[dev]) {")
+    e("        hipError_t er = hipFuncSetAttribute((const void*)k_pre_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
+    e("        if (er != hipSuccess) return er;")
+    e("        er = hipFuncSetAttribute((const void*)k_pre_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);")
+    e("        if (er != hipSuccess) return er;")
+    e("        attr_done[dev] = 1;")
+    e("    }")
+    e(f"    if (frag) hipLaunchKernelGGL((k_pre_gemm<true>), dim3(grid), dim3({W4 * 64}), kLdsBytes, st, (const char*)stream_w, bias_tab, (const char*)enc,")
+    e("                                 (char*)pre_x, (char*)pre_acc, M, ntiles, grid);")
+    e(f"    else hipLaunchKernelGGL((k_pre_gemm<false>), dim3(grid), dim3({W4 * 64}), kLdsBytes, st, (const char*)stream_w, bias_tab, (const char*)enc,")
+    e("                            (char*)pre_x, (char*)pre_acc, M, ntiles, grid);")
+    e("    return hipGetLastError();")
+    e("}")
+    e("}  // namespace mip")
+    return "\n".join(L) + "\n"
+
+
 def variants_header(vis, n):
     L = ["// AUTO-GENERATED by gen_pre_gemm.py -- do not edit by hand.", "#pragma once", '#include "kernels.hpp"', "namespace mip {",
          "// two-kernel bf16 MLP of the variants whose encoding is too wide for k_mlp_bf16's wave-private LDS area (mlp_pre_plan.py)",
@@ -335,9 +546,10 @@ def main():
     outdir = sys.argv[1] if len(sys.argv) > 1 else HERE
     vis = [vi for vi, a in enumerate(gb.VARIANTS) if supported(a)]
     for vi in vis:
-        p = PrePlan.build(gb.VARIANTS[vi])
+        once = os.environ.get("MLP_PRE_FORM", "") == "once"
+        p = PrePlan.build(gb.VARIANTS[vi], split=True) if once else PrePlan.build(gb.VARIANTS[vi])
         with open(os.path.join(outdir, f"pre_gemm_gen_v{vi}.hip"), "w") as f:
-            f.write(gen_gemm(p, vi))
+            f.write(gen_gemm_once(p, vi) if once else gen_gemm(p, vi))
         with open(os.path.join(outdir, f"mlp_bf16_pre_gen_v{vi}.hip"), "w") as f:
             f.write(gb.gen_kernel(p.trunk, vi))
         with open(os.path.join(outdir, f"_gen_pre_tables_v{vi}.bin"), "wb") as f:
