@@ -1250,6 +1250,8 @@ int mipnerf_train_step(mipnerf_ctx* c, int64_t B, const mipnerf_rays* rays, cons
         return fail(MIPNERF_E_INVALID, "train_step: bad argument");
     if (!has_train_step(c))
         return fail(MIPNERF_E_UNSUPPORTED, "train_step: no bf16 training kernels for this variant; it trains in fp32 precision");
+    if (c->cfg.unbounded && !has_bf16_train_pre(c->P))      // the unbounded branch hands FRAGMENT encodings to the two-kernel form only
+        return fail(MIPNERF_E_UNSUPPORTED, "train_step: the unbounded-scene model trains through the two-kernel (pre-GEMM) form");
     if (!rays->origins || !rays->directions || !rays->viewdirs || !rays->radii || !rays->near || !rays->far || !rays->lossmult)
         return fail(MIPNERF_E_INVALID, "train_step: a Rays field is null");
     if (!c->params_set) return fail(MIPNERF_E_INVALID, "train_step: mipnerf_set_params has not been called");
