@@ -75,12 +75,10 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_
 // profiles/r02n_ds_read_tr_probe.txt).  Lane i of group (hi, g = n >> 4) therefore ADDRESSES the granule (feature quad 4 g + (i & 3),
 // sample 16 f + 8 r + 4 hi + (i >> 2)) for read r in {0, 1} and RECEIVES feature 16 g + i of samples 16 f + 8 r + 4 hi + 0 .. 3.
 typedef short v4s16e __attribute__((ext_vector_type(4)));
-// ROW = bytes between consecutive samples of the LDS image: 64 (row-major rows) or 16 (the fragment image, see wgrad_body).
-template <int ROW>
 __device__ __forceinline__ bf16x8 lds_frag_enc(const char* blk, unsigned enc_lane_off, int f) {
-    const char* p = blk + enc_lane_off + f * (16 * ROW);
+    const char* p = blk + enc_lane_off + f * (16 * 64);
     const v4s16e lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16e*)(size_t)(p));
-    const v4s16e hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16e*)(size_t)(p + 8 * ROW));
+    const v4s16e hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s16e*)(size_t)(p + 8 * 64));
     typedef short v8s16e __attribute__((ext_vector_type(8)));
     const v8s16e v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return __builtin_bit_cast(bf16x8, v);
@@ -214,8 +212,8 @@ __device__ __forceinline__ void k_wgrad_recompute_body(char* smem, const char* _
 // Two instantiations behind one workgroup-uniform branch, so the encoding path costs the standard jobs nothing (as one body with the
 // choice inside the unrolled operand loop, the standard training step ran 12 % slower: 4.73 instead of 4.20 ms).
 // ENC = 2 (the one-call training step of the unbounded model): the encoding arrives as the B-operand FRAGMENTS k_pre_gemm reads fastest
-// ([wave tile][k-step][lane (hi, n)][8 features]); a 32-feature block = two consecutive k-steps = 2 KiB that land lane-linear like a T-block.
-// In that LDS image the granule (feature quad q of the block, sample s) sits at (q >> 2) * 1024 + ((q >> 1) & 1) * 512 + s * 16 + (q & 1) * 8.
+// ([wave tile][k-step][lane (hi, n)][8 features]); a 32-feature block = two consecutive k-steps = 2 KiB, gathered into the same row-major LDS
+// image as ENC = 1 (see the DMA below), so both encoding forms share the operand reads.
 template <int ENC>
 __device__ __forceinline__ void wgrad_body(char* smem, const char* __restrict__ HT, const char* __restrict__ GT, const WgradJob* jp, const int4 wg,
                                            int64_t n_wt, int NH, int NG, float* __restrict__ partials, const WgradEnc* __restrict__ Ep, int lane,
@@ -231,9 +229,7 @@ __device__ __forceinline__ void wgrad_body(char* smem, const char* __restrict__ 
     if (ENC) E = *Ep;                                       // (uniform scalar loads) the record the training forward left behind the T-blocks
     // encoding jobs: DMA source offset of this lane (sample lane >> 2 of a 16-sample half, 16-byte piece lane & 3) and its operand-read offset
     const unsigned enc_dma_piece = (unsigned)(lane & 3) * 16u;
-    const unsigned enc_lane_off =
-        ENC == 2 ? (unsigned)(((lane >> 4) & 1) * 1024 + ((lane >> 1) & 1) * 512 + (lane & 1) * 8 + (4 * (lane >> 5) + ((lane & 15) >> 2)) * 16)
-                 : (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (4 * ((lane >> 4) & 1) + (lane & 3)) * 8);
+    const unsigned enc_lane_off = (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (4 * ((lane >> 4) & 1) + (lane & 3)) * 8);
 
     f32x16 acc[9];
 #pragma unroll
@@ -252,7 +248,28 @@ __device__ __forceinline__ void wgrad_body(char* smem, const char* __restrict__ 
         char* st = smem + stage * kStageBytes;
         if (has_b) {
             if (ENC == 2) {
-                dma_block((const char*)E.enc + (wt * E.frag_ksteps + 2 * b_blk) * 1024, st + wave * 2048, lane16);
+                // fragment source: the block's two k-steps = 2 KiB, piece (k-step ks, lane half hi, sample n) at ks * 1024 + hi * 512 + n * 16.
+                // Landed lane-linearly they would make the transposing reads 4-way bank-conflicted (k-step and lane half are multiples of 256
+                // bytes apart); every lane therefore FETCHES the piece that belongs at its place of the row-major [32 samples][64 B] image
+                // the ENC = 1 path reads conflict-free: lane L of DMA d brings feature octet L & 3 of sample 16 d + (L >> 2).
+                const char* base = (const char*)E.enc + (wt * E.frag_ksteps + 2 * b_blk) * 1024;
+                const char* p0 = base + ((lane >> 1) & 1) * 1024 + (lane & 1) * 512 + (lane >> 2) * 16;
+                const char* p1 = p0 + 256;
+                char* dst = st + wave * 2048;
+                const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)dst;
+                unsigned keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\t"
+                    "s_mov_b32 m0, %3\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, off" MIP_WGRAD_LOAD_POLICY "\n\t"
+                    "s_add_u32 m0, m0, 1024\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %2, off" MIP_WGRAD_LOAD_POLICY "\n\t"
+                    "s_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(p0), "v"(p1), "s"(lds_addr)
+                    : "memory");
             } else if (ENC == 1) {
                 // rows wt * 32 + (lane >> 2) [+ 16], clamped to the last sample (their deltas are zero); the clamp makes the row per-lane,
                 // so both DMAs take a full 64-bit lane address
@@ -302,10 +319,8 @@ __device__ __forceinline__ void wgrad_body(char* smem, const char* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (j < nB) {
-                        const bf16x8 b0 = ENC == 2 ? lds_frag_enc<16>(sb + j * 2048, enc_lane_off, 0)
-                                                   : (ENC == 1 ? lds_frag_enc<64>(sb + j * 2048, enc_lane_off, 0) : lds_frag(st + j * 2048));
-                        const bf16x8 b1 = ENC == 2 ? lds_frag_enc<16>(sb + j * 2048, enc_lane_off, 1)
-                                                   : (ENC == 1 ? lds_frag_enc<64>(sb + j * 2048, enc_lane_off, 1) : lds_frag(st + j * 2048 + 1024));
+                        const bf16x8 b0 = ENC ? lds_frag_enc(sb + j * 2048, enc_lane_off, 0) : lds_frag(st + j * 2048);
+                        const bf16x8 b1 = ENC ? lds_frag_enc(sb + j * 2048, enc_lane_off, 1) : lds_frag(st + j * 2048 + 1024);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[j], 0, 0, 0);
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
                     }
