@@ -60,9 +60,9 @@ def test_kernels_match_the_reference_where_the_reference_is_right(G):
 
 
 @pytest.mark.parametrize("randomized", [False, True])
-@pytest.mark.parametrize("white", [True, False])
-def test_unbounded_model_forward_vs_oracle(G, randomized, white):
-    B, N = 40, 64
+@pytest.mark.parametrize("white,shape", [(True, (40, 64)), (False, (40, 64)), (True, (3, 600)), (False, (7, 45))])     # 600: the K = 16 bucket (round 5)
+def test_unbounded_model_forward_vs_oracle(G, randomized, white, shape):
+    B, N = shape
     rays = syn.synthetic_rays(B, seed=61, unbounded=True)
     params = syn.make_params(seed=17, density_gain=40.0, **ARCH)
     rng = np.random.default_rng(5)
@@ -77,7 +77,7 @@ def test_unbounded_model_forward_vs_oracle(G, randomized, white):
     for lvl in range(2):
         for nm, a, b in zip(G.NAMES, got[lvl], want[lvl]):
             errs[f"l{lvl}_{nm}"] = G.maxdiff(a, b)
-    G.record(f"unbounded forward randomized={randomized} white={white}", **errs)
+    G.record(f"unbounded forward B={B} N={N} randomized={randomized} white={white}", **errs)
     # level 0: nothing upstream but the fence posts (bit-exact) and the encoding (1e-5): fp32 MLP accuracy
     assert errs["l0_t_samples"] <= 1e-6 * float(np.abs(want[0][4]).max())
     assert errs["l0_rgb"] <= 5e-5 and errs["l0_acc"] <= 5e-5 and errs["l0_weights"] <= 5e-5
