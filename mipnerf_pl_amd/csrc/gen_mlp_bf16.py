@@ -443,6 +443,19 @@ __device__ __forceinline__ void ipe_next_store(const bf16x8& fs, const bf16x8& f
     } while (0)
 """
 
+DEEP_RING_MACRO = r"""// One wave per SIMD (the 512-wide trunk, gen_mlp_bf16.waves_of): a ring group is 16 chunks = 16 of a wave's MFMAs = ~0.5 us, less than the
+// L2 -> LDS latency of the group behind it, and there is no second wave to cover the wait.  These kernels keep kAhead groups in flight in a
+// ring of kAhead + 1 slots: entering group g waits, with a COUNTED vmcnt, for this wave's four DMAs of group g only (the 4 (kAhead - 1) DMAs
+// of the groups behind it stay in flight), and refills the slot of group g - 1 with group g + kAhead.  Group 0 of a tile waits for
+// everything: the tile's encodings were issued behind the ring DMAs and are read right after.
+#define GROUP_BEGIN_DEEP(g, WAITCNT)                                                                                     \
+    do {                                                                                                                \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITCNT) : "memory");                          \
+        if ((g) + kAhead < kNumGroups) issue_group<DMA>(stream, smem, (g) + kAhead, ((g) + kAhead) % (kAhead + 1), wave, lane16);      \
+        else if (has_next) issue_group<DMA>(stream, smem, (g) + kAhead - kNumGroups, ((g) + kAhead) % (kAhead + 1), wave, lane16);    \
+    } while (0)
+"""
+
 
 def _shadow_fits(plan: Plan) -> bool:
     """Three ops behind the last encoding reader with >= 2 x 18 MFMA slots each (gen_kernel places one encoding k-step per op)."""
@@ -465,6 +478,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     wide = max(plan.arch.net_width, plan.arch.net_width_condition) > 256      # one wave per SIMD, 512-register budget
     WG_PER_CU = 1 if wide else 8 // WAVES
     nreg = max(plan.arch.net_width, plan.arch.net_width_condition) // 16      # k-step fragments of one activation register set
+    AHEAD = int(os.environ.get("MLP_WIDE_AHEAD", "3")) if wide else 1         # ring groups in flight (GROUP_BEGIN_DEEP); the 8-wave kernels: 1
+    SLOTS = AHEAD + 1 if wide else globals()["SLOTS"]
     sfx = f"_pre_v{variant}" if pre else ("" if variant == 0 else f"_v{variant}")
     nchunks = len(plan.chunks)
     assert nchunks % GROUP == 0, "stream must be a whole number of ring groups"
@@ -511,8 +526,12 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e(f"constexpr int kGroupBytes = {GROUP * CHUNK_BYTES};")
     e(f"constexpr int kNumGroups = {ngroups};")
     e(f"constexpr int kTileSamples = {WAVES * 32};")
+    if wide:
+        e(f"constexpr int kAhead = {AHEAD};")
     e(KERNEL_PREAMBLE.replace("BARRIER_INSN", "s_nop 0" if ABLATE_BARRIER else "s_barrier")
       .replace("WAIT_INSN", "s_waitcnt lgkmcnt(0)" if ABLATE_WAIT else "s_waitcnt vmcnt(0) lgkmcnt(0)"))
+    if wide:
+        e(DEEP_RING_MACRO)
     e("template <bool DMA, bool IPE>")
     e(f"__global__ void __launch_bounds__({WAVES * 64}, {1 if wide else 2})")
     e("k_mlp_bf16(const char* __restrict__ stream, const float* __restrict__ bias_tab,")
@@ -537,7 +556,13 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     if SETPRIO:
         e("    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // MI355X_MICROARCH.md, two waves per SIMD, item 4")
     shadow = IPE_SHADOW and nenc == 6 and _shadow_fits(plan)
-    e("    if ((int)blockIdx.x < ntiles) issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
+    if wide:
+        e("    if ((int)blockIdx.x < ntiles) {")
+        for g in range(AHEAD):
+            e(f"        issue_group<DMA>(stream, smem, {g}, {g}, wave, lane16);")
+        e("    }")
+    else:
+        e("    if ((int)blockIdx.x < ntiles) issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
     if shadow:
         e("    if (IPE && (int)blockIdx.x < ntiles) {      // the first tile's encoding; every later one is computed in the previous tile's shadow")
         e("        const int64_t s_first = (int64_t)blockIdx.x * kTileSamples + wave * 32 + n;")
@@ -669,7 +694,11 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
                 side[first + pi_ * stride].append("if (IPE) { " + stmt + " }")
 
     # ---- tile prologue --------------------------------------------------------------------------
-    e("        GROUP_BEGIN(0, 1);")
+    def group_begin(g, note=""):
+        if wide:          # group 0: a full wait (the tile's encoding DMAs are younger than the ring's and are read next)
+            return f"GROUP_BEGIN_DEEP({g}, {0 if g == 0 else 4 * (AHEAD - 1)});{note}"
+        return f"GROUP_BEGIN({g}, {(g + 1) % SLOTS});{note}"
+    e(f"        {group_begin(0)}")
     for c in range(PREFETCH):
         e(f"        {lda(c)}")
     for stmt in prologue:
@@ -688,13 +717,14 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         if lc < nreal:
             if lc % GROUP == 0:
                 g = lc // GROUP
-                e(f"        GROUP_BEGIN({g}, {(g + 1) % SLOTS});")
+                e(f"        {group_begin(g)}")
             e(f"        {lda(lc)}")
         for stmt in side[c]:
             e(f"        {stmt}")
         e("        PIN();")
     for g in range((nreal + GROUP - 1) // GROUP, ngroups):
-        e(f"        GROUP_BEGIN({g}, {(g + 1) % SLOTS});      // a whole group of zero padding: nothing reads it, but its barrier issues the next tile's group 0")
+        pad_note = "      // a whole group of zero padding: nothing reads it, but its barrier issues the next tile's group 0"
+        e(f"        {group_begin(g, pad_note)}")
     for stmt in epilogue_pieces(plan, panels[-1]):
         e(f"        {stmt}")
     e("        if (hi == 0 && s < M) {")
