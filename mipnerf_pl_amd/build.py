@@ -28,7 +28,7 @@ UNITS = [
     # (source, extra flags)
     ("kernels_ray.hip", ["-ffp-contract=off"]),
     ("kernels_train.hip", ["-ffp-contract=off"]),
-    ("kernels_360.hip", ["-ffp-contract=off"]),
+    ("kernels_360.hip", ["-ffp-contract=off"] + (["-DMIP_IPE360_ROW_PAD=" + os.environ["MLP_IPE360_ROW_PAD"]] if os.environ.get("MLP_IPE360_ROW_PAD") else [])),
     ("kernels_resample_grad.hip", ["-ffp-contract=off"]),
     ("kernels_pack.hip", []),
     ("kernels_mlp_f32.hip", ["-ffp-contract=off"]),

@@ -94,6 +94,13 @@ __device__ __forceinline__ void ipe360_pair(float y, float var, int l, int min_d
 //     buffer covers whole 256-sample tiles (an even number of wave tiles), samples past the end repeat the last one;
 //   rows: row-major [M, F]: consecutive threads write consecutive 8-feature runs of one sample's row.
 constexpr int kFragSamples = 64;
+// LDS row of a sample's projections = 21 + PAD floats.  PAD = 7 is what the wrap-around needs; with it a wave's 64 lanes (one sample each)
+// read rows 28 floats apart = 16 distinct banks: 4-way conflicts, 66 % of the kernel's LDS-active cycles (profiles/r05_lds_conflicts.txt).
+// An odd row length (PAD = 8) makes the 64 rows start in 64 different banks -- measured, no difference: 7.78-7.81 vs 7.79-7.82 ms per unbounded
+// bf16 forward; the kernel is bound by its 5.1 TB/s of stores, the conflicts hide behind them.  Knob kept (build.py: MLP_IPE360_ROW_PAD).
+#ifndef MIP_IPE360_ROW_PAD
+#define MIP_IPE360_ROW_PAD 7
+#endif
 template <typename OutT, bool FRAG>
 __global__ void __launch_bounds__(256)
 k_cast_ipe_360_tile(int64_t B, int N, int min_deg, int L, int contracted, const float* __restrict__ t, const float* __restrict__ origins,
@@ -101,7 +108,7 @@ k_cast_ipe_360_tile(int64_t B, int N, int min_deg, int L, int contracted, const 
     typedef OutT vec8 __attribute__((ext_vector_type(8)));
     // projections of a sample: its 21 directions followed by the first 7 again, so that the eight consecutive features of a vector
     // (directions j0 .. j0 + 7, wrapping into the next degree) are eight consecutive LDS words -- one address per vector, literal offsets
-    constexpr int kRow = kBasis360N + 7;
+    constexpr int kRow = kBasis360N + MIP_IPE360_ROW_PAD;      // (>= 7 columns of wrap-around; see MIP_IPE360_ROW_PAD above)
     __shared__ GaussFull sg[kFragSamples];
     __shared__ float sy[kFragSamples][kRow], sv[kFragSamples][kRow];
     const int tid = threadIdx.x;
