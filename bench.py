@@ -708,7 +708,7 @@ def run_fp32_c4(args, e):
         utf = flop_u * M / (ulaunch * 1e-3) / 1e12
         unb = {"ms_per_step": round(udt / steps * 1e3, 4), "value": round(B * N * 2 * e.world * steps / udt, 1), "launch_ms": round(ulaunch, 4),
                "flop_per_sample": flop_u, "achieved": round(utf, 2), "frac": round(utf / peak, 4), "finite": bool(torch.isfinite(uout[-1][0]).all()),
-               "model": "MipNerf(unbounded=True): 672-wide encoding, fp32 only"}
+               "model": "MipNerf(unbounded=True): 672-wide encoding, fp32 precision"}
         # ... and in bf16 (round 4: k_pre_gemm + trunk kernel, csrc/gen_pre_gemm.py): same rays, same weights, agreement with the fp32 frame
         try:
             bm = MipNerf(num_samples=N, precision="bf16", unbounded=True)

@@ -61,8 +61,9 @@ VARIANTS = [
     Arch(net_width_condition=256, use_viewdirs=False),                 # MLP.forward(x, None): colour head on the trunk output
     Arch(net_depth=6, skip_index=3),                                   # another depth / skip period (20 parameter tensors)
     # SURVEY 8(f)-4, the unbounded-scene model: MipNerf(unbounded=True) feeds the 2 x 21 x 16 = 672 off-axis IPE features of the
-    # contracted Gaussians (kernels_360.hip) to the same 8 x 256 trunk (first layer 672 -> 256, skip concat 256 + 672).  fp32 only:
-    # 42 k-steps per sample do not fit the bf16 kernels' 8-KiB wave-private encoding area.
+    # contracted Gaussians (kernels_360.hip) to the same 8 x 256 trunk (first layer 672 -> 256, skip concat 256 + 672).  bf16_kernels=False:
+    # 42 k-steps per sample do not fit THIS generator's 8-KiB wave-private encoding area -- its bf16 form is the two-kernel one (gen_pre_gemm.py:
+    # k_pre_gemm + a trunk kernel generated here with pre_gemm=True), inference and training.
     Arch(xyz_dim=672, feat_per_deg=42, bf16_kernels=False),
     # two view layers (mlp_net_depth_condition = 2, mip_nerf.py:62-69).  Round 5: bf16 INFERENCE kernel too -- its stream is 39 ring
     # groups + one whole group of zero padding (the ring phase must be tile-invariant: an even number of groups), which the generator

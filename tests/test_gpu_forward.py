@@ -421,8 +421,8 @@ def test_fused_small_kernels_equal_per_stage_kernels(G, N, randomized):
 
 
 def test_two_view_layers_variant_fp32(G):
-    """mlp_net_depth_condition = 2 (mip_nerf.py:62-69: a second Wc -> Wc view layer, 26 parameter tensors): its own fp32-only
-    architecture variant -- forward against the reference's golden, loss and every gradient of a training step against the
+    """mlp_net_depth_condition = 2 (mip_nerf.py:62-69: a second Wc -> Wc view layer, 26 parameter tensors): its own
+    architecture variant -- fp32: forward against the reference's golden, loss and every gradient of a training step against the
     reference's autograd (the fp32 GEMM backward walks the view layers in a loop); bf16 (round 5): inference kernel and training kernels."""
     from mipnerf_pl_amd import MipNerf
     from mipnerf_pl_amd.system import MipNeRFSystem, DEFAULT_HPARAMS
