@@ -44,7 +44,10 @@ enum {
 /* compute precision of the MLP (the rest of the path is always fp32) */
 enum {
     MIPNERF_PREC_FP32 = 0, /* v_mfma_f32_32x32x2_f32, exact fp32 products (parity mode)   */
-    MIPNERF_PREC_BF16 = 1  /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate    */
+    MIPNERF_PREC_BF16 = 1, /* v_mfma_f32_32x32x16_bf16, bf16 operands / fp32 accumulate    */
+    MIPNERF_OUT_BF16_FRAGMENTS = 2 /* out_dtype of mipnerf_cast_ipe_360 only: bf16 in the MFMA B-operand fragment layout  */
+                                   /* [wave tile of 32 samples][k-step][64 lanes][8], whole 256-sample tiles (the buffer    */
+                                   /* holds ceil(M / 256) * 256 rows) -- what the two-kernel MLP form reads fastest         */
 };
 
 /* flags */
@@ -227,7 +230,7 @@ int mipnerf_generate_rays(int64_t num_rays, const float* cameras, const int32_t*
  *   (NULL = deterministic) jitters between midpoints in inverse-depth space.  Outputs t_inv, t_samples [B,N+1].
  * cast_ipe_360: t [B,N+1] -> conical-frustum Gaussians with FULL covariance -> scene contraction of mean and covariance
  *   (contracted != 0) -> off-axis IPE on 21 basis directions and frequencies 2^l, l in [min_deg, max_deg):
- *   enc [B*N, 2*21*(max_deg-min_deg)] (fp32 or bf16; feature = half*21L + l*21 + basis).  means [B*N,3] / covs [B*N,3,3]
+ *   enc [B*N, 2*21*(max_deg-min_deg)] (fp32 or bf16; feature = half*21L + l*21 + basis; or MIPNERF_OUT_BF16_FRAGMENTS).  means [B*N,3] / covs [B*N,3,3]
  *   (both or neither; may be the only outputs, enc = NULL) receive the (contracted) Gaussians. */
 int mipnerf_sample_along_rays_360(int64_t num_rays, int32_t num_samples, const float* near, const float* far,
                                   const float* t_rand, float* t_inv, float* t_samples, void* stream);
@@ -384,7 +387,8 @@ int mipnerf_selftest(void* stream);
  * coarse fence posts as ONE launch and the coarse level's compositing + the fine level's resampling as ONE launch (N <= 128 or 192 < N <= 256; the
  * weights go from registers to the sampler's LDS row), 0 = one launch per stage (same bits); option 5: 1 [default] = fp32 inference (mipnerf_mlp_forward,
  * mipnerf_forward) runs the register-resident kernel k_mlp_f32r where one was generated for the architecture (widths <= 256), 0 = the LDS-resident
- * k_mlp_f32 (same function, another summation order: results agree to fp32 rounding). */
+ * k_mlp_f32 (same function, another summation order: results agree to fp32 rounding); option 6: 1 = the `enc` argument of
+ * mipnerf_mlp_forward_train is in the fragment layout (MIPNERF_OUT_BF16_FRAGMENTS; two-kernel variants only), 0 [default] = row-major. */
 int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
 /* Sum of the elapsed times (ms) and the number of MLP launches recorded since the last call
  * (option 2); synchronises on the recorded events. */

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("MIPNERF_LIB", os.path.join(HERE, "csrc", "libmipnerf_
 
 OK, E_INVALID, E_UNSUPPORTED, E_HIP, E_WORKSPACE = 0, 1, 2, 3, 4
 PREC_FP32, PREC_BF16 = 0, 1
+OUT_BF16_FRAGMENTS = 2      # out_dtype of mipnerf_cast_ipe_360 only (include/mipnerf_hip.h)
 FLAG_WHITE_BKGD, FLAG_DISPARITY = 1, 2
 NUM_PARAM_TENSORS = 24
 MAX_SAMPLES = 1024

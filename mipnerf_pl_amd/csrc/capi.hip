@@ -268,6 +268,7 @@ struct mipnerf_ctx {
     float* d_stream_f32r = nullptr;
     float* d_aux_f32r = nullptr;
     int f32_resident = 1;            // option 5: 1 = k_mlp_f32r where generated (inference), 0 = the LDS-resident k_mlp_f32
+    int train_enc_frag = 0;          // option 6: mipnerf_mlp_forward_train's enc is in the fragment layout (two-kernel variants)
     // two-kernel bf16 inference of the variants whose encoding does not fit k_mlp_bf16's wave-private LDS area (gen_pre_gemm.py):
     // k_pre_gemm's weight stream + accumulator images, the trunk kernel's stream + bias table, and scratch for the per-stage entry point
     PreTables pre;
@@ -593,6 +594,7 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
         case 3: c->fused_ipe = value ? 1 : 0; return MIPNERF_OK;
         case 4: c->fuse_small = value ? 1 : 0; return MIPNERF_OK;
         case 5: c->f32_resident = value ? 1 : 0; return MIPNERF_OK;
+        case 6: c->train_enc_frag = value ? 1 : 0; return MIPNERF_OK;
         default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
     }
 }
@@ -775,8 +777,10 @@ int mipnerf_cast_ipe_360(int64_t B, int32_t N, int32_t min_deg, int32_t max_deg,
     if (B < 1 || N < 1 || !t || !origins || !dirs || !radii || (!enc && !means) || ((means == nullptr) != (covs == nullptr)))
         return fail(MIPNERF_E_INVALID, "cast_ipe_360: bad argument");
     if (min_deg < 0 || max_deg <= min_deg || max_deg > 31) return fail(MIPNERF_E_INVALID, "cast_ipe_360: need 0 <= min_deg < max_deg <= 31");
+    const bool frag = out_dtype == MIPNERF_OUT_BF16_FRAGMENTS;
+    if (frag && (!enc || means)) return fail(MIPNERF_E_INVALID, "cast_ipe_360: the fragment layout is an encoding-only output");
     HIP_TRY(mip::launch_cast_ipe_360(B, N, min_deg, max_deg, contracted, t, origins, dirs, radii, enc,
-                                     out_dtype == MIPNERF_PREC_BF16, means, covs, S(stream)));
+                                     out_dtype == MIPNERF_PREC_BF16 || frag, means, covs, S(stream), frag));
     return MIPNERF_OK;
 }
 
@@ -915,7 +919,7 @@ static int mlp_forward_train_noise(mipnerf_ctx* c, int64_t M, int32_t N, const v
 
 int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, float* rgb_sigma,
                               float* raw, void* act, void* masks, void* stream) {
-    return mlp_forward_train_noise(c, M, N, enc, viewenc, rgb_sigma, raw, act, masks, nullptr, stream);
+    return mlp_forward_train_noise(c, M, N, enc, viewenc, rgb_sigma, raw, act, masks, nullptr, stream, c && c->train_enc_frag && has_bf16_train_pre(c->P));
 }
 
 int mipnerf_mlp_dgrad(mipnerf_ctx* c, int64_t M, const float* d_raw, const void* masks, void* delta, void* stream) {

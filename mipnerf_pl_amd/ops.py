@@ -293,13 +293,24 @@ def sample_along_rays_360(origins, directions, radii, num_samples, near, far, ra
     return t_inv, cast_rays_360(t, origins, directions, radii, contracted=False)
 
 
-def cast_ipe_360(t_samples, origins, directions, radii, min_deg, max_deg, contracted=True, precision=L.PREC_FP32):
+def cast_ipe_360(t_samples, origins, directions, radii, min_deg, max_deg, contracted=True, precision=L.PREC_FP32, fragments=False):
     """Fused frustum -> full-covariance Gaussian -> contraction -> off-axis IPE: [B, N, 2*21*(max_deg-min_deg)]; what
-    `integrated_pos_enc_360(parameterization(cast_rays(...)))` of the reference is meant to compute (mip.py:292-319, 431-447)."""
+    `integrated_pos_enc_360(parameterization(cast_rays(...)))` of the reference is meant to compute (mip.py:292-319, 431-447).
+    fragments=True (bf16 only): the MFMA B-operand fragment layout the two-kernel MLP form reads fastest -- an opaque
+    [ceil(B N / 256) * 256, features] bf16 buffer for `autograd.mlp_native(..., frag_shape=(B, N))`, not a row-major tensor."""
     t_samples = _f32c(t_samples, "t_samples")
     B, N1 = t_samples.shape
-    enc = torch.empty(B, N1 - 1, 42 * (max_deg - min_deg), device=t_samples.device, dtype=_torch_dtype(precision))
+    F = 42 * (max_deg - min_deg)
     o, d, r = _f32c(origins, "origins"), _f32c(directions, "directions"), _f32c(radii, "radii")
+    if fragments:
+        if precision != L.PREC_BF16:
+            raise ValueError("cast_ipe_360(fragments=True) is a bf16 layout")
+        M = B * (N1 - 1)
+        enc = torch.empty((M + 255) // 256 * 256, F, device=t_samples.device, dtype=torch.bfloat16)
+        L.check(L.lib().mipnerf_cast_ipe_360(B, N1 - 1, min_deg, max_deg, int(bool(contracted)), _ptr(t_samples), _ptr(o), _ptr(d),
+                                             _ptr(r), _ptr(enc), L.OUT_BF16_FRAGMENTS, None, None, _stream()), "cast_ipe_360")
+        return enc
+    enc = torch.empty(B, N1 - 1, F, device=t_samples.device, dtype=_torch_dtype(precision))
     L.check(L.lib().mipnerf_cast_ipe_360(B, N1 - 1, min_deg, max_deg, int(bool(contracted)), _ptr(t_samples), _ptr(o), _ptr(d),
                                          _ptr(r), _ptr(enc), precision, None, None, _stream()), "cast_ipe_360")
     return enc
