@@ -201,6 +201,11 @@ def mlp_native_f32(mlp, samples_enc, viewdirs_enc):
     return _MLPNativeF32.apply(mlp, samples_enc, viewdirs_enc, *mlp.ordered_params())
 
 
+# The unbounded model's bf16 training forward writes its 672-wide encoding as MFMA fragments (faster for k_pre_gemm and the weight-gradient
+# jobs).  False = row-major rows, the layout of the per-stage C ABI: same arithmetic, same bits -- the parity tests run both and compare.
+FRAGMENT_ENCODINGS = True
+
+
 def mlp_native(mlp, samples_enc, viewdirs_enc, frag_shape=None):
     """Differentiable bf16 MLP: samples_enc [B,N,xyz_dim] bf16 (or, frag_shape = (B, N), the fragment buffer of
     ops.cast_ipe_360(fragments=True)), viewdirs_enc [B,32] bf16 -> raw [B,N,4] fp32."""
@@ -312,7 +317,7 @@ def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_ra
                     t_samples = 1.0 / t_inv
                 # bf16: the encoding as MFMA fragments (k_pre_gemm and the weight-gradient jobs read them faster than rows: 7.4 -> 6.9 ms per step)
                 enc = ops.cast_ipe_360(t_samples, rays.origins, rays.directions, rays.radii, model.min_deg_point, model.max_deg_point,
-                                       contracted=True, precision=model.precision, fragments=native)
+                                       contracted=True, precision=model.precision, fragments=native and FRAGMENT_ENCODINGS)
         elif through and lvl > 0:
             B = rays.origins.shape[0]
             u = None
@@ -330,7 +335,7 @@ def mipnerf_forward_train(model, rays, randomized, white_bkgd, t_rand=None, u_ra
                 enc = ops.cast_ipe(t_samples, rays.origins, rays.directions, rays.radii, model.min_deg_point,
                                    model.max_deg_point, model.disable_integration, precision=model.precision)
         if native:
-            raw = mlp_native(model.mlp, enc, venc, frag_shape=(t_samples.shape[0], N) if unbounded else None)
+            raw = mlp_native(model.mlp, enc, venc, frag_shape=(t_samples.shape[0], N) if (unbounded and FRAGMENT_ENCODINGS) else None)
         else:
             raw = mlp_native_f32(model.mlp, enc, venc)
         comp_rgb, distance, acc, weights = render_from_raw(raw, t_samples, rays.directions, white_bkgd,

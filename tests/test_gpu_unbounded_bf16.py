@@ -152,15 +152,22 @@ def test_one_call_native_step_equals_the_autograd_route(G, B, N, white):
     rays = G.to_dev(syn.synthetic_rays(B, seed=B + 1, unbounded=True))
     gt = torch.rand(B, 3, device=DEV)
     t_rand, u_rand = torch.rand(B, N + 1, device=DEV), torch.rand(B, N + 1, device=DEV)
+    import mipnerf_pl_amd.autograd as AG
     res = {}
-    for native in (False, True):
+    for native in (False, True, "rows"):
         model = _model(params, N, "bf16")
-        if native:
+        if native is True:
             scal, outs = model.train_step_native(rays, gt, True, white, t_rand=t_rand, u_rand=u_rand, return_outputs=True)
             loss = float(scal[0])
             fine = outs[1]
         else:
-            ret = model(rays, True, white, t_rand=t_rand, u_rand=u_rand)
+            # False: autograd on fragment encodings (the default); "rows": autograd on row-major rows (the per-stage ABI's layout) -- the
+            # cross-check of the two encoding layouts of k_pre_gemm and of the weight-gradient jobs
+            AG.FRAGMENT_ENCODINGS = native is False
+            try:
+                ret = model(rays, True, white, t_rand=t_rand, u_rand=u_rand)
+            finally:
+                AG.FRAGMENT_ENCODINGS = True
             mask = rays.lossmult
             mse = [(mask * (r[0] - gt) ** 2).sum() / mask.sum() for r in ret]
             dl = [distloss(r[3], r[4]) for r in ret]
@@ -170,10 +177,13 @@ def test_one_call_native_step_equals_the_autograd_route(G, B, N, white):
             fine = tuple(x.detach() for x in ret[1])
         res[native] = (loss, torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone(), fine)
     (l0, g0, f0), (l1, g1, f1) = res[False], res[True]
+    lr_, gr_, _ = res["rows"]
+    e_rows = G.maxdiff(gr_, g1) / float(gr_.abs().max())
+    assert abs(lr_ - l1) <= 2e-6 * max(1.0, abs(lr_)) and e_rows <= 2e-5, (lr_, l1, e_rows)       # measured <= 7e-9: fragments == rows
     for a, b in zip(f0, f1):
         assert G.maxdiff(a, b) <= 2e-6, G.maxdiff(a, b)      # same forward kernels on the same inputs (the activations run fused / stand-alone)
     eg = G.maxdiff(g0, g1) / float(g0.abs().max())
-    G.record(f"unbounded native_train_step B={B} N={N}", loss_autograd=l0, loss_native=l1, grad_rel=eg)
+    G.record(f"unbounded native_train_step B={B} N={N}", loss_autograd=l0, loss_native=l1, grad_rel=eg, grad_rel_rows_vs_fragments=e_rows)
     assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)) and eg <= 2e-5, (l0, l1, eg)
     # fused tail (compositing + distloss + the next level's inverse-depth fence posts in one launch) == one launch per stage, bit for bit
     grads = []
