@@ -213,3 +213,28 @@ def test_pre_gemm_training_plan_emulation_matches_oracle():
     # the job table tells the kernel which jobs read the encoding
     jt = tp.job_table()
     assert [int(r[3]) for r in jt] == [j.b_src for j in tp.jobs]
+
+
+def test_wgrad_fragment_gather_builds_the_row_major_lds_image():
+    """k_mlp_wgrad, encoding jobs on FRAGMENT encodings (kernels_wgrad.hip, wgrad_body<2>): every lane of the two LDS-DMAs of a 32-feature
+    block fetches the 16-byte piece that belongs at its place of the row-major [32 samples][64 B] image the transposing reads expect
+    (landed lane-linearly the pieces sit multiples of 256 B apart: 4-way bank conflicts).  The address arithmetic of the source, restated:
+    fragment layout = [k-step][lane half][sample][8 features] (kernels_360.hip enc360_index), LDS destination = DMA base + lane * 16."""
+    src = open(os.path.join(REPO, "mipnerf_pl_amd", "csrc", "kernels_wgrad.hip")).read()
+    assert "const char* p0 = base + ((lane >> 1) & 1) * 1024 + (lane & 1) * 512 + (lane >> 2) * 16;" in src
+    assert "const char* p1 = p0 + 256;" in src
+    frag = np.zeros(2048, np.int32)                       # one block = two k-steps; value = sample * 100 + feature, per bf16 element (2 bytes)
+    for ks in range(2):
+        for hi in range(2):
+            for n in range(32):
+                for j in range(8):
+                    frag[(ks * 1024 + hi * 512 + n * 16 + j * 2) // 2 * 2] = n * 100 + ks * 16 + hi * 8 + j
+    lds = np.full(2048, -1, np.int32)
+    for d in range(2):                                    # the second DMA: source + 256 bytes, LDS destination + 1024 bytes
+        for lane in range(64):
+            p = ((lane >> 1) & 1) * 1024 + (lane & 1) * 512 + (lane >> 2) * 16 + d * 256
+            dst = d * 1024 + lane * 16
+            lds[dst:dst + 16] = frag[p:p + 16]
+    for s in range(32):
+        for f in range(32):
+            assert lds[s * 64 + f * 2] == s * 100 + f, (s, f)
