@@ -238,3 +238,29 @@ def test_wgrad_fragment_gather_builds_the_row_major_lds_image():
     for s in range(32):
         for f in range(32):
             assert lds[s * 64 + f * 2] == s * 100 + f, (s, f)
+
+
+def test_wgrad_transposing_reads_deliver_the_plans_operand():
+    """The operand reads of the encoding jobs (kernels_wgrad.hip lds_frag_enc): two ds_read_b64_tr_b16 per fragment from the row-major
+    [32 samples][64 B] LDS image.  Instruction semantics as probed on MI355X (profiles/r02n_ds_read_tr_probe.txt): within a group of 16 lanes,
+    lane i receives element (i & 3) of the 8-byte granules addressed by lanes (i >> 2) + 4 k, k = 0 .. 3.  With the source's per-lane address
+    every lane (hi, n) must end up with feature column n of the samples Plan.drow(hi, 8 f + j), j = 0 .. 7 -- the B operand the plan's
+    emulation feeds the weight-gradient MFMA (emulate_train_tile: ET[b, f, (hi, n), j])."""
+    src = open(os.path.join(REPO, "mipnerf_pl_amd", "csrc", "kernels_wgrad.hip")).read()
+    assert "const unsigned enc_lane_off = (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * 64 + (4 * ((lane >> 4) & 1) + (lane & 3)) * 8);" in src
+    assert "const char* p = blk + enc_lane_off + f * (16 * 64);" in src and "(p + 8 * 64)" in src
+    from mipnerf_pl_amd.mlp_plan import Plan
+    image = lambda byte: (byte // 64, (byte % 64) // 2)          # LDS byte -> (sample, feature) of the row-major image
+    for f in range(2):
+        got = {}
+        for r in range(2):
+            addr = [(4 * (L_ >> 5) + ((L_ & 15) >> 2)) * 64 + (4 * ((L_ >> 4) & 1) + (L_ & 3)) * 8 + f * 1024 + r * 512 for L_ in range(64)]
+            for lane in range(64):
+                grp, i = lane & ~15, lane & 15
+                for k in range(4):
+                    src_lane = grp + (i >> 2) + 4 * k
+                    got[(lane, 4 * r + k)] = image(addr[src_lane] + 2 * (i & 3))
+        for lane in range(64):
+            hi, n = lane >> 5, lane & 31
+            for j in range(8):
+                assert got[(lane, j)] == (Plan.drow(hi, 8 * f + j), n), (f, lane, j, got[(lane, j)])
