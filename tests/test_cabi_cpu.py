@@ -332,3 +332,21 @@ def test_one_wave_per_simd_kernel_ring_is_consistent():
     pro = src[:src.index("for (int tile = blockIdx.x;")]
     assert [tuple(map(int, m)) for m in re.findall(r"issue_group<DMA>\(stream, smem, (\d+), (\d+), wave, lane16\);", pro)][-ahead:] == [(g, g) for g in range(ahead)]
     assert "((g) + kAhead) % (kAhead + 1)" in src
+
+
+def test_sample_count_limit_is_one_number_everywhere():
+    """num_samples <= 1024 = 64 lanes x 16 samples: the header, the ctypes layer, the LDS row constants and the samples-per-lane dispatch of
+    every per-ray kernel (buckets 1, 2, 4, 8, 16) say the same."""
+    csrc = os.path.join(REPO, "mipnerf_pl_amd", "csrc")
+    hdr = open(os.path.join(REPO, "include", "mipnerf_hip.h")).read()
+    assert int(re.search(r"#define MIPNERF_MAX_SAMPLES (\d+)", hdr).group(1)) == L.MAX_SAMPLES == 1024
+    assert "constexpr int kPdfMaxBins = 1024;" in open(os.path.join(csrc, "raywave.hpp")).read()
+    assert "constexpr int kMaxBins = 1024;" in open(os.path.join(csrc, "kernels_resample_grad.hip")).read()
+    n = 0
+    for f in ("kernels_ray.hip", "kernels_train.hip", "kernels_resample_grad.hip"):
+        src = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r"case 5: case 6: case 7: case 8: (MIP_\w+)\(8\); break;\s*\n\s*case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: (MIP_\w+)\(16\); break;\s*\n\s*default: return hipErrorInvalidValue;", src):
+            assert m.group(1) == m.group(2)
+            n += 1
+        assert src.count("(8); break;") == src.count("(16); break;"), f          # no dispatch without the 16-samples-per-lane bucket
+    assert n == 7
