@@ -196,13 +196,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
         f.write("/* empty: only provides the DT_NEEDED name libamdhip64.so */\n")
     subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", os.path.join(stub_dir, "libamdhip64.so"), stub_c])
     rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    # The dynamic symbol table is the C ABI and nothing else: a linker version script keeps `mipnerf_*` (the entry points
+    # include/mipnerf_hip.h / mipnerf_diag.h declare) and makes every C++ launcher, kernel handle and table blob local.
+    vers = os.path.join(stub_dir, "exports.map")
+    with open(vers, "w") as f:
+        f.write("{ global: mipnerf_*; local: *; };\n")
     cmd = ["g++", "-shared", "-fPIC", "-o", LIB] + objs + [
-        "-Wl,--no-as-needed", "-L" + stub_dir, "-lamdhip64", "-Wl,--as-needed", "-Wl,--allow-shlib-undefined",
+        "-Wl,--version-script=" + vers, "-Wl,--no-as-needed", "-L" + stub_dir, "-lamdhip64", "-Wl,--as-needed", "-Wl,--allow-shlib-undefined",
         "-Wl,-rpath," + rocm_lib, "-Wl,--enable-new-dtags", "-lstdc++", "-lm"]
     if verbose:
         print("[build]", " ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    cmd = ["g++", "-shared", "-fPIC", "-o", DIAG_LIB] + diag_objs + cmd[cmd.index("-Wl,--no-as-needed"):]
+    cmd = ["g++", "-shared", "-fPIC", "-o", DIAG_LIB] + diag_objs + cmd[cmd.index("-Wl,--version-script=" + vers):]
     if verbose:
         print("[build]", " ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

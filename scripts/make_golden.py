@@ -8,6 +8,8 @@ Run (only possible in the build container; the GPU box has no /root/reference):
 
     (no flag)                the 11 round-1 files: forward cases, stages, training gradients, ray generation, metrics (~1 min)
     --only-fullsize          round 2: BASELINE configs[1] 4096x128 and configs[3] 8192x256, every ray (~1 min on 8 threads)
+    --only-frame             round 6: ONE whole 800 x 800 `RenderGen` frame (BASELINE configs[4]) rendered by the unmodified reference on the
+                             trained field: 79 chunks of 8192 rays, N = 128 (~15 min on 8 threads)
     --only-fullsize-train    round 3: loss + all 24 gradients of the reference's training step at 4096x128 (configs[1], configs[2] inputs; ~2 min)
     --only-quality-run TAG THREADS SEED / --only-quality-merge   round 3: reference training runs (600 steps x 1024 rays x 128 samples) on the
                              procedural multi-scale scene, test PSNR at 4 scales (2-4 h of CPU per run)
@@ -699,6 +701,94 @@ def fullsize_trained_case(name, field, batch, num_samples, ray_seed, train_step)
 
 
 
+def _ref_rendergen(poses=None):
+    """The reference's `RenderGen` (render_video.py:19-118) and `create_spheric_poses` (utils/vis.py).  render_video.py imports
+    Lightning, so the class body is exec'd from the mounted file, unmodified.  `poses`: indices of the 120 spheric poses to keep (every
+    pose's rays are computed independently of the others, render_video.py:68-80) -- the whole path at 800 x 800 is 8 GB of float64."""
+    import ast
+    import collections
+    for mod in ("torchvision", "torchvision.transforms", "matplotlib", "matplotlib.pyplot"):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules["cv2"].COLORMAP_JET = 2        # default argument evaluated at import (utils/vis.py:75)
+    from utils.vis import create_spheric_poses
+    src = open(os.path.join(REF, "render_video.py")).read()
+    cls = [n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "RenderGen"][0]
+    csp = create_spheric_poses if poses is None else (lambda radius: np.asarray(create_spheric_poses(radius))[list(poses)])
+    ns = dict(np=np, Dataset=torch.utils.data.Dataset, create_spheric_poses=csp, Rays=RefRays,
+              Rays_keys=RefRays._fields, collections=collections)
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "render_video.py", "exec"), ns)
+    return ns["RenderGen"], create_spheric_poses
+
+
+FRAME = dict(pose=7, size=800, chunk=8192, num_samples=128, camera_angle_x=0.6911112070083618)
+
+
+def frame_case(name, field):
+    """Round 6: BASELINE configs[4] pinned end to end.  The unmodified reference renders ONE 800 x 800 pose of its
+    spheric path on the trained field: rays from `RenderGen` (render_video.py:29-112) with the focal of render_video.py:125, batched as
+    the DataLoader of render_video.py:129-132 does (leading axis of 1, .float()), chunked by `rearrange_render_image` (mip.py:404-421),
+    then the loop of `MipNeRFSystem.render_image` (nerf_system.py:151-177): `MipNerf.forward(chunk, False, white_bkgd=True)` under
+    no_grad for each of the 79 chunks (the last one ragged: 1024 rays), concatenated and reshaped to [1, H, W, 3].  Stored: coarse and
+    fine rgb, fine distance and acc, val_mask, the pose, the scene's own pixels for these rays (tests/dataset_fixture.py quadrature,
+    8 bit) and the reference's PSNR against them.  The rays are NOT stored: the test generates them on the device from the pose."""
+    import hashlib
+    import time
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import dataset_fixture as fx
+    F = FRAME
+    RenderGen, create_spheric_poses = _ref_rendergen(poses=[F["pose"]])
+    focal = .5 * F["size"] / np.tan(.5 * F["camera_angle_x"])                      # render_video.py:125
+    ds = RenderGen(focal, [F["size"], F["size"]], 1)
+    assert len(ds) == 1
+    one = ds[0]
+    rays = RefRays(*[torch.from_numpy(np.asarray(getattr(one, k)))[None].float() for k in RefRays._fields])   # DataLoader(batch_size=1) + .float()
+    _, height, width, _ = rays.origins.shape
+    f = np.load(os.path.join(OUT, field + ".npz"))
+    params = {k[2:]: f[k] for k in f.files if k.startswith("p_")}
+    model = RefMipNerf(num_samples=F["num_samples"])
+    load_params(model, params)
+    model.eval()
+    chunks, val_mask = refmip.rearrange_render_image(rays, F["chunk"])
+    assert len(chunks) == 79 and chunks[-1].origins.shape[0] == 1024
+    coarse, fine, dist, accs = [], [], [], []
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for i, batch_rays in enumerate(chunks):
+            (c_rgb, _, _, _, _), (f_rgb, distance, acc, _, _) = model(batch_rays, False, True)
+            coarse.append(c_rgb)
+            fine.append(f_rgb)
+            dist.append(distance)
+            accs.append(acc)
+            if i % 10 == 0:
+                print(f"  [{name}] chunk {i}/79 ({time.perf_counter() - t0:.0f} s)", flush=True)
+    dt = time.perf_counter() - t0
+    coarse = torch.cat(coarse, 0).reshape(1, height, width, 3).numpy()
+    fine = torch.cat(fine, 0).reshape(1, height, width, 3).numpy()
+    dist = torch.cat(dist, 0).reshape(height, width).numpy()
+    accs = torch.cat(accs, 0).reshape(height, width).numpy()
+    # the scene's own pixels along these rays (float64 quadrature), composited on white like the training images
+    gt = np.empty((height, width, 3), np.float64)
+    o, d = np.asarray(one.origins, np.float64), np.asarray(one.directions, np.float64)
+    for r0 in range(0, height, 40):
+        rgb, alpha = fx._render_scene(o[r0:r0 + 40], d[r0:r0 + 40], 2.0, 6.0)
+        gt[r0:r0 + 40] = rgb * alpha[..., None] + (1.0 - alpha[..., None])
+    gt_u8 = np.round(255.0 * np.clip(gt, 0, 1)).astype(np.uint8)
+    g = gt_u8.astype(np.float32) / 255.0
+    psnr = lambda img: float(-10.0 * np.log10(np.mean((img[0].astype(np.float64) - g) ** 2)))
+    h = hashlib.sha256()
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    out = {"cfg_" + k: v for k, v in F.items()}
+    out.update(field=field, field_sha256=h.hexdigest(), focal=np.float64(focal), pose=np.asarray(create_spheric_poses(4)[F["pose"]], np.float64),
+               coarse_rgb=coarse, fine_rgb=fine, distance=dist, acc=accs, val_mask=val_mask.numpy(), gt_u8=gt_u8,
+               psnr_fine=np.float64(psnr(fine)), psnr_coarse=np.float64(psnr(coarse)), threads=torch.get_num_threads(), seconds=dt,
+               frac_empty=float((accs < 0.05).mean()), frac_opaque=float((accs > 0.95).mean()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"wrote {name}.npz: reference frame {dt:.0f} s on {torch.get_num_threads()} threads; PSNR vs the scene fine {out['psnr_fine']:.3f} "
+          f"coarse {out['psnr_coarse']:.3f} dB; {out['frac_empty']:.2f} empty / {out['frac_opaque']:.2f} opaque pixels; "
+          f"{os.path.getsize(os.path.join(OUT, name + '.npz')) / 1e6:.1f} MB")
+
+
 def quality_run(tag, threads, draw_seed):
     """Quality stand-in at realistic scale: the UNMODIFIED reference trained on the procedural multi-scale
     Blender-format scene of tests/dataset_fixture.py (Multicam dataset class -> rays; MipNerf; loss of nerf_system.py:99-111 with
@@ -1023,6 +1113,9 @@ if __name__ == "__main__":
     if "--only-fullsize-trained" in sys.argv:   # round 4: headline-size forward / training-step goldens on that field
         fullsize_trained_case("fulltrained_c2_4096x128", "trained_field", 4096, 128, ray_seed=200, train_step=True)
         fullsize_trained_case("fulltrained_c4_8192x256", "trained_field", 8192, 256, ray_seed=201, train_step=False)
+        sys.exit(0)
+    if "--only-frame" in sys.argv:           # round 6: BASELINE configs[4], one whole RenderGen frame by the reference (~15 min)
+        frame_case("frame_c5_800x800", "trained_field")
         sys.exit(0)
     if "--only-quality-run" in sys.argv:     # round 3: one reference training run on the procedural multi-scale scene (hours of CPU)
         i = sys.argv.index("--only-quality-run")

@@ -37,6 +37,20 @@ def test_every_declared_symbol_is_exported(lib):
     assert sorted(L.SIGNATURES) == names
 
 
+def _dynamic_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+
+
+def test_dynamic_symbol_table_is_exactly_the_c_abi(lib):
+    """the libraries export the entry points their headers declare and NOTHING else -- no mip::launch_* C++ launchers,
+    kernel handles or table blobs (a linker version script in build.py keeps `mipnerf_*` only)."""
+    assert _dynamic_symbols(L.LIB_PATH) == header_functions()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(REPO, "include", "mipnerf_diag.h")).read(), flags=re.S)
+    assert _dynamic_symbols(L.DIAG_LIB_PATH) == sorted(set(re.findall(r"\b(mipnerf_[a-z0-9_]+)\s*\(", src)))
+
+
 def test_abi_version_and_compiled_arch(lib):
     assert lib.mipnerf_abi_version() == 5
     cfg = L.Config()
