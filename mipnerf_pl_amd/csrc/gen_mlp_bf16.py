@@ -449,11 +449,15 @@ DEEP_RING_MACRO = r"""// One wave per SIMD (the 512-wide trunk, gen_mlp_bf16.wav
 // ring of kAhead + 1 slots: entering group g waits, with a COUNTED vmcnt, for this wave's four DMAs of group g only (the 4 (kAhead - 1) DMAs
 // of the groups behind it stay in flight), and refills the slot of group g - 1 with group g + kAhead.  Group 0 of a tile waits for
 // everything: the tile's encodings were issued behind the ring DMAs and are read right after.
+// The refill runs AROUND the stream unconditionally: on a workgroup's last tile the last kAhead groups prefetch groups 0 .. kAhead - 1 once
+// more (48 KiB of L2 reads nobody consumes) so that the counted wait holds at every boundary -- with a refill that stopped at the last
+// tile only 4 (kNumGroups - 1 - g) DMAs would be younger than group g's and vmcnt(4 (kAhead - 1)) would pass before group g has landed
+// (ADVICE r05).  The kernel ends with vmcnt(0): no LDS-DMA may land after the workgroup has released its LDS.
 #define GROUP_BEGIN_DEEP(g, WAITCNT)                                                                                     \
     do {                                                                                                                \
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITCNT) : "memory");                          \
         if ((g) + kAhead < kNumGroups) issue_group<DMA>(stream, smem, (g) + kAhead, ((g) + kAhead) % (kAhead + 1), wave, lane16);      \
-        else if (has_next) issue_group<DMA>(stream, smem, (g) + kAhead - kNumGroups, ((g) + kAhead) % (kAhead + 1), wave, lane16);    \
+        else issue_group<DMA>(stream, smem, (g) + kAhead - kNumGroups, ((g) + kAhead) % (kAhead + 1), wave, lane16);                  \
     } while (0)
 """
 
@@ -736,6 +740,8 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e("            if (raw_out) raw_out[s] = make_float4(raw_r, raw_g, raw_b, raw_density);")
     e("        }")
     e("    }")
+    if wide:
+        e('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the refill runs around the stream: no LDS-DMA may land after the workgroup has released its LDS')
     e("}")
     e("")
     if variant:

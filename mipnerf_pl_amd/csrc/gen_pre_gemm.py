@@ -268,7 +268,9 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
             if g2 < ngroups:
                 e(f"        issue_group<DMA>(stream, smem, {g2}, {g2 % RING_SLOTS}, wave, lane16);")
             else:
-                e(f"        if (has_next) issue_group<DMA>(stream, smem, {g2 - ngroups}, {g2 % RING_SLOTS}, wave, lane16);")
+                # around the stream, also on the last tile: the counted waits assume DMA(g + 1) is younger than DMA(g) at EVERY barrier
+                # (ADVICE r05); the phantom groups land in free slots and the kernel ends with vmcnt(0)
+                e(f"        issue_group<DMA>(stream, smem, {g2 - ngroups}, {g2 % RING_SLOTS}, wave, lane16);")
     e("        if (!has_next) break;")
     e("        tile = tnext;")
     e("        bsrc = bnext;")
@@ -480,7 +482,7 @@ def gen_gemm_once(p: PrePlan, vi: int) -> str:
             if g2 < ngroups:
                 e(f"        issue_group<DMA>(stream, smem, {g2}, {g2 % slots}, wave, lane16);")
             else:
-                e(f"        if (has_next) issue_group<DMA>(stream, smem, {g2 - ngroups}, {g2 % slots}, wave, lane16);")
+                e(f"        issue_group<DMA>(stream, smem, {g2 - ngroups}, {g2 % slots}, wave, lane16);      // around the stream, also on the last tile (see gen_gemm)")
     e("        if (!has_next) break;")
     e("        tile = tnext;")
     e("        bsrc = bnext;")

@@ -346,6 +346,13 @@ def test_one_wave_per_simd_kernel_ring_is_consistent():
     pro = src[:src.index("for (int tile = blockIdx.x;")]
     assert [tuple(map(int, m)) for m in re.findall(r"issue_group<DMA>\(stream, smem, (\d+), (\d+), wave, lane16\);", pro)][-ahead:] == [(g, g) for g in range(ahead)]
     assert "((g) + kAhead) % (kAhead + 1)" in src
+    # the counted wait of the tile's LAST kAhead - 1 groups leans on the next tile's groups being in flight, so the refill must not
+    # stop on a workgroup's last tile (has_next == false): it runs around the stream unconditionally, and the kernel drains before it ends
+    macro = src[src.index("#define GROUP_BEGIN_DEEP(g, WAITCNT)"):]
+    macro = macro[:macro.index("} while (0)")]
+    assert "has_next" not in macro and "(g) + kAhead - kNumGroups" in macro
+    tail = src[src.index("if (hi == 0 && s < M)"):]
+    assert 's_waitcnt vmcnt(0)' in tail[:tail.index("\n}\n")]
 
 
 def test_sample_count_limit_is_one_number_everywhere():
