@@ -160,7 +160,7 @@ def test_generated_gemm_body(vi, split):
     # counted waits: never more than the vector-memory operations known to be younger than the awaited group's DMA (its successor's four
     # chunks + the loads of two barrier intervals), minus the margin
     # the counts assume the successor group's DMA is in flight at EVERY barrier, so the refill may not stop on the last tile
-    assert "if (has_next) issue_group" not in src and 's_waitcnt vmcnt(0)' in src[src.index("if (!has_next) break;"):]
+    assert "if (has_next) issue_group" not in "\n".join(body) and 's_waitcnt vmcnt(0)' in src[src.index("if (!has_next) break;"):]
     ks_ = [int(x) for x in re.findall(r"RING_BARRIER\((\d+)\);", src)]
     assert ks_ and max(ks_) <= 4 + 2 * per_gap - gp.VM_MARGIN and min(ks_) >= 4
 
