@@ -445,8 +445,15 @@ def run_train(args, e):
         roofline["hbm_view"] = {"bytes_per_step": traffic, "achieved_TBps": round(traffic / (ms * 1e-3) / 1e12, 3), "peak_TBps": 8.0,
                                 "frac_of_peak": round(traffic / (ms * 1e-3) / 8e12, 4),
                                 "note": "store-everything backprop: 3.73 TFLOP / 20.9 GB = 178 FLOP/B, below the 312 FLOP/B ridge"}
+    lightning = None
+    if e.world == 1 and args.precision == "bf16" and not args.autograd:
+        try:
+            lightning = run_lightning_route(args, e, model0.state_dict(), R, gt, N)
+            lightning["vs_graphed_step"] = round(lightning["ms_per_step"] / ms, 4)
+        except Exception as ex:      # noqa: BLE001  (a sub-record must not take the bench line down)
+            lightning = {"error": f"{type(ex).__name__}: {ex}"}
     rec = {"value": round(value, 1), "ms_per_step": round(ms, 4), "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
-           "roofline": roofline, "ranks": per_rank,
+           "roofline": roofline, "ranks": per_rank, "lightning_route": lightning,
            "config": {"workload": (f"training step (randomized forward + loss incl. distloss + backward + one flat gradient all-reduce + "
                                    f"Adam + MipLRDecay), {B} rays x ({N}+{N}) samples per GPU"),
                       "mode": "train", "preheat_seconds": PREHEAT["seconds"], "rays_per_gpu": B, "global_batch_rays": B * e.world, "samples_per_level": N, "levels": model.num_levels,
@@ -458,6 +465,47 @@ def run_train(args, e):
                       "lr_schedule": "device" if graphed else "host",
                       "parallelism": f"data-parallel x{e.world}, one {4 * sum(p.numel() for p in model.parameters())} B all-reduce per step"}}
     return rec
+
+
+def run_lightning_route(args, e, state_dict, R, gt, N):
+    """The step an UNMODIFIED train.py executes (nerf_system.py:70-121 under Lightning's automatic optimisation, train.py:48-64): the system's
+    own `configure_optimizers()` (torch.optim.Adam over the 24 parameter tensors + host-side MipLRDecay), then per batch
+    optimizer.zero_grad() -> training_step -> loss.backward() -> optimizer.step() -> scheduler.step(), eager, no opt-ins.  Timed twice: with
+    training_step routed onto the one-call native step behind a single autograd node (the default since round 6) and with the per-stage
+    autograd Functions of rounds 1-5 (`native_training_step = False`)."""
+    import torch
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    out = {}
+    for key, native in (("ms_per_step", True), ("per_stage_autograd_ms_per_step", False)):
+        hp = dict(DEFAULT_HPARAMS)
+        hp.update({"nerf.num_samples": N})
+        system = MipNeRFSystem(hp, precision=args.precision)
+        system.mip_nerf.load_state_dict(state_dict)
+        system = system.to(e.dev)
+        system.native_training_step = native
+        (opt,), (sch,) = system.configure_optimizers()
+        assert type(opt) is torch.optim.Adam
+
+        def step():
+            opt.zero_grad()
+            loss = system.training_step((R, gt), 0)
+            loss.backward()
+            opt.step()
+            sch["scheduler"].step()
+            return [(loss.detach().reshape(1),)]
+        step()
+        preheat(step, e)
+        dt, o = timed(e, step, args.warmup, args.steps)
+        assert bool(torch.isfinite(o[-1][0]).all())
+        out[key] = round(dt / args.steps * 1e3, 4)
+        if native:
+            out["routed_onto_native_step"] = bool(system._native_step_route(R))
+        del system, opt, sch
+    B = R.origins.shape[0]
+    out["value"] = round(B * N * 2 / (out["ms_per_step"] * 1e-3), 1)
+    out["workload"] = (f"MipNeRFSystem.training_step + loss.backward() + torch.optim.Adam.step() + MipLRDecay.step(), eager, {B} rays x ({N}+{N}) samples: "
+                       "what Lightning's automatic optimisation runs for an unmodified train.py")
+    return out
 
 
 def pmc_traffic(kind, precision, samples_per_launch=None, path=None):

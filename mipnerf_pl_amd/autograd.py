@@ -196,6 +196,49 @@ class _MLPNativeF32(torch.autograd.Function):
         return (None, d_enc, None, *nctx.split_grads(grad_flat, ctx.shapes))
 
 
+class _NativeStepLoss(torch.autograd.Function):
+    """The whole training step's loss as ONE autograd node (MipNerf.loss_native): forward = mipnerf_train_step (forward of both levels,
+    the loss of nerf_system.py:99-111, compositing / MLP backward, weight gradients) into a private flat gradient buffer; backward =
+    that buffer times the incoming scalar gradient, sliced into the parameters' shapes.  Nothing is recomputed and no activation is kept
+    alive between the two: what the node saves is the 2.45-MB gradient."""
+
+    @staticmethod
+    def forward(ctx, model, rays, gt_rgb, cfg, draws, *params):
+        dev = rays.origins.device
+        mlp = model.mlp
+        nctx = mlp.native(dev)
+        shapes = [p.shape for p in params]
+        grad = torch.empty(nctx.grad_numel(shapes), device=dev, dtype=torch.float32)
+        randomized, white_bkgd, clm, dlm, dml = cfg
+        scalars, _ = model._train_step_call(rays, gt_rgb, randomized, white_bkgd, clm, dlm, dml, draws[0], draws[1], draws[2], grad, 0)
+        ctx.nctx, ctx.shapes, ctx.mlp = nctx, shapes, mlp
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(scalars)
+        return scalars[0].clone(), scalars
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_scalars):
+        (grad,) = ctx.saved_tensors
+        flat = grad * g_loss                                     # one launch over the flat buffer (dL/dloss is 1 under loss.backward())
+        mlp = ctx.mlp
+        hooked = any(getattr(p, "_backward_hooks", None) for p in mlp.ordered_params())
+        if mlp.grads_are_flat() and not hooked:
+            # flat mode (MLP.flatten_parameters: this package's own loops): .grad aliases the flat buffer; add / write there, nothing to return
+            if mlp._flat_grad_valid:
+                mlp._flat_grad.add_(flat)
+            else:
+                mlp._flat_grad.copy_(flat)
+            mlp._flat_grad_valid = True
+            return (None,) * 5 + (None,) * len(ctx.shapes)
+        return (None,) * 5 + tuple(ctx.nctx.split_grads(flat, ctx.shapes))
+
+
+def native_step_loss(model, rays, gt_rgb, randomized, white_bkgd, coarse_loss_mult, distloss_mult, disable_multiscale_loss,
+                     t_rand=None, u_rand=None, density_randn=None):
+    cfg = (bool(randomized), bool(white_bkgd), float(coarse_loss_mult), float(distloss_mult), bool(disable_multiscale_loss))
+    return _NativeStepLoss.apply(model, rays, gt_rgb, cfg, (t_rand, u_rand, density_randn), *model.mlp.ordered_params())
+
+
 def mlp_native_f32(mlp, samples_enc, viewdirs_enc):
     """Differentiable fp32 MLP: samples_enc [B,N,96] fp32, viewdirs_enc [B,32] fp32 (27 + zero pad) -> raw [B,N,4]."""
     return _MLPNativeF32.apply(mlp, samples_enc, viewdirs_enc, *mlp.ordered_params())

@@ -569,24 +569,23 @@ class MipNerf(torch.nn.Module):
             ret.append(tuple(tens))
         return ret
 
-    def train_step_native(self, rays: Rays, gt_rgb, randomized: bool, white_bkgd: bool, coarse_loss_mult: float = 0.1,
-                          distloss_mult: float = 0.01, disable_multiscale_loss: bool = False, t_rand=None, u_rand=None,
-                          return_outputs: bool = False, density_randn=None):
-        """forward + loss (nerf_system.py:99-111) + backward of the whole hot path in ONE native call
-        (mipnerf_train_step): no autograd graph.  The gradient of the loss lands in the parameters' .grad (zero-copy
-        when the MLP is in flat mode, `mlp.flatten_parameters()`).  Returns (scalars [6] tensor = loss, mse_c, mse_f,
-        distloss_c, distloss_f, psnr_fine, outputs or None).  bf16 precision only."""
-        if self.precision != L.PREC_BF16:
-            raise NotImplementedError("train_step_native is the bf16 path; fp32 parity mode trains through autograd")
-        if not self.stop_resample_grad:
-            raise NotImplementedError("stop_resample_grad=False trains through autograd in fp32 precision (the one-call native step "
-                                      "implements the shipped stop-gradient resampler)")
+    def native_step_supported(self, device) -> bool:
+        """True when the one-call native training step (mipnerf_train_step) serves this model on `device`: bf16 precision, the shipped
+        stop-gradient resampler, an MLP shape with generated bf16 training kernels."""
+        if self.precision != L.PREC_BF16 or not self.stop_resample_grad or torch.device(device).type != "cuda":
+            return False
+        try:
+            ctx = self.mlp.native(torch.device(device))
+        except NotImplementedError:
+            return False
+        return int(L.lib().mipnerf_train_workspace_bytes(ctx.handle, 64)) > 0
+
+    def _train_step_call(self, rays: Rays, gt_rgb, randomized, white_bkgd, coarse_loss_mult, distloss_mult, disable_multiscale_loss,
+                         t_rand, u_rand, density_randn, grad, accumulate, return_outputs=False):
+        """One mipnerf_train_step launch sequence: loss scalars [6] + the flat gradient written (accumulate = 0) or added (1) into `grad`."""
         dev = rays.origins.device
-        if not rays.origins.is_cuda:
-            raise RuntimeError("train_step_native needs rays on a HIP device; there is no CPU fallback")
         B, N = rays.origins.shape[0], self.num_samples
-        mlp = self.mlp
-        ctx = mlp.native(dev)
+        ctx = self.mlp.native(dev)
         f = [ops._f32c(getattr(rays, k), k) for k in Rays._fields]
         rp = L.RaysPtrs(*[t.data_ptr() for t in f])
         gt = ops._f32c(gt_rgb[..., :3], "gt_rgb")
@@ -595,17 +594,10 @@ class MipNerf(torch.nn.Module):
             u_rand = torch.rand(B, N + 1, device=dev) if u_rand is None else ops._f32c(u_rand, "u_rand")
         dz = self._density_randn(randomized, B, dev, density_randn)
         need = int(L.lib().mipnerf_train_workspace_bytes(ctx.handle, B))
+        if need == 0:
+            raise NotImplementedError("the one-call native training step has no bf16 training kernels for this MLP shape "
+                                      "(csrc/gen_mlp_train.py); it trains through autograd (MipNerf.forward + loss.backward())")
         ws = ctx.scratch("train_step", need)
-        dropped = all(p.grad is None for p in mlp.ordered_params())
-        flat_mode = mlp.grads_are_flat() or (mlp.is_flat() and dropped)
-        if flat_mode:
-            if dropped:                         # zero_grad(set_to_none=True) of a foreign optimizer: start from zero
-                mlp._flat_grad_valid = False
-            mlp.gather_foreign_grads()          # re-attaches the .grad views
-            grad, accumulate = mlp._flat_grad, 1 if mlp._flat_grad_valid else 0
-        else:
-            total = ctx.grad_numel([p.shape for p in mlp.ordered_params()])
-            grad, accumulate = torch.empty(total, device=dev, dtype=torch.float32), 0
         scalars = torch.empty(6, device=dev, dtype=torch.float32)
         outs, ret = None, None
         if return_outputs:
@@ -621,7 +613,41 @@ class MipNerf(torch.nn.Module):
                                            u_rand.data_ptr() if randomized else None, None if dz is None else dz.data_ptr(),
                                            flags, float(coarse_loss_mult),
                                            float(distloss_mult), int(bool(disable_multiscale_loss)), ws.data_ptr(), ws.numel(),
-                                           grad.data_ptr(), accumulate, scalars.data_ptr(), outs, ops._stream()), "train_step")
+                                           grad.data_ptr(), int(accumulate), scalars.data_ptr(), outs, ops._stream()), "train_step")
+        return scalars, ret
+
+    def _check_native_step(self, rays):
+        if self.precision != L.PREC_BF16:
+            raise NotImplementedError("train_step_native is the bf16 path; fp32 parity mode trains through autograd")
+        if not self.stop_resample_grad:
+            raise NotImplementedError("stop_resample_grad=False trains through autograd in fp32 precision (the one-call native step "
+                                      "implements the shipped stop-gradient resampler)")
+        if not rays.origins.is_cuda:
+            raise RuntimeError("train_step_native needs rays on a HIP device; there is no CPU fallback")
+
+    def train_step_native(self, rays: Rays, gt_rgb, randomized: bool, white_bkgd: bool, coarse_loss_mult: float = 0.1,
+                          distloss_mult: float = 0.01, disable_multiscale_loss: bool = False, t_rand=None, u_rand=None,
+                          return_outputs: bool = False, density_randn=None):
+        """forward + loss (nerf_system.py:99-111) + backward of the whole hot path in ONE native call
+        (mipnerf_train_step): no autograd graph.  The gradient of the loss lands in the parameters' .grad (zero-copy
+        when the MLP is in flat mode, `mlp.flatten_parameters()`).  Returns (scalars [6] tensor = loss, mse_c, mse_f,
+        distloss_c, distloss_f, psnr_fine, outputs or None).  bf16 precision only."""
+        self._check_native_step(rays)
+        dev = rays.origins.device
+        mlp = self.mlp
+        ctx = mlp.native(dev)
+        dropped = all(p.grad is None for p in mlp.ordered_params())
+        flat_mode = mlp.grads_are_flat() or (mlp.is_flat() and dropped)
+        if flat_mode:
+            if dropped:                         # zero_grad(set_to_none=True) of a foreign optimizer: start from zero
+                mlp._flat_grad_valid = False
+            mlp.gather_foreign_grads()          # re-attaches the .grad views
+            grad, accumulate = mlp._flat_grad, 1 if mlp._flat_grad_valid else 0
+        else:
+            total = ctx.grad_numel([p.shape for p in mlp.ordered_params()])
+            grad, accumulate = torch.empty(total, device=dev, dtype=torch.float32), 0
+        scalars, ret = self._train_step_call(rays, gt_rgb, randomized, white_bkgd, coarse_loss_mult, distloss_mult, disable_multiscale_loss,
+                                             t_rand, u_rand, density_randn, grad, accumulate, return_outputs)
         if flat_mode:
             mlp._flat_grad_valid = True
         else:
@@ -629,6 +655,19 @@ class MipNerf(torch.nn.Module):
             for p, g in zip(ps, ctx.split_grads(grad, [p.shape for p in ps])):
                 p.grad = g if p.grad is None else p.grad.add_(g)
         return scalars, ret
+
+    def loss_native(self, rays: Rays, gt_rgb, randomized: bool, white_bkgd: bool, coarse_loss_mult: float = 0.1,
+                    distloss_mult: float = 0.01, disable_multiscale_loss: bool = False, t_rand=None, u_rand=None, density_randn=None):
+        """The training loss of nerf_system.py:99-111 as ONE autograd node over the parameters (round 6): its forward is the one-call
+        native step (forward of both levels + loss + the whole backward: the 3-kernel bf16 path), its backward hands the gradient that
+        call already computed -- scaled by the incoming dL/dloss -- to the parameters.  `loss.backward()`, AccumulateGrad, tensor hooks
+        and therefore DistributedDataParallel's reducer and any torch optimizer see ordinary per-parameter gradients, so a loop that
+        knows nothing about this package (Lightning's automatic optimisation, train.py:48-64) runs the fast path.
+        Returns (loss [] attached to the graph, scalars [6] detached = loss, mse_c, mse_f, distloss_c, distloss_f, psnr_fine)."""
+        self._check_native_step(rays)
+        from .autograd import native_step_loss
+        return native_step_loss(self, rays, gt_rgb, randomized, white_bkgd, coarse_loss_mult, distloss_mult, disable_multiscale_loss,
+                                t_rand, u_rand, density_randn)
 
     def _forward_native(self, rays, randomized, white_bkgd, t_rand=None, u_rand=None, density_randn=None, out=None, ws=None):
         """`out` (optional): preallocated per-level tuples (comp_rgb, distance, acc, weights, t_samples) to write into

@@ -110,7 +110,10 @@ class MipNeRFSystem(_Base):
             mlp_net_width_condition=hp['nerf.mlp.net_width_condition'], mlp_skip_index=hp['nerf.mlp.skip_index'],
             mlp_num_rgb_channels=hp['nerf.mlp.num_rgb_channels'],
             mlp_num_density_channels=hp['nerf.mlp.num_density_channels'],
-            mlp_net_activation=hp['nerf.mlp.net_activation'], precision=precision, unbounded=bool(hp.get('nerf.unbounded', False)))
+            mlp_net_activation=hp['nerf.mlp.net_activation'],
+            # (Lightning's load_from_checkpoint(path, precision=...) merges extra keywords INTO the stored hyper-parameters instead of
+            # passing them to the constructor, so the precision is also read from there)
+            precision=precision or hp.get('nerf.precision') or hp.get('precision'), unbounded=bool(hp.get('nerf.unbounded', False)))
 
     def forward(self, batch_rays, randomized: bool, white_bkgd: bool):
         return self.mip_nerf(batch_rays, randomized, white_bkgd)     # nerf_system.py:50-54
@@ -181,14 +184,40 @@ class MipNeRFSystem(_Base):
 
     def training_step(self, batch, batch_nb):   # nerf_system.py:95-121
         rays, rgbs = batch
-        ret = self(rays, self.train_randomized, self.white_bkgd)
-        loss, _, _ = self.compute_loss(ret, rays, rgbs)
-        with torch.no_grad():
-            psnr_fine = calc_psnr(ret[-1][0], rgbs[..., :3])
+        if self._native_step_route(rays):
+            # round 6: the same loss as ONE autograd node whose forward is the one-call native step (forward + loss + the 3-kernel bf16
+            # backward) and whose backward hands the finished gradient to the parameters: Lightning's automatic optimisation
+            # (loss.backward() -> any torch optimizer; DDP's reducer hooks fire as usual) runs the fast path without opting into anything
+            loss, scalars = self.mip_nerf.loss_native(
+                rays, rgbs, self.train_randomized, self.white_bkgd, coarse_loss_mult=self.hparams['loss.coarse_loss_mult'],
+                disable_multiscale_loss=self.hparams['loss.disable_multiscale_loss'])
+            psnr_fine = scalars[5]
+        else:
+            ret = self(rays, self.train_randomized, self.white_bkgd)
+            loss, _, _ = self.compute_loss(ret, rays, rgbs)
+            with torch.no_grad():
+                psnr_fine = calc_psnr(ret[-1][0], rgbs[..., :3])
         self.log('train/loss', loss)
         self.log('train/psnr', psnr_fine, prog_bar=True)
         self._log_lr()
         return loss
+
+    def _native_step_route(self, rays) -> bool:
+        """training_step goes through MipNerf.loss_native when the one-call native step serves this configuration (bf16, stop-gradient
+        resampler, an MLP shape with bf16 training kernels, rays on the GPU, gradients wanted).  `self.native_training_step = False` (or
+        MIPNERF_NATIVE_TRAINING_STEP=0) keeps the per-stage autograd Functions -- same kernels underneath, the route of the fp32 parity mode."""
+        import os
+        if not getattr(self, "native_training_step", os.environ.get("MIPNERF_NATIVE_TRAINING_STEP", "1") != "0"):
+            return False
+        if not (torch.is_grad_enabled() and rays.origins.is_cuda and rays.origins.shape[0] > 0):
+            return False
+        if not all(p.requires_grad for p in self.mip_nerf.parameters()):
+            return False
+        key = (self.mip_nerf.precision, rays.origins.device)
+        cache = self.__dict__.setdefault("_native_route_ok", {})
+        if key not in cache:
+            cache[key] = self.mip_nerf.native_step_supported(rays.origins.device)
+        return cache[key]
 
     def _log_lr(self):
         """nerf_system.py:117 `self.log('lr', ...)`: the learning rate of the first param group of the configured optimiser

@@ -1,0 +1,98 @@
+"""BASELINE configs[4] pinned against the reference END TO END.
+
+`tests/golden/frame_c5_800x800.npz` (scripts/make_golden.py --only-frame) is ONE whole 800 x 800 pose of the reference's spheric render
+path, rendered by the UNMODIFIED reference on CPU: rays from its `RenderGen` (render_video.py:29-112), chunked by its
+`rearrange_render_image` (mip.py:404-421), 79 chunk forwards of `MipNerf.forward` in the loop of `MipNeRFSystem.render_image`
+(nerf_system.py:151-177) on the trained field.  Here the same frame comes from the product route a user of render_video.py / eval.py would
+run: `datasets.RenderGen` (camera table -> rays generated ON THE DEVICE by k_generate_rays), `MipNeRFSystem.render_image` with
+`enable_hip_graph()` (model.GraphedFrame: the 79 chunks, the ragged last one of 1024 rays included, as one captured hipGraph).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_util
+    assert torch.cuda.is_available()
+    return gpu_util
+
+
+def _psnr(a, b):
+    return float(-10.0 * np.log10(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2) + 1e-30))
+
+
+def render_reference_frame(G, g, precision, graph=True):
+    """(coarse [1,H,W,3], fine [1,H,W,3], val_mask, distance [1,H,W], fine acc [H*W] or None) of the golden's pose through the product route"""
+    from mipnerf_pl_amd import Rays
+    from mipnerf_pl_amd.datasets import RenderGen
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    f = G.load_golden(str(g["field"]))
+    params = {k[2:]: f[k] for k in f if k.startswith("p_")}
+    h = hashlib.sha256()
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    assert h.hexdigest() == str(g["field_sha256"]), "golden was written for another trained_field.npz"
+    size, pose = int(g["cfg_size"]), int(g["cfg_pose"])
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({"nerf.num_samples": int(g["cfg_num_samples"]), "val.chunk_size": int(g["cfg_chunk"]), "val.randomized": False, "train.white_bkgd": True})
+    system = MipNeRFSystem(hp, precision=precision)
+    missing, unexpected = system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()}, strict=True)
+    assert not missing and not unexpected
+    system = system.to(DEV).eval()
+    if graph:
+        system.enable_hip_graph()
+    focal = .5 * size / np.tan(.5 * float(g["cfg_camera_angle_x"]))                 # render_video.py:125
+    assert focal == float(g["focal"])
+    ds = RenderGen(focal, [size, size], scales=1, device=torch.device(DEV))
+    assert len(ds) == 120
+    rays = ds[pose]                                                                 # [H, W, k], generated on the device
+    batch = Rays(*[x[None] for x in rays])                                          # DataLoader(batch_size=1), render_video.py:129-132
+    rgbs = torch.empty(1, size, size, 3, device=DEV)                                # render_image reads its shape only
+    coarse, fine, val_mask, dist = system.render_image((batch, rgbs), return_distance=True)
+    acc = system._graphed.acc[1].clone() if graph else None
+    if graph:
+        assert system._graphed.graph not in (None, False), "the frame did not run as a captured hipGraph"
+        assert system._graphed.n == size * size and (system._graphed.n % system._graphed.chunk) == 1024      # 79 chunks, ragged tail
+    return coarse, fine, val_mask, dist, acc
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_whole_rendergen_frame_vs_reference(G, precision):
+    g = G.load_golden("frame_c5_800x800")
+    size = int(g["cfg_size"])
+    coarse, fine, val_mask, dist, acc = render_reference_frame(G, g, precision)
+    assert coarse.shape == fine.shape == (1, size, size, 3) and dist.shape == (1, size, size) and val_mask.shape == (1, size, size, 1)
+    assert np.array_equal(val_mask.cpu().numpy(), g["val_mask"])
+    gt = g["gt_u8"].astype(np.float32) / 255.0
+    errs = dict(coarse_rgb=G.maxdiff(coarse, g["coarse_rgb"]), fine_rgb=G.maxdiff(fine, g["fine_rgb"]), distance=G.maxdiff(dist[0], g["distance"]),
+                acc=G.maxdiff(acc.reshape(size, size), g["acc"]),
+                psnr_vs_reference_frame=_psnr(fine.cpu().numpy(), g["fine_rgb"]), psnr_coarse_vs_reference_frame=_psnr(coarse.cpu().numpy(), g["coarse_rgb"]),
+                psnr_vs_scene=_psnr(fine[0].cpu().numpy(), gt), ref_psnr_vs_scene=float(g["psnr_fine"]))
+    tail = size * size - 1024                                                       # the ragged last chunk, on its own
+    errs["fine_rgb_tail_chunk"] = G.maxdiff(fine.reshape(-1, 3)[tail:], g["fine_rgb"].reshape(-1, 3)[tail:])
+    G.record(f"frame_c5 {precision}", **errs)
+    assert abs(_psnr(g["fine_rgb"][0], gt) - float(g["psnr_fine"])) < 1e-6          # the golden's own number regenerates
+    if precision == "fp32":
+        assert errs["coarse_rgb"] <= G.TOL_FP32["rgb"] and errs["fine_rgb"] <= G.TOL_FP32["rgb"], errs
+        assert errs["distance"] <= G.TOL_FP32["distance"] and errs["acc"] <= G.TOL_FP32["acc"], errs
+        assert abs(errs["psnr_vs_scene"] - errs["ref_psnr_vs_scene"]) < 1e-3, errs
+    else:
+        assert errs["psnr_vs_reference_frame"] >= 66.0 and errs["psnr_coarse_vs_reference_frame"] >= 66.0, errs
+        assert abs(errs["psnr_vs_scene"] - errs["ref_psnr_vs_scene"]) < 0.1, errs    # the north star's 0.1 dB, on a whole frame
+        assert errs["fine_rgb"] <= G.TOL_BF16["rgb"] and errs["acc"] <= G.TOL_BF16["acc"] and errs["distance"] <= G.TOL_BF16["distance"], errs
+
+
+def test_graphed_frame_equals_chunk_loop_on_the_reference_frame(G):
+    """the captured graph and the reference-shaped chunk loop of render_image (nerf_system.py:151-177) give the same bits on this frame"""
+    g = G.load_golden("frame_c5_800x800")
+    a = render_reference_frame(G, g, "bf16", graph=True)
+    b = render_reference_frame(G, g, "bf16", graph=False)
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)

@@ -435,14 +435,16 @@ def test_end_to_end_training_bf16_tracks_fp32(G):
 @pytest.mark.parametrize("flat", [True, False])
 def test_native_train_step_equals_autograd_path(G, flat):
     """mipnerf_train_step (forward + loss + backward in one native call, no autograd graph) against
-    training_step + loss.backward() through the custom autograd Functions: same kernels underneath, so loss and every
-    gradient must agree to fp32 round-off (the loss reduction runs in fp64 instead of torch's fp32)."""
+    training_step + loss.backward() through the per-stage custom autograd Functions: same kernels underneath, so loss and every
+    gradient must agree to fp32 round-off (the loss reduction runs in fp64 instead of torch's fp32).  Round 6: the DEFAULT
+    training_step (one autograd node whose forward is that native call, MipNerf.loss_native) + loss.backward() must give the
+    native call's loss and gradient BIT FOR BIT, and twice that after a second backward (AccumulateGrad)."""
     from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
     g = G.load_golden("train_64x64_trained")
     rays, gt = G.to_dev(G.rays_of(g)), torch.from_numpy(g["gt"]).to(DEV)
     params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
     res = {}
-    for native in (False, True):
+    for route in ("per_stage", "native_call", "routed"):
         hp = dict(DEFAULT_HPARAMS)
         hp.update({'nerf.num_samples': 64, 'train.randomized': False})
         system = MipNeRFSystem(hp, precision="bf16")
@@ -450,25 +452,65 @@ def test_native_train_step_equals_autograd_path(G, flat):
         system = system.to(DEV)
         if flat:
             system.mip_nerf.mlp.flatten_parameters()
-        if native:
+        if route == "native_call":
             loss = system.training_step_native((rays, gt), 0)
             loss2 = system.training_step_native((rays, gt), 1)          # second call accumulates like a second backward()
-            grads2 = torch.cat([p.grad.reshape(-1) for p in system.mip_nerf.parameters()]).clone()
         else:
+            system.native_training_step = route == "routed"
+            assert system._native_step_route(rays) == (route == "routed")
             loss = system.training_step((rays, gt), 0)
+            assert loss.requires_grad and loss.shape == ()
             loss.backward()
+            if route == "routed":
+                g1 = torch.cat([p.grad.reshape(-1) for p in system.mip_nerf.parameters()]).clone()
+                loss2 = system.training_step((rays, gt), 1)
+                loss2.backward()
         grads = torch.cat([p.grad.reshape(-1) for p in system.mip_nerf.parameters()]).clone()
-        res[native] = (float(loss), grads, float(system.logged['train/psnr']))
-        if native:
+        res[route] = (float(loss), grads, float(system.logged['train/psnr']))
+        if route != "per_stage":
             assert abs(float(loss2) - float(loss)) < 1e-7
-            assert G.maxdiff(grads2, 2.0 * res[False][1]) <= 2e-5 * float(res[False][1].abs().max())
-            grads = grads2 / 2.0
-            res[native] = (float(loss), grads, res[native][2])
-    (l0, g0, p0), (l1, g1, p1) = res[False], res[True]
+            assert G.maxdiff(grads, 2.0 * res["per_stage"][1]) <= 2e-5 * float(res["per_stage"][1].abs().max())
+            res[route] = (float(loss), grads / 2.0 if route == "native_call" else g1, res[route][2])
+    (l0, g0, p0), (l1, g1, p1), (l2, g2, p2) = res["per_stage"], res["native_call"], res["routed"]
     eg = G.maxdiff(g0, g1) / float(g0.abs().max())
-    G.record(f"native_train_step flat={flat}", loss_autograd=l0, loss_native=l1, grad_rel=eg, psnr_autograd=p0, psnr_native=p1)
+    G.record(f"native_train_step flat={flat}", loss_autograd=l0, loss_native=l1, grad_rel=eg, psnr_autograd=p0, psnr_native=p1,
+             routed_vs_native_call=G.maxdiff(g2, g1))
     assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0)) and abs(p0 - p1) <= 1e-3 and eg <= 2e-5
     assert abs(l1 - float(g["loss"])) <= 5e-3      # and the bf16 loss is the reference's loss (fp32) to bf16 accuracy
+    # the routed training_step IS the native call: same loss bits, same psnr bits, and (first backward: gradient x 1.0) the same gradient
+    # bits up to the halving of the accumulated native gradient above (exact in binary floating point unless a value is denormal)
+    assert l2 == l1 and p2 == p1 and G.maxdiff(g2, g1) <= 1e-12 * float(g1.abs().max()) + 1e-30
+
+
+def test_routed_training_step_scales_with_the_incoming_gradient_and_feeds_hooks(G):
+    """MipNerf.loss_native is an ordinary autograd node: (3 * loss).backward() gives 3 x the gradient, torch.autograd.grad returns the
+    per-parameter gradients, and tensor hooks on the parameters (what DistributedDataParallel's reducer registers) fire once each."""
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    g = G.load_golden("train_64x64_trained")
+    rays, gt = G.to_dev(G.rays_of(g)), torch.from_numpy(g["gt"]).to(DEV)
+    params = orc.make_params(seed=int(g["param_seed"]), density_gain=float(g["density_gain"]))
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({'nerf.num_samples': 64, 'train.randomized': False})
+    system = MipNeRFSystem(hp, precision="bf16")
+    system.load_state_dict({"mip_nerf.mlp." + k: torch.from_numpy(v.copy()) for k, v in params.items()})
+    system = system.to(DEV)
+    ps = list(system.mip_nerf.parameters())
+    loss = system.training_step((rays, gt), 0)
+    base = torch.autograd.grad(loss, ps)
+    assert all(b is not None and b.shape == p.shape for b, p in zip(base, ps)) and all(p.grad is None for p in ps)
+    fired = []
+    handles = [p.register_hook(lambda gr, i=i: fired.append(i)) for i, p in enumerate(ps)]
+    (3.0 * system.training_step((rays, gt), 1)).backward()
+    assert sorted(fired) == list(range(len(ps)))
+    for p, b in zip(ps, base):
+        assert G.maxdiff(p.grad, 3.0 * b) <= 1e-6 * float(b.abs().max()) + 1e-30
+    for h in handles:
+        h.remove()
+    # evaluation / no_grad and frozen parameters keep the ordinary routes
+    with torch.no_grad():
+        assert not system._native_step_route(rays)
+    ps[0].requires_grad_(False)
+    assert not system._native_step_route(rays)
 
 
 def test_mlp_module_forward_is_differentiable(G):

@@ -247,3 +247,33 @@ def test_360_oracle_blocks_pinned_by_the_reference_where_it_is_right():
         assert np.array_equal(t_inv, g[f"{tag}_t_inv"])                              # bit-exact fence posts
         assert np.abs(m - g[f"{tag}_means"]).max() <= 2e-7 * np.abs(g[f"{tag}_means"]).max()
         assert np.array_equal(t, (np.float32(1) / t_inv).astype(np.float32))
+
+
+def test_oracle_renders_chunks_of_the_reference_frame(golden_dir):
+    """Round 6: tests/golden/frame_c5_800x800.npz is ONE whole 800 x 800 RenderGen pose rendered by the unmodified reference (BASELINE
+    configs[4]; scripts/make_golden.py --only-frame).  The oracle -- rays restated from the stored pose (RenderGen's pixel -> ray rule is
+    Multicam's, render_video.py:60-80), forward on the trained field -- reproduces two of its 79 chunks on CPU: a slice of the middle of
+    the image and the ragged 1024-ray tail."""
+    import hashlib
+    g = load(golden_dir, "frame_c5_800x800")
+    f = load(golden_dir, str(g["field"]))
+    params = {k[2:]: f[k] for k in f if k.startswith("p_")}
+    h = hashlib.sha256()
+    for k in sorted(params):
+        h.update(np.ascontiguousarray(params[k]).tobytes())
+    assert h.hexdigest() == str(g["field_sha256"])
+    size, focal = int(g["cfg_size"]), float(g["focal"])
+    assert g["fine_rgb"].shape == (1, size, size, 3) and g["distance"].shape == (size, size) and size * size % int(g["cfg_chunk"]) == 1024
+    assert np.array_equal(g["val_mask"], np.ones((1, size, size, 1), np.float32))                    # lossmult (mip.py:407)
+    p2c = np.array([[1.0 / focal, 0.0, -0.5 * size / focal], [0.0, -1.0 / focal, 0.5 * size / focal], [0.0, 0.0, -1.0]])
+    R = orc.generate_rays_multicam(g["pose"][:3], p2c, size, size, 2.0, 6.0, 1.0)
+    flat = orc.Rays(*[a.reshape(size * size, -1) for a in R])
+    for lo, n in ((size * size - 1024, 1024), (400 * size + 100, 600)):
+        part = orc.Rays(*[a[lo:lo + n] for a in flat])
+        ret = orc.mipnerf_forward(params, part, False, True, num_samples=int(g["cfg_num_samples"]))
+        for name, lvl, k in (("coarse_rgb", 0, 0), ("fine_rgb", 1, 0), ("distance", 1, 1), ("acc", 1, 2)):
+            want = g[name].reshape(size * size, -1)[lo:lo + n]
+            got = np.asarray(ret[lvl][k]).reshape(n, -1)
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-4, err_msg=f"{name} rays {lo}..{lo + n}")
+    gt = g["gt_u8"].astype(np.float32) / 255.0
+    assert abs(float(-10.0 * np.log10(np.mean((g["fine_rgb"][0].astype(np.float64) - gt) ** 2))) - float(g["psnr_fine"])) < 1e-6
