@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MIPNERF_ABI_VERSION 5
+#define MIPNERF_ABI_VERSION 6
 
 enum {
     MIPNERF_OK = 0,
@@ -220,6 +220,12 @@ int mipnerf_sorted_piecewise_constant_pdf(int64_t num_rays, int32_t num_bins, co
  * neighbouring pixel along image rows, last row repeated, times 2/sqrt(12). */
 int mipnerf_generate_rays(int64_t num_rays, const float* cameras, const int32_t* cam_idx,
                           const int32_t* pix_idx, const mipnerf_rays_out* out, void* stream);
+/* The same with a camera table of DOUBLES and float64 arithmetic, results rounded to float32 once at the end: `RenderGen`
+ * (render_video.py:29-112) forms its rays in float64 numpy from the float64 poses of create_spheric_poses and casts with .float()
+ * (render_video.py:131); the radii are the norm of a DIFFERENCE of neighbouring directions (1e-3 of their size), which float32
+ * arithmetic gets to 1e-4 relative only. */
+int mipnerf_generate_rays_f64(int64_t num_rays, const double* cameras, const int32_t* cam_idx,
+                              const int32_t* pix_idx, const mipnerf_rays_out* out, void* stream);
 
 /* ---- unbounded scenes (mip-NeRF 360) --------------------------------------------------------------------------------
  * Correct versions of what the reference's dead code aims at (models/mip.py:106-124 sample_along_rays_360, :38-47 full
@@ -296,9 +302,19 @@ int mipnerf_resample_along_rays_bwd(int64_t num_rays, int32_t num_samples, const
  * `partials` are scratch.  Buffer sizes for M samples come from mipnerf_mlp_train_sizes. */
 int mipnerf_mlp_train_sizes(const mipnerf_ctx* ctx, int64_t num_points, size_t* act_bytes,
                             size_t* mask_bytes, size_t* delta_bytes, size_t* partial_bytes);
+/* `enc`: bf16, row-major [num_points, xyz_dim].  LIFETIME (two-kernel variants, i.e. contexts with unbounded = 1): their weight-gradient
+ * jobs read the ENCODING ITSELF -- `act` ends in a record of the `enc` pointer -- so `enc` must stay allocated and unmodified until the
+ * mipnerf_mlp_backward / mipnerf_mlp_wgrad call that consumes this `act` has been issued on the same stream; the standard shapes transpose
+ * their 96 features into `act` and do not look at `enc` again. */
 int mipnerf_mlp_forward_train(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples,
                               const void* enc, const void* viewenc, float* rgb_sigma, float* raw,
                               void* act, void* masks, void* stream);
+/* The same with `enc` in the MFMA-fragment layout mipnerf_cast_ipe_360 writes for MIPNERF_OUT_BF16_FRAGMENTS (whole 256-sample tiles;
+ * k_pre_gemm and the weight-gradient jobs read it lane-linearly).  Two-kernel variants only: MIPNERF_E_UNSUPPORTED for every other
+ * context (a fragment buffer must never be read as rows).  Same lifetime rule for `enc`.  (ABI 6: replaces the per-context option 6.) */
+int mipnerf_mlp_forward_train_fragments(mipnerf_ctx* ctx, int64_t num_points, int32_t num_samples,
+                                        const void* enc, const void* viewenc, float* rgb_sigma, float* raw,
+                                        void* act, void* masks, void* stream);
 int mipnerf_mlp_backward(mipnerf_ctx* ctx, int64_t num_points, const float* d_raw, const void* act,
                          const void* masks, void* delta, float* partials, float* grad_flat,
                          int32_t accumulate, void* stream);
@@ -387,8 +403,7 @@ int mipnerf_selftest(void* stream);
  * coarse fence posts as ONE launch and the coarse level's compositing + the fine level's resampling as ONE launch (N <= 128 or 192 < N <= 256; the
  * weights go from registers to the sampler's LDS row), 0 = one launch per stage (same bits); option 5: 1 [default] = fp32 inference (mipnerf_mlp_forward,
  * mipnerf_forward) runs the register-resident kernel k_mlp_f32r where one was generated for the architecture (widths <= 256), 0 = the LDS-resident
- * k_mlp_f32 (same function, another summation order: results agree to fp32 rounding); option 6: 1 = the `enc` argument of
- * mipnerf_mlp_forward_train is in the fragment layout (MIPNERF_OUT_BF16_FRAGMENTS; two-kernel variants only), 0 [default] = row-major. */
+ * k_mlp_f32 (same function, another summation order: results agree to fp32 rounding). */
 int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
 /* Sum of the elapsed times (ms) and the number of MLP launches recorded since the last call
  * (option 2); synchronises on the recorded events. */

@@ -71,6 +71,7 @@ SIGNATURES = {
     "mipnerf_cast_ipe_360": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
     "mipnerf_gauss_360": (C.c_int, [_I64, _I32, _I32, _I32, _P, _P, _P, C.c_int, _P, _P, _P]),
     "mipnerf_generate_rays": (C.c_int, [_I64, _P, _P, _P, C.POINTER(RaysPtrs), _P]),
+    "mipnerf_generate_rays_f64": (C.c_int, [_I64, _P, _P, _P, C.POINTER(RaysPtrs), _P]),
     "mipnerf_eval_workspace_floats": (_I64, [_I32, _I32]),
     "mipnerf_eval_errors": (C.c_int, [_I32, _I32, _P, _P, _P, _P, _P]),
     "mipnerf_activate": (C.c_int, [_I64, _P, _F, _F, _P, _F, _P, _P]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "mipnerf_resample_along_rays_bwd": (C.c_int, [_I64, _I32, _P, _P, _P, _F, _P, _P, _P]),
     "mipnerf_mlp_train_sizes": (C.c_int, [_P, _I64, C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ), C.POINTER(_SZ)]),
     "mipnerf_mlp_forward_train": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "mipnerf_mlp_forward_train_fragments": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "mipnerf_mlp_backward": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "mipnerf_adam_step": (C.c_int, [_I64, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, _I32, _P]),
     "mipnerf_adam_step_scheduled": (C.c_int, [_I64, _P, _P, _P, _P, C.POINTER(LrSchedule), _P, _P, _P]),

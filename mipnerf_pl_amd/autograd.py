@@ -107,15 +107,10 @@ class _MLPNative(torch.autograd.Function):
         masks = torch.empty(sz[1], dtype=torch.uint8, device=dev)
         raw = torch.empty(B, N, 4, device=dev, dtype=torch.float32)
         rgb_sigma = torch.empty_like(raw)
-        if frag_shape is not None:
-            nctx.set_option(6, 1)
-        try:
-            L.check(L.lib().mipnerf_mlp_forward_train(nctx.handle, M, N, enc.data_ptr(), venc.data_ptr(), rgb_sigma.data_ptr(),
-                                                      raw.data_ptr(), act.data_ptr(), masks.data_ptr(), ops._stream()),
-                    "mlp_forward_train")
-        finally:
-            if frag_shape is not None:
-                nctx.set_option(6, 0)
+        # fragment encodings go through their own entry point (ABI 6; a per-context toggle was not safe across threads / streams)
+        fwd = L.lib().mipnerf_mlp_forward_train_fragments if frag_shape is not None else L.lib().mipnerf_mlp_forward_train
+        L.check(fwd(nctx.handle, M, N, enc.data_ptr(), venc.data_ptr(), rgb_sigma.data_ptr(), raw.data_ptr(), act.data_ptr(), masks.data_ptr(),
+                    ops._stream()), "mlp_forward_train")
         ctx.save_for_backward(act, masks)
         # wide encodings (the unbounded-scene model's two-kernel form): the weight-gradient kernel reads the ENCODING itself (rows or fragments) --
         # the act buffer records its address -- so it must outlive the forward; the standard shapes transposed their 96 features into `act`

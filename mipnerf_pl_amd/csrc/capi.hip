@@ -268,7 +268,6 @@ struct mipnerf_ctx {
     float* d_stream_f32r = nullptr;
     float* d_aux_f32r = nullptr;
     int f32_resident = 1;            // option 5: 1 = k_mlp_f32r where generated (inference), 0 = the LDS-resident k_mlp_f32
-    int train_enc_frag = 0;          // option 6: mipnerf_mlp_forward_train's enc is in the fragment layout (two-kernel variants)
     // two-kernel bf16 inference of the variants whose encoding does not fit k_mlp_bf16's wave-private LDS area (gen_pre_gemm.py):
     // k_pre_gemm's weight stream + accumulator images, the trunk kernel's stream + bias table, and scratch for the per-stage entry point
     PreTables pre;
@@ -594,7 +593,6 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
         case 3: c->fused_ipe = value ? 1 : 0; return MIPNERF_OK;
         case 4: c->fuse_small = value ? 1 : 0; return MIPNERF_OK;
         case 5: c->f32_resident = value ? 1 : 0; return MIPNERF_OK;
-        case 6: c->train_enc_frag = value ? 1 : 0; return MIPNERF_OK;
         default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
     }
 }
@@ -804,6 +802,16 @@ int mipnerf_generate_rays(int64_t n, const float* cameras, const int32_t* cam_id
     return MIPNERF_OK;
 }
 
+int mipnerf_generate_rays_f64(int64_t n, const double* cameras, const int32_t* cam_idx, const int32_t* pix_idx,
+                              const mipnerf_rays_out* out, void* stream) {
+    if (n < 1 || !cameras || !out || !out->origins || !out->directions || !out->viewdirs || !out->radii ||
+        !out->lossmult || !out->near || !out->far)
+        return fail(MIPNERF_E_INVALID, "generate_rays_f64: bad argument");
+    HIP_TRY(mip::launch_generate_rays_f64(n, cameras, cam_idx, pix_idx, out->origins, out->directions, out->viewdirs,
+                                          out->radii, out->lossmult, out->near, out->far, S(stream)));
+    return MIPNERF_OK;
+}
+
 // ---- evaluation metrics (utils/metrics.py:191-197) ---------------------------------------------------------------
 int64_t mipnerf_eval_workspace_floats(int32_t height, int32_t width) {
     return height > 0 && width > 0 ? mip::eval_errors_partial_floats(height, width) : 0;
@@ -919,7 +927,14 @@ static int mlp_forward_train_noise(mipnerf_ctx* c, int64_t M, int32_t N, const v
 
 int mipnerf_mlp_forward_train(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, float* rgb_sigma,
                               float* raw, void* act, void* masks, void* stream) {
-    return mlp_forward_train_noise(c, M, N, enc, viewenc, rgb_sigma, raw, act, masks, nullptr, stream, c && c->train_enc_frag && has_bf16_train_pre(c->P));
+    return mlp_forward_train_noise(c, M, N, enc, viewenc, rgb_sigma, raw, act, masks, nullptr, stream, false);
+}
+
+int mipnerf_mlp_forward_train_fragments(mipnerf_ctx* c, int64_t M, int32_t N, const void* enc, const void* viewenc, float* rgb_sigma,
+                                        float* raw, void* act, void* masks, void* stream) {
+    if (c && !has_bf16_train_pre(c->P))
+        return fail(MIPNERF_E_UNSUPPORTED, "mlp_forward_train_fragments: this context has no two-kernel (pre-GEMM) training form; its kernels read row-major encodings");
+    return mlp_forward_train_noise(c, M, N, enc, viewenc, rgb_sigma, raw, act, masks, nullptr, stream, true);
 }
 
 int mipnerf_mlp_dgrad(mipnerf_ctx* c, int64_t M, const float* d_raw, const void* masks, void* delta, void* stream) {

@@ -45,6 +45,9 @@ hipError_t launch_piecewise_constant_pdf(int64_t B, int N, const float* bins, co
 hipError_t launch_generate_rays(int64_t n, const float* cams, const int32_t* cam_idx, const int32_t* pix_idx,
                                 float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
                                 float* nearp, float* farp, hipStream_t st);
+hipError_t launch_generate_rays_f64(int64_t n, const double* cams, const int32_t* cam_idx, const int32_t* pix_idx,
+                                    float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
+                                    float* nearp, float* farp, hipStream_t st);
 
 // ---- kernels_360.hip (unbounded scenes: s-space sampling, contraction, off-axis IPE; raymath360.hpp) ----
 hipError_t launch_reciprocal(int64_t n, const float* x, float* y, hipStream_t st);

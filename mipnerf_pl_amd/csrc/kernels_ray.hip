@@ -450,15 +450,19 @@ hipError_t launch_ray_prologue(int64_t B, int deg, const float* viewdirs, void* 
 // the neighbour is taken along axis 0 = image rows).
 namespace mip {
 namespace {
-__device__ __forceinline__ void pixel_direction(const float* __restrict__ cam, float x, float y, float d[3]) {
-    float c0, c1, c2;
-    if (cam[26] == 0.0f) {
-        const float W = cam[21], H = cam[22], f = cam[27];
-        c0 = (x - W * 0.5f + 0.5f) / f;
-        c1 = -(y - H * 0.5f + 0.5f) / f;
-        c2 = -1.0f;
+// T = float: the arithmetic of Blender / Multicam._generate_rays (float32 numpy); T = double: RenderGen (render_video.py:29-112 runs on the
+// float64 poses of create_spheric_poses, so its directions and above all its radii -- the norm of a DIFFERENCE of neighbouring directions,
+// 1e-3 of their size -- carry float64 accuracy before the .float() of render_video.py:131)
+template <typename T>
+__device__ __forceinline__ void pixel_direction(const T* __restrict__ cam, T x, T y, T d[3]) {
+    T c0, c1, c2;
+    if (cam[26] == T(0)) {
+        const T W = cam[21], H = cam[22], f = cam[27];
+        c0 = (x - W * T(0.5) + T(0.5)) / f;
+        c1 = -(y - H * T(0.5) + T(0.5)) / f;
+        c2 = T(-1);
     } else {
-        const float px = x + 0.5f, py = y + 0.5f;
+        const T px = x + T(0.5), py = y + T(0.5);
         c0 = cam[12] * px + cam[13] * py + cam[14];
         c1 = cam[15] * px + cam[16] * py + cam[17];
         c2 = cam[18] * px + cam[19] * py + cam[20];
@@ -468,40 +472,49 @@ __device__ __forceinline__ void pixel_direction(const float* __restrict__ cam, f
 }
 }  // namespace
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_generate_rays(int64_t n, const float* __restrict__ cams, const int32_t* __restrict__ cam_idx,
+k_generate_rays(int64_t n, const T* __restrict__ cams, const int32_t* __restrict__ cam_idx,
                 const int32_t* __restrict__ pix_idx, float* __restrict__ origins, float* __restrict__ directions,
                 float* __restrict__ viewdirs, float* __restrict__ radii, float* __restrict__ lossmult,
                 float* __restrict__ nearp, float* __restrict__ farp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float* cam = cams + (size_t)(cam_idx ? cam_idx[i] : 0) * 32;
+    const T* cam = cams + (size_t)(cam_idx ? cam_idx[i] : 0) * 32;
     const int W = (int)cam[21], H = (int)cam[22];
     const int p = pix_idx ? pix_idx[i] : (int)i;
     const int yy = p / W, xx = p - yy * W;
-    float d[3], dn[3];
-    pixel_direction(cam, (float)xx, (float)yy, d);
+    T d[3], dn[3];
+    pixel_direction<T>(cam, (T)xx, (T)yy, d);
     const int yn = yy + 1 < H ? yy + 1 : yy - 1;
-    pixel_direction(cam, (float)xx, (float)yn, dn);
-    const float e0 = d[0] - dn[0], e1 = d[1] - dn[1], e2 = d[2] - dn[2];
-    const float dx = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
-    const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    pixel_direction<T>(cam, (T)xx, (T)yn, dn);
+    const T e0 = d[0] - dn[0], e1 = d[1] - dn[1], e2 = d[2] - dn[2];
+    const T dx = sqrt(e0 * e0 + e1 * e1 + e2 * e2);
+    const T nrm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        origins[i * 3 + k] = cam[4 * k + 3];
-        directions[i * 3 + k] = d[k];
-        viewdirs[i * 3 + k] = d[k] / nrm;
+        origins[i * 3 + k] = (float)cam[4 * k + 3];
+        directions[i * 3 + k] = (float)d[k];
+        viewdirs[i * 3 + k] = (float)(d[k] / nrm);
     }
-    radii[i] = dx * 2.0f / 3.4641016151377544f;
-    lossmult[i] = cam[25];
-    nearp[i] = cam[23];
-    farp[i] = cam[24];
+    radii[i] = (float)(dx * T(2) / (T)(sizeof(T) == 4 ? 3.4641016151377544f : 3.4641016151377544));      // np.sqrt(12) in the table's precision
+    lossmult[i] = (float)cam[25];
+    nearp[i] = (float)cam[23];
+    farp[i] = (float)cam[24];
 }
 
 hipError_t launch_generate_rays(int64_t n, const float* cams, const int32_t* cam_idx, const int32_t* pix_idx,
                                 float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
                                 float* nearp, float* farp, hipStream_t st) {
-    hipLaunchKernelGGL(k_generate_rays, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, cams, cam_idx, pix_idx,
+    hipLaunchKernelGGL(k_generate_rays<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, cams, cam_idx, pix_idx,
+                       origins, directions, viewdirs, radii, lossmult, nearp, farp);
+    return hipGetLastError();
+}
+
+hipError_t launch_generate_rays_f64(int64_t n, const double* cams, const int32_t* cam_idx, const int32_t* pix_idx,
+                                    float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
+                                    float* nearp, float* farp, hipStream_t st) {
+    hipLaunchKernelGGL(k_generate_rays<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, cams, cam_idx, pix_idx,
                        origins, directions, viewdirs, radii, lossmult, nearp, farp);
     return hipGetLastError();
 }

@@ -321,7 +321,8 @@ class RenderGen(torch.utils.data.Dataset):
             w, h, f = base_size[0] / 2 ** i, base_size[1] / 2 ** i, base_focal / 2 ** i
             pix2cam = np.array([[1.0 / f, 0.0, -0.5 * w / f], [0.0, -1.0 / f, 0.5 * h / f], [0.0, 0.0, -1.0]])
             for m in c2w:
-                records.append(ops.camera_record(m.astype(np.float32), w, h, self.near, self.far, pix2cam=pix2cam))
+                # float64 table -> float64 ray arithmetic on the device, as the reference's numpy (its poses and pix2cam are float64)
+                records.append(ops.camera_record(np.asarray(m, np.float64), w, h, self.near, self.far, pix2cam=pix2cam, dtype=torch.float64))
                 self.sizes.append((int(h), int(w)))
         self.n_sample = len(records)
         self.cameras = torch.stack(records)

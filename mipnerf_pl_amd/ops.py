@@ -186,15 +186,16 @@ def volumetric_rendering_packed(rgb_sigma, t_samples, dirs, white_bkgd):
     return comp_rgb, distance, acc, weights
 
 
-def camera_record(c2w, width, height, near, far, focal=None, pix2cam=None, lossmult=1.0):
-    """One row of the camera table of `generate_rays` (32 floats, include/mipnerf_hip.h): Blender pinhole camera
-    when `focal` is given (datasets.py:226-228), Multicam when `pix2cam` is given (datasets.py:125-131)."""
-    rec = torch.zeros(32, dtype=torch.float32)
-    rec[0:12] = torch.as_tensor(c2w, dtype=torch.float32)[:3, :4].reshape(-1)
+def camera_record(c2w, width, height, near, far, focal=None, pix2cam=None, lossmult=1.0, dtype=torch.float32):
+    """One row of the camera table of `generate_rays` (32 numbers, include/mipnerf_hip.h): Blender pinhole camera
+    when `focal` is given (datasets.py:226-228), Multicam when `pix2cam` is given (datasets.py:125-131).
+    dtype=torch.float64: a table for float64 ray arithmetic (RenderGen, render_video.py:29-112)."""
+    rec = torch.zeros(32, dtype=dtype)
+    rec[0:12] = torch.as_tensor(c2w, dtype=dtype)[:3, :4].reshape(-1)
     if (focal is None) == (pix2cam is None):
         raise ValueError("give exactly one of focal (Blender) / pix2cam (Multicam)")
     if pix2cam is not None:
-        rec[12:21] = torch.as_tensor(pix2cam, dtype=torch.float32)[:3, :3].reshape(-1)
+        rec[12:21] = torch.as_tensor(pix2cam, dtype=dtype)[:3, :3].reshape(-1)
         rec[26] = 1.0
     else:
         rec[27] = float(focal)
@@ -204,9 +205,16 @@ def camera_record(c2w, width, height, near, far, focal=None, pix2cam=None, lossm
 
 def generate_rays(cameras, num_rays=None, cam_idx=None, pix_idx=None):
     """Rays of datasets.py:214-263 / 116-168 computed on the device: `cameras` [ncam, 32] float32 HIP tensor of
-    `camera_record` rows, ray i = pixel pix_idx[i] (y*W + x; None = i) of camera cam_idx[i] (None = 0)."""
+    `camera_record` rows, ray i = pixel pix_idx[i] (y*W + x; None = i) of camera cam_idx[i] (None = 0).
+    A float64 table selects float64 arithmetic (mipnerf_generate_rays_f64); the rays are float32 either way."""
     from .rays import Rays
-    cameras = _f32c(cameras, "cameras").reshape(-1, 32)
+    f64 = cameras.dtype == torch.float64
+    if f64:
+        if not cameras.is_cuda:
+            raise RuntimeError("cameras: needs a HIP device tensor")
+        cameras = cameras.contiguous().reshape(-1, 32)
+    else:
+        cameras = _f32c(cameras, "cameras").reshape(-1, 32)
     dev = cameras.device
     if num_rays is None:
         num_rays = int(pix_idx.numel()) if pix_idx is not None else int(cameras[0, 21].item() * cameras[0, 22].item())
@@ -221,8 +229,8 @@ def generate_rays(cameras, num_rays=None, cam_idx=None, pix_idx=None):
     out = [torch.empty(num_rays, k, device=dev, dtype=torch.float32) for k in (3, 3, 3, 1, 1, 1, 1)]
     rp = L.RaysPtrs(*[t.data_ptr() for t in out])
     import ctypes as C
-    L.check(L.lib().mipnerf_generate_rays(num_rays, _ptr(cameras), _ptr(ci), _ptr(pi), C.byref(rp), _stream()),
-            "generate_rays")
+    fn = L.lib().mipnerf_generate_rays_f64 if f64 else L.lib().mipnerf_generate_rays
+    L.check(fn(num_rays, _ptr(cameras), _ptr(ci), _ptr(pi), C.byref(rp), _stream()), "generate_rays")
     return Rays(*out)
 
 

@@ -52,7 +52,7 @@ def test_dynamic_symbol_table_is_exactly_the_c_abi(lib):
 
 
 def test_abi_version_and_compiled_arch(lib):
-    assert lib.mipnerf_abi_version() == 5
+    assert lib.mipnerf_abi_version() == 6
     cfg = L.Config()
     assert lib.mipnerf_compiled_arch(C.byref(cfg)) == 0
     assert (cfg.net_depth, cfg.net_width, cfg.net_depth_condition, cfg.net_width_condition, cfg.skip_index) == (8, 256, 1, 128, 4)
