@@ -34,7 +34,7 @@ sys.path.insert(0, REPO)
 
 FLOP_PER_SAMPLE = 1_220_608          # 2 x 610,304 MAC of the MLP per ray-sample (forward)
 FLOP_PER_SAMPLE_TRAIN = 3_556_608    # forward + dgrad + wgrad
-CURRENT_ROUND = 5          # profiles/mlp_pmc.json must carry this round's PMC passes (VERDICT r03 hygiene): bump it and re-run scripts/pmc_traffic.sh every round
+CURRENT_ROUND = 6          # profiles/mlp_pmc.json must carry this round's PMC passes (VERDICT r03 hygiene): bump it and re-run scripts/pmc_traffic.sh every round
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
@@ -117,6 +117,28 @@ def setup(args):
             s_.close()
         dist.init_process_group(os.environ.get("MIPNERF_BENCH_BACKEND", "nccl"), rank=0, world_size=1)
     return e
+
+
+def rank_report(e):
+    """Who ran: per rank its device, so that a multi-GPU record explains itself -- "RCCL saw N ranks on N distinct GPUs".
+    Collective when world > 1 (all ranks call it)."""
+    import torch
+    import torch.distributed as dist
+    p = torch.cuda.get_device_properties(e.dev)
+    me = {"rank": e.rank, "local_rank": e.local_rank, "device": str(e.dev), "name": torch.cuda.get_device_name(e.dev),
+          "gcn_arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count, "hbm_gib": round(p.total_memory / 2 ** 30, 1),
+          "pci_bus_id": getattr(p, "pci_bus_id", None), "uuid": str(getattr(p, "uuid", "")) or None, "pid": os.getpid()}
+    ranks = [me]
+    if e.world > 1:
+        ranks = [None] * e.world
+        dist.all_gather_object(ranks, me)
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        ver = None
+    ids = [(r["uuid"] or r["pci_bus_id"] or r["device"]) for r in ranks]
+    return {"world_size": e.world, "backend": (dist.get_backend() if dist.is_initialized() else None),
+            "rccl_version": ver, "distinct_devices": len(set(ids)), "shared_gpu_plumbing_test": bool(e.share), "ranks": ranks}
 
 
 PREHEAT = {"seconds": 0.0}
@@ -664,7 +686,52 @@ def run_render(args, e):
                                    f"over {e.world} rank(s), rgb all-gathered"),
                       "mode": "render", "samples_per_level": N, "frame_rays": Himg * Wimg,
                       "rays_per_gpu_max": shard_bounds(Himg * Wimg, 0, e.world)[1], "parallelism": f"ray-split x{e.world}, all_gather of 12 B/ray"}}
+    if e.world == 1 and N == 128:
+        try:
+            rec["reference_frame"] = render_reference_frame(args, e, frames)
+        except Exception as ex:      # noqa: BLE001  (a sub-record must not take the bench line down)
+            rec["reference_frame"] = {"error": f"{type(ex).__name__}: {ex}"}
     return rec
+
+
+def render_reference_frame(args, e, frames):
+    """configs[4] with a LIVE parity figure: the pose of tests/golden/frame_c5_800x800.npz -- one whole 800 x 800 `RenderGen`
+    frame rendered by the unmodified reference on the trained field (scripts/make_golden.py --only-frame) -- through the product route:
+    datasets.RenderGen (rays generated on the device) -> MipNeRFSystem.render_image with the frame's captured hipGraph; timed, then compared
+    with the reference's pixels."""
+    import numpy as np
+    import torch
+    from mipnerf_pl_amd import Rays
+    from mipnerf_pl_amd.datasets import RenderGen
+    from mipnerf_pl_amd.system import DEFAULT_HPARAMS, MipNeRFSystem
+    gdir = os.path.join(REPO, "tests", "golden")
+    g = np.load(os.path.join(gdir, "frame_c5_800x800.npz"))
+    f = np.load(os.path.join(gdir, str(g["field"]) + ".npz"))
+    size = int(g["cfg_size"])
+    hp = dict(DEFAULT_HPARAMS)
+    hp.update({"nerf.num_samples": int(g["cfg_num_samples"]), "val.chunk_size": int(g["cfg_chunk"])})
+    system = MipNeRFSystem(hp, precision=args.precision)
+    system.load_state_dict({"mip_nerf.mlp." + k[2:]: torch.from_numpy(f[k].copy()) for k in f.files if k.startswith("p_")})
+    system = system.to(e.dev).eval()
+    system.enable_hip_graph(not args.no_graph)
+    ds = RenderGen(float(g["focal"]), [size, size], scales=1, device=e.dev)
+    rgbs = torch.empty(1, size, size, 3, device=e.dev)
+
+    def step():
+        rays = ds[int(g["cfg_pose"])]                          # rays of the pose from the camera table, every frame (k_generate_rays)
+        return system.render_image((Rays(*[x[None] for x in rays]), rgbs))
+    step()
+    dt, out = timed(e, step, 1, frames)
+    fine = out[1][0].cpu().numpy().astype(np.float64)
+    gt = g["gt_u8"].astype(np.float64) / 255.0
+    psnr = lambda a, b: float(-10.0 * np.log10(np.mean((a - b) ** 2) + 1e-30))
+    return {"ms_per_step": round(dt / frames * 1e3, 3), "steps": frames, "hip_graph": bool(getattr(system._graphed, "graph", None)) if not args.no_graph else False,
+            "psnr_vs_reference_frame_db": round(psnr(fine, g["fine_rgb"][0].astype(np.float64)), 2),
+            "max_abs_fine_rgb": float(np.abs(fine - g["fine_rgb"][0]).max()),
+            "psnr_vs_scene_db": round(psnr(fine, gt), 3), "reference_psnr_vs_scene_db": round(float(g["psnr_fine"]), 3),
+            "workload": (f"pose {int(g['cfg_pose'])} of the reference's spheric render path at {size} x {size}, trained field, rays generated on the device, "
+                         f"{int(g['cfg_chunk'])}-ray chunks (79, the last one 1024 rays); golden = the unmodified reference's frame, "
+                         "tests/golden/frame_c5_800x800.npz")}
 
 
 def run_ceiling(args, e):
@@ -1051,6 +1118,7 @@ def main():
             ceiling = {"error": f"{type(ex).__name__}: {ex}"}
     head_mode = "inference" if "inference" in recs else args.mode
     head = recs.pop(head_mode)
+    who = rank_report(e)
     cpu = None
     if e.rank == 0 and e.world == 1 and not args.no_cpu_baseline and inputs is not None:
         cpu = cpu_baseline(args, *inputs)
@@ -1067,6 +1135,11 @@ def main():
                 "cpu_baseline": cpu}
         if head.get("sustained") is not None:
             line["sustained"] = head["sustained"]
+        tr = recs.get("train") or (head if head_mode == "train" else {})
+        if tr.get("ranks"):                      # the gradient all-reduce as the launch stream timed it, next to the ranks that took part
+            who["train_allreduce_ms"] = tr["ranks"].get("allreduce_ms")
+            who["train_ms_per_step_min_max"] = [tr["ranks"].get("ms_per_step_min"), tr["ranks"].get("ms_per_step_max")]
+        line["ranks"] = who
         if ceiling is not None:
             line["ceiling"] = ceiling
             if line.get("roofline") and "lds_fed" in ceiling and ceiling["lds_fed"] > 0:

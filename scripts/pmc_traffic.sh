@@ -6,7 +6,7 @@
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_traffic; mkdir -p $OUT
-ROUND=${ROUND:-5}
+ROUND=${ROUND:-6}
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/inf_$c -o pmc -- python $ROOT/bench.py --mode inference --no-graph --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --preheat-seconds 0 --ceiling-seconds 0 > $OUT/inf_$c.log 2>&1; echo "pmc inference $c rc=$?"

@@ -38,6 +38,12 @@ def test_bench_self_launches_two_ranks():
         assert line[k]["n_gpus"] == 2 and line[k]["value"] > 0 and line[k]["roofline"]["frac"] > 0, k
     assert line["render"]["scaling"] == "strong" and line["train"]["scaling"] == "weak"
     assert line["cpu_baseline"] is None          # N = 1 only
+    # round 6: the line says who ran -- one entry per rank with its device; here both ranks share cuda:0 and the line says so
+    who = line["ranks"]
+    assert who["world_size"] == 2 and [r["rank"] for r in who["ranks"]] == [0, 1] and who["backend"] == "gloo"
+    assert who["shared_gpu_plumbing_test"] is True and who["distinct_devices"] == 1 and all(r["name"] for r in who["ranks"])
+    assert who["train_allreduce_ms"] is not None and who["train_allreduce_ms"] > 0
+    assert line["train"]["lightning_route"] is None and "reference_frame" not in line["render"]      # N = 1 only
 
 
 @pytest.mark.gpu
@@ -70,6 +76,11 @@ def test_bench_single_gpu_line():
     assert line["sustained"]["value"] > 0 and "train" in line and "render" in line
     assert line["train"]["config"]["hip_graph"] is True and line["train"]["config"]["hip_graph_capture_error"] is None
     assert line["train"]["ranks"]["ms_per_step_min"] > 0
+    # round 6: who ran; the step an unmodified train.py executes (Lightning's automatic optimisation), routed onto the one-call native step;
+    # the render record is not rendered for N = 32 against the reference's frame (its golden is N = 128)
+    assert line["ranks"]["world_size"] == 1 and line["ranks"]["distinct_devices"] == 1 and line["ranks"]["ranks"][0]["compute_units"] == 256
+    lr = line["train"]["lightning_route"]
+    assert lr["routed_onto_native_step"] is True and 0 < lr["ms_per_step"] <= lr["per_stage_autograd_ms_per_step"] * 1.05, lr
     # round 3: the MFMA ceiling of THIS chip and the fp32 configs[3] forward travel in the same line
     assert 0.3 < line["ceiling"]["lds_fed"] <= line["ceiling"]["register_fed"] * 1.05 < 1.1, line["ceiling"]
     assert 0.3 < line["ceiling"]["lds_and_dma_fed"] <= line["ceiling"]["lds_fed"] * 1.05, line["ceiling"]   # + the L2 -> LDS weight stream
