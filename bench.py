@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lightning-route", action="store_true", help="train: skip the lightning_route sub-record (PMC passes: its per-level "
+                    "launches would mix into the per-kernel means)")
     ap.add_argument("--mode", default="all", choices=["all", "inference", "train", "render"],
                     help="all (default): headline inference + train and render sub-records; inference / train / render: "
                          "only that workload, reported at the top level")
@@ -468,7 +470,7 @@ def run_train(args, e):
                                 "frac_of_peak": round(traffic / (ms * 1e-3) / 8e12, 4),
                                 "note": "store-everything backprop: 3.73 TFLOP / 20.9 GB = 178 FLOP/B, below the 312 FLOP/B ridge"}
     lightning = None
-    if e.world == 1 and args.precision == "bf16" and not args.autograd:
+    if e.world == 1 and args.precision == "bf16" and not args.autograd and not args.no_lightning_route:
         try:
             lightning = run_lightning_route(args, e, model0.state_dict(), R, gt, N)
             lightning["vs_graphed_step"] = round(lightning["ms_per_step"] / ms, 4)
@@ -856,6 +858,8 @@ def run_fp32_c4(args, e):
         try:
             unb["train"] = run_train_unbounded(args, e)
         except Exception as ex:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()          # (with world > 1 the other ranks are inside this sub-record's collectives: say why this one left)
             unb["train"] = {"error": f"{type(ex).__name__}: {ex}"}
     except Exception as ex:  # noqa: BLE001  (an extra must not take the record down)
         unb = {"error": f"{type(ex).__name__}: {ex}"}
@@ -928,15 +932,15 @@ def run_train_unbounded(args, e, which=("fp32", "bf16", "bf16_graph")):
             loss.backward()
             opt.step()
             sch["scheduler"].step()
-            return loss
+            return loss.detach()          # (not the graph: its node keeps the model, and with it the step's 12-GiB workspace, alive past `del system`)
         step()
         step()
         dt, loss = timed(e, step, 0, steps)
         ms = dt / steps * 1e3
         tf = out["flop_per_sample"] * B * N * 2 / (ms * 1e-3) / 1e12
         out[precision] = {"ms_per_step": round(ms, 3), "steps": steps, "value": round(B * N * 2 * e.world / (ms * 1e-3), 1), "achieved_tflops": round(tf, 1),
-                          "frac_of_peak": round(tf / PEAK_TFLOPS[precision], 4), "loss_finite": bool(torch.isfinite(loss.detach()))}
-        del system, opt
+                          "frac_of_peak": round(tf / PEAK_TFLOPS[precision], 4), "loss_finite": bool(torch.isfinite(loss))}
+        del system, opt, loss
         torch.cuda.empty_cache()
     if "fp32" in out and "bf16" in out:
         out["speedup_bf16_over_fp32"] = round(out["fp32"]["ms_per_step"] / out["bf16"]["ms_per_step"], 2)
@@ -1083,6 +1087,10 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    if os.environ.get("MIPNERF_BENCH_WATCHDOG_SECONDS"):
+        # a rank stuck in a collective says WHERE: every thread's Python stack on stderr after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MIPNERF_BENCH_WATCHDOG_SECONDS"]), exit=True)
     e = setup(args)
     PREHEAT["seconds"] = max(0.0, args.preheat_seconds)
     import torch.distributed as dist

@@ -60,7 +60,8 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc"
 # silently produce a product library with wrong gradients: such a build needs MIPNERF_EXPERIMENT_BUILD=1 AND its own MIPNERF_LIB_NAME, and
 # the library it produces refuses mipnerf_create() unless the process sets MIPNERF_ALLOW_EXPERIMENT_LIB=1 (capi.hip).
 WRONG_RESULT_KNOBS = {"MLP_ABLATE_BARRIER": "0", "MLP_ABLATE_WAIT": "0", "MLP_ABLATE_LDA": "0", "MLP_F32R_GEN_ABLATE": "0", "MLP_F32R_ABLATE": "",
-                      "MLP_TRAIN_ABLATE_TMFMA": "0", "MLP_WGRAD_TR": "0", "MLP_TRAIN_SKIP_STORES": "0", "MLP_WGRAD_RECOMPUTE_PROBE": "0"}
+                      "MLP_TRAIN_ABLATE_TMFMA": "0", "MLP_WGRAD_TR": "0", "MLP_TRAIN_SKIP_STORES": "0", "MLP_WGRAD_RECOMPUTE_PROBE": "0",
+                      "MLP_PRE_ABLATE_STORES": "0", "MLP_TRUNK_ABLATE_PRELOADS": "0"}
 
 
 def experiment_flags():

@@ -46,6 +46,9 @@ IPE_SHADOW_STRIDE = int(os.environ.get("MLP_IPE_SHADOW_STRIDE", "4"))    # one p
 # trunk kernels of the two-kernel form: pre_x / pre_acc (read once, 1.5 KB per sample) with the non-temporal policy, so that they do not push the weight
 # stream out of the L2: 7.803 / 7.812 / 7.819 vs 7.835 / 7.837 / 7.862 ms per forward in three alternating pairs (-0.4 %, profiles/r04z_trunk_nt_loads_ab.txt)
 PRE_NT = os.environ.get("MLP_PRE_NT_LOADS", "1") == "1"
+# round 6, timing probe for the one-kernel form: the trunk without its 1,536 B/sample of pre_x / pre_acc loads -- the values come
+# from LDS instead (stale weights as X, the bias table as accumulator images).  WRONG results (build.py: WRONG_RESULT_KNOBS)
+ABLATE_PRELOADS = os.environ.get("MLP_TRUNK_ABLATE_PRELOADS", "0") == "1"
 NE = 3                # rotating registers for LDS-resident B operands (E0..E2)
 ENC_WAVE_BYTES = 8192  # wave-private LDS: 6 KiB encoding + 2 KiB view encoding
 
@@ -231,6 +234,10 @@ def bias_pieces(plan, pn):
 
 
 KERNEL_PREAMBLE = r"""
+#ifndef MIP_CHUNKS_PER_WAVE
+#define MIP_CHUNKS_PER_WAVE 4      // 1-KiB chunks a wave moves per ring group (issue_group)
+#endif
+constexpr int kChunksPerWave = MIP_CHUNKS_PER_WAVE;
 #define LDA(off) (*reinterpret_cast<const bf16x8*>(ring_lane + (off)))
 #define LDB(off) (*reinterpret_cast<const bf16x8*>(enc_lane + (off)))
 #define MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), acc, 0, 0, 0)
@@ -285,9 +292,11 @@ __device__ __forceinline__ void issue_group(const char* __restrict__ stream, cha
     // loop and spills ~530 SGPRs to VGPR lanes; an opaque copy makes each base two scalar adds at its point of use
     asm volatile("" : "+s"(stream));
 #endif
-    const char* gbase = stream + ((size_t)group * kGroupBytes + (size_t)wave * 4096);   // uniform
-    char* lbase = smem + slot * kGroupBytes + wave * 4096;                              // uniform
+    const char* gbase = stream + ((size_t)group * kGroupBytes + (size_t)wave * (kChunksPerWave * 1024));   // uniform
+    char* lbase = smem + slot * kGroupBytes + wave * (kChunksPerWave * 1024);                              // uniform
     if (DMA) {
+#pragma unroll
+      for (int blk = 0; blk < kChunksPerWave / 4; ++blk, gbase += 4096, lbase += 4096) {
         // Issued through inline asm on purpose: hipcc models the builtin as a FLAT access with a pending
         // LDS side effect, which degrades EVERY later `s_waitcnt lgkmcnt(N)` to lgkmcnt(0) and puts a
         // vmcnt(0) in front of the bias reads for as long as the DMA is in flight (i.e. always).  Its
@@ -307,12 +316,13 @@ __device__ __forceinline__ void issue_group(const char* __restrict__ stream, cha
             : "=&s"(keep)
             : "v"(lane16), "s"(gbase), "s"(lds_addr)
             : "memory");
+      }
     } else {
         // opaque copy: stops LLVM from re-associating (stream + lane) + constant into one hoisted 64-bit
         // VGPR address per chunk (38 groups x 4 chunks of them would be spilled to scratch)
         asm volatile("" : "+v"(lane16));
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < kChunksPerWave; ++i)
             *reinterpret_cast<float4*>(lbase + i * 1024 + lane16) =
                 *reinterpret_cast<const float4*>(gbase + i * 1024 + lane16);
     }
@@ -456,8 +466,16 @@ DEEP_RING_MACRO = r"""// One wave per SIMD (the 512-wide trunk, gen_mlp_bf16.wav
 #define GROUP_BEGIN_DEEP(g, WAITCNT)                                                                                     \
     do {                                                                                                                \
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITCNT) : "memory");                          \
-        if ((g) + kAhead < kNumGroups) issue_group<DMA>(stream, smem, (g) + kAhead, ((g) + kAhead) % (kAhead + 1), wave, lane16);      \
-        else issue_group<DMA>(stream, smem, (g) + kAhead - kNumGroups, ((g) + kAhead) % (kAhead + 1), wave, lane16);                  \
+        if ((g) + kAhead < kNumGroups) issue_group<DMA>(stream, smem, (g) + kAhead, ((g) + kAhead) % kSlots, wave, lane16);      \
+        else issue_group<DMA>(stream, smem, (g) + kAhead - kNumGroups, ((g) + kAhead) % kSlots, wave, lane16);                  \
+    } while (0)
+// kSlots = kAhead + 2 (MLP_WIDE_SPARE_SLOT=1): group g + kAhead goes into the slot of group g - 2, whose LDS reads returned long ago (every
+// MFMA slot waits for all but its last PREFETCH - 1 reads), so the boundary need not drain this wave's in-flight A-fragment reads of group g - 1
+#define GROUP_BEGIN_DEEP_NODRAIN(g, WAITCNT)                                                                             \
+    do {                                                                                                                \
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(WAITCNT) : "memory");                                     \
+        if ((g) + kAhead < kNumGroups) issue_group<DMA>(stream, smem, (g) + kAhead, ((g) + kAhead) % kSlots, wave, lane16);      \
+        else issue_group<DMA>(stream, smem, (g) + kAhead - kNumGroups, ((g) + kAhead) % kSlots, wave, lane16);                  \
     } while (0)
 """
 
@@ -479,12 +497,22 @@ def waves_of(arch: Arch) -> int:
 def gen_kernel(plan: Plan, variant: int = 0) -> str:
     pre = plan.pre_gemm        # trunk of the two-kernel form (mlp_pre_plan.py): X preloaded, skip-layer accumulators from k_pre_gemm
     WAVES = waves_of(plan.arch)                 # (shadow the module defaults: everything below is per kernel)
-    GROUP = 4 * WAVES
     wide = max(plan.arch.net_width, plan.arch.net_width_condition) > 256      # one wave per SIMD, 512-register budget
+    # chunks a wave DMAs per ring group.  The one-wave-per-SIMD kernels can take 8 (MLP_WIDE_CPW): a group is then 32 of a wave's MFMAs, so the
+    # workgroup meets at a barrier half as often -- with one wave per SIMD nobody covers for a wave parked at the barrier
+    PREFETCH = int(os.environ.get("MLP_WIDE_PREFETCH", globals()["PREFETCH"])) if wide else globals()["PREFETCH"]      # A-fragment read distance (chunks)
+    CPW = int(os.environ.get("MLP_WIDE_CPW", "4")) if wide else 4
+    assert CPW in (4, 8)
+    GROUP = CPW * WAVES
     WG_PER_CU = 1 if wide else 8 // WAVES
     nreg = max(plan.arch.net_width, plan.arch.net_width_condition) // 16      # k-step fragments of one activation register set
-    AHEAD = int(os.environ.get("MLP_WIDE_AHEAD", "3")) if wide else 1         # ring groups in flight (GROUP_BEGIN_DEEP); the 8-wave kernels: 1
-    SLOTS = AHEAD + 1 if wide else globals()["SLOTS"]
+    # Round 6 A/B on the 512-wide trunk (profiles/r06c_w512_group_prefetch_ab.txt, r06d_w512_spare_slot_ab.txt; ms per 524,288 samples): default of round 5
+    # (3 groups in flight, 4 slots) 2.085-2.121; 32-chunk groups (MLP_WIDE_CPW=8: half the barriers) 2.14; A fragments 6 / 8 chunks ahead 2.10 / 2.11;
+    # a spare slot (no LDS drain at the boundaries) with 2 / 4 groups in flight 2.088-2.093 / 2.096-2.104.  None of the ring's knobs is worth more
+    # than 1.3 %: at 128 samples per workgroup the kernel pulls its 4.5-MiB weight stream through L2 -> LDS at 9.6 TB/s chip-wide, which is what bounds it.
+    AHEAD = int(os.environ.get("MLP_WIDE_AHEAD", "2")) if wide else 1         # ring groups in flight (GROUP_BEGIN_DEEP); the 8-wave kernels: 1
+    SPARE = wide and os.environ.get("MLP_WIDE_SPARE_SLOT", "1") == "1"           # one more ring slot than groups in flight: no LDS drain at the group boundaries
+    SLOTS = (AHEAD + (2 if SPARE else 1)) if wide else globals()["SLOTS"]
     sfx = f"_pre_v{variant}" if pre else ("" if variant == 0 else f"_v{variant}")
     nchunks = len(plan.chunks)
     assert nchunks % GROUP == 0, "stream must be a whole number of ring groups"
@@ -519,7 +547,13 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         e(f"namespace v{variant}{'pre' if pre else ''} {{")
     e("typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;")
     e("typedef __attribute__((ext_vector_type(16))) float f32x16;")
-    if pre and PRE_NT:
+    if pre and ABLATE_PRELOADS:
+        e("extern __shared__ __attribute__((aligned(16))) char smem_probe[];")
+        e("typedef __attribute__((ext_vector_type(4))) float f32x4p_;")
+        e("__device__ __forceinline__ bf16x8 pre_fake(const bf16x8* p) { return *reinterpret_cast<const bf16x8*>(smem_probe + ((unsigned)(size_t)p & 0x7ff0u)); }")
+        e(f"__device__ __forceinline__ f32x4p_ pre_fake(const f32x4p_* p) {{ return *reinterpret_cast<const f32x4p_*>(smem_probe + {ring_bytes} + ((unsigned)(size_t)p & 0x1ff0u)); }}")
+        e("#define PRE_LD(ptr) pre_fake(ptr)")
+    elif pre and PRE_NT:
         e("#define PRE_LD(ptr) __builtin_nontemporal_load(ptr)")
     if wide:
         e("#define MIP_OPAQUE_STREAM_BASE 1")
@@ -529,10 +563,13 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e(f"constexpr int kEncWaveBytes = {ENC_WAVE_BYTES};")
     e(f"constexpr int kLdsBytes = {lds_bytes};")
     e(f"constexpr int kGroupBytes = {GROUP * CHUNK_BYTES};")
+    if CPW != 4:
+        e(f"#define MIP_CHUNKS_PER_WAVE {CPW}")
     e(f"constexpr int kNumGroups = {ngroups};")
     e(f"constexpr int kTileSamples = {WAVES * 32};")
     if wide:
         e(f"constexpr int kAhead = {AHEAD};")
+        e(f"constexpr int kSlots = {SLOTS};")
     e(KERNEL_PREAMBLE.replace("BARRIER_INSN", "s_nop 0" if ABLATE_BARRIER else "s_barrier")
       .replace("WAIT_INSN", "s_waitcnt lgkmcnt(0)" if ABLATE_WAIT else "s_waitcnt vmcnt(0) lgkmcnt(0)"))
     if wide:
@@ -701,7 +738,9 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     # ---- tile prologue --------------------------------------------------------------------------
     def group_begin(g, note=""):
         if wide:          # group 0: a full wait (the tile's encoding DMAs are younger than the ring's and are read next)
-            return f"GROUP_BEGIN_DEEP({g}, {0 if g == 0 else 4 * (AHEAD - 1)});{note}"
+            if SPARE and g != 0:
+                return f"GROUP_BEGIN_DEEP_NODRAIN({g}, {CPW * (AHEAD - 1)});{note}"
+            return f"GROUP_BEGIN_DEEP({g}, {0 if g == 0 else CPW * (AHEAD - 1)});{note}"
         return f"GROUP_BEGIN({g}, {(g + 1) % SLOTS});{note}"
     e(f"        {group_begin(0)}")
     for c in range(PREFETCH):

@@ -45,6 +45,8 @@ VM_MARGIN = 4                                             # see the counted vmcn
 # 8.68 / 8.72 with both (profiles/r04y_pre_gemm_policy_ab.txt); 13 instead of 11 operands in flight: no difference.  Both on by default.
 NT_STORES = os.environ.get("MLP_PRE_NT_STORES", "1") == "1"
 NT_PASS1 = os.environ.get("MLP_PRE_NT_PASS1", "1") == "1"
+# round 6, timing probe for the one-kernel form: k_pre_gemm without its 1,536 B/sample of stores.  WRONG results (build.py: WRONG_RESULT_KNOBS)
+ABLATE_STORES = os.environ.get("MLP_PRE_ABLATE_STORES", "0") == "1"
 
 
 def gen_gemm(p: PrePlan, vi: int) -> str:
@@ -164,7 +166,9 @@ def gen_gemm(p: PrePlan, vi: int) -> str:
     e("// (the DMA of group g + 1 and the B-operand loads issued since), so the prefetched operands are never waited for here")
     e('#define RING_BARRIER(K) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\\n\\ts_barrier" ::"n"(K) : "memory")')
     e("// stores: wave-uniform base + literal offset (SGPRs) + the 32-bit lane offset, so no 64-bit VGPR address per 4 KiB of output stays live")
-    if NT_STORES:
+    if ABLATE_STORES:      # timing probe (WRONG results): the two outputs are computed and dropped -- what a kernel that keeps them on chip would not write
+        e('#define ST16(p, v) do { auto v_ = (v); asm volatile("" :: "v"(v_)); } while (0)')
+    elif NT_STORES:
         e("#define ST16(p, v) __builtin_nontemporal_store((v), (p))")
     else:
         e("#define ST16(p, v) *(p) = (v)")

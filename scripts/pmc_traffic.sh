@@ -10,7 +10,7 @@ ROUND=${ROUND:-6}
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/inf_$c -o pmc -- python $ROOT/bench.py --mode inference --no-graph --steps 3 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --preheat-seconds 0 --ceiling-seconds 0 > $OUT/inf_$c.log 2>&1; echo "pmc inference $c rc=$?"
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/train_$c -o pmc -- python $ROOT/bench.py --mode train --steps 3 --warmup 1 --no-graph --no-cpu-baseline --preheat-seconds 0 > $OUT/train_$c.log 2>&1; echo "pmc train $c rc=$?"
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/train_$c -o pmc -- python $ROOT/bench.py --mode train --steps 3 --warmup 1 --no-graph --no-cpu-baseline --no-lightning-route --preheat-seconds 0 > $OUT/train_$c.log 2>&1; echo "pmc train $c rc=$?"
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/f32_$c -o pmc -- python $ROOT/bench.py --mode inference --no-graph --precision fp32 --steps 2 --warmup 1 --no-cpu-baseline --sustain-seconds 0 --preheat-seconds 0 > $OUT/f32_$c.log 2>&1; echo "pmc fp32 $c rc=$?"
 done
 python - $OUT $ROUND <<'PY' | tee $ROOT/gpurun_out/pmc_traffic_summary.txt

@@ -321,17 +321,19 @@ def test_wrong_result_build_knobs_need_an_explicit_opt_in(monkeypatch):
 
 
 def test_one_wave_per_simd_kernel_ring_is_consistent():
-    """The 512-wide trunk's bf16 kernel (gen_mlp_bf16.waves_of: 4-wave workgroups, one wave per SIMD) keeps kAhead ring groups in flight in
-    kAhead + 1 slots with counted vmcnt waits.  From the generated source: every chunk is read from the slot its group was issued into, every
-    group boundary is there exactly once, group 0 waits for everything (the tile's encoding DMAs are younger than the ring's), every other
-    boundary leaves exactly the 4 (kAhead - 1) DMAs of the groups behind it in flight, and the group count keeps the ring phase tile-invariant."""
+    """The 512-wide trunk's bf16 kernel (gen_mlp_bf16.waves_of: 4-wave workgroups, one wave per SIMD) keeps kAhead ring groups in flight with
+    counted vmcnt waits in kSlots = kAhead + 2 slots (round 6: the spare slot means a boundary refills the slot of group g - 2, whose reads
+    returned long ago, and need not drain the wave's in-flight A-fragment reads).  From the generated source: every chunk is read from the slot
+    its group was issued into, every group boundary is there exactly once, group 0 waits for everything (the tile's encoding DMAs are younger than
+    the ring's), every other boundary leaves exactly the 4 (kAhead - 1) DMAs of the groups behind it in flight, the group count keeps the ring
+    phase tile-invariant, and the refill never depends on has_next."""
     src = open(os.path.join(REPO, "mipnerf_pl_amd", "csrc", "mlp_bf16_gen_v6.hip")).read()
     ahead = int(re.search(r"constexpr int kAhead = (\d+);", src).group(1))
+    slots = int(re.search(r"constexpr int kSlots = (\d+);", src).group(1))
     ngroups = int(re.search(r"constexpr int kNumGroups = (\d+);", src).group(1))
     group_bytes = int(re.search(r"constexpr int kGroupBytes = (\d+);", src).group(1))
     ring_bytes = int(re.search(r"constexpr int kRingBytes = (\d+);", src).group(1))
-    slots = ahead + 1
-    assert ring_bytes == slots * group_bytes and group_bytes == 16 * 1024 and ngroups % slots == 0
+    assert slots == ahead + 2 and ring_bytes == slots * group_bytes and group_bytes == 16 * 1024 and ngroups % slots == 0
     assert "__launch_bounds__(256, 1)" in src and "MIP_OPAQUE_STREAM_BASE" in src
     body = src[src.index("for (int tile = blockIdx.x;"):]
     body = body[:body.index("if (hi == 0 && s < M)")]
@@ -339,18 +341,18 @@ def test_one_wave_per_simd_kernel_ring_is_consistent():
     assert len(offs) == ngroups * 16
     for c, off in enumerate(offs):                      # chunk c of the stream: group c // 16 lives in slot (c // 16) % slots
         assert off == ((c // 16) % slots) * group_bytes + (c % 16) * 1024, (c, off)
-    begins = [(int(g), int(w)) for g, w in re.findall(r"GROUP_BEGIN_DEEP\((\d+), (\d+)\);", body)]
-    assert [g for g, _ in begins] == list(range(ngroups))
-    assert begins[0][1] == 0 and all(w == 4 * (ahead - 1) for _, w in begins[1:])
-    # the prologue issues groups 0 .. kAhead - 1 into slots 0 .. kAhead - 1; the macro refills slot (g + kAhead) % slots with group g + kAhead
+    begins = [(kind, int(g), int(w)) for kind, g, w in re.findall(r"GROUP_BEGIN_DEEP(_NODRAIN)?\((\d+), (\d+)\);", body)]
+    assert [g for _, g, _ in begins] == list(range(ngroups))
+    assert begins[0][0] == "" and begins[0][2] == 0 and all(k == "_NODRAIN" and w == 4 * (ahead - 1) for k, _, w in begins[1:])
+    # the prologue issues groups 0 .. kAhead - 1 into slots 0 .. kAhead - 1; the macros refill slot (g + kAhead) % kSlots with group g + kAhead
     pro = src[:src.index("for (int tile = blockIdx.x;")]
     assert [tuple(map(int, m)) for m in re.findall(r"issue_group<DMA>\(stream, smem, (\d+), (\d+), wave, lane16\);", pro)][-ahead:] == [(g, g) for g in range(ahead)]
-    assert "((g) + kAhead) % (kAhead + 1)" in src
-    # the counted wait of the tile's LAST kAhead - 1 groups leans on the next tile's groups being in flight, so the refill must not
-    # stop on a workgroup's last tile (has_next == false): it runs around the stream unconditionally, and the kernel drains before it ends
-    macro = src[src.index("#define GROUP_BEGIN_DEEP(g, WAITCNT)"):]
-    macro = macro[:macro.index("} while (0)")]
-    assert "has_next" not in macro and "(g) + kAhead - kNumGroups" in macro
+    for name in ("GROUP_BEGIN_DEEP(g, WAITCNT)", "GROUP_BEGIN_DEEP_NODRAIN(g, WAITCNT)"):
+        macro = src[src.index("#define " + name):]
+        macro = macro[:macro.index("} while (0)")]
+        assert "has_next" not in macro and "(g) + kAhead - kNumGroups" in macro and "((g) + kAhead) % kSlots" in macro
+    nodrain = src[src.index("#define GROUP_BEGIN_DEEP_NODRAIN"):]
+    assert "lgkmcnt" not in nodrain[:nodrain.index("} while (0)")]
     tail = src[src.index("if (hi == 0 && s < M)"):]
     assert 's_waitcnt vmcnt(0)' in tail[:tail.index("\n}\n")]
 
