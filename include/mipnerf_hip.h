@@ -403,7 +403,9 @@ int mipnerf_selftest(void* stream);
  * coarse fence posts as ONE launch and the coarse level's compositing + the fine level's resampling as ONE launch (N <= 128 or 192 < N <= 256; the
  * weights go from registers to the sampler's LDS row), 0 = one launch per stage (same bits); option 5: 1 [default] = fp32 inference (mipnerf_mlp_forward,
  * mipnerf_forward) runs the register-resident kernel k_mlp_f32r where one was generated for the architecture (widths <= 256), 0 = the LDS-resident
- * k_mlp_f32 (same function, another summation order: results agree to fp32 rounding). */
+ * k_mlp_f32 (same function, another summation order: results agree to fp32 rounding); option 6 (ABI 6, round 6): 1 [default] = the bf16 forward of an
+ * unbounded = 1 context (mipnerf_forward) runs as ONE MLP kernel per level -- layer 0 and the skip layer as k-step-major ops of the trunk kernel, the 672-wide encoding
+ * streamed through a wave-private LDS ring --, 0 = k_pre_gemm + trunk kernel with their 1.5-KiB-per-sample hand-off through HBM (same bits). */
 int mipnerf_set_option(mipnerf_ctx* ctx, int option, int value);
 /* Sum of the elapsed times (ms) and the number of MLP launches recorded since the last call
  * (option 2); synchronises on the recorded events. */

@@ -97,7 +97,7 @@ def generate() -> None:
     import re
     for f in os.listdir(CSRC):
         if re.fullmatch(r"(mlp_bf16(_trainfwd|_trainfwd_pre|_dgrad)?_gen_v\d+\.(hip|o)|_gen_train_tables(_v\d+)?\.bin|mlp_f32r_gen_v\d+\.(hip|o)|_gen_f32r_tables_v\d+\.bin|"
-                        r"pre_gemm_gen_v\d+\.(hip|o)|mlp_bf16_pre_gen_v\d+\.(hip|o)|_gen_pre_tables_v\d+\.bin)", f):
+                        r"pre_gemm_gen_v\d+\.(hip|o)|mlp_bf16_pre_gen_v\d+\.(hip|o)|mlp_bf16_fused_gen_v\d+\.(hip|o)|_gen_pre_tables_v\d+\.bin)", f):
             os.remove(os.path.join(CSRC, f))
     subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_mlp_bf16.py"), CSRC])
     subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_mlp_train.py"), CSRC])
@@ -112,7 +112,7 @@ def variant_units():
     for f in sorted(os.listdir(CSRC)):
         if re.fullmatch(r"mlp_bf16_gen_v\d+\.hip", f) or re.fullmatch(r"mlp_bf16_trainfwd(_pre)?_gen_v\d+\.hip", f):
             out.append((f, NO_IEEE + ["-ffp-contract=off"]))
-        elif re.fullmatch(r"(pre_gemm_gen|mlp_bf16_pre_gen)_v\d+\.hip", f):      # two-kernel bf16 form of wide encodings (gen_pre_gemm.py)
+        elif re.fullmatch(r"(pre_gemm_gen|mlp_bf16_pre_gen|mlp_bf16_fused_gen)_v\d+\.hip", f):      # two-kernel bf16 form of wide encodings (gen_pre_gemm.py)
             out.append((f, NO_IEEE + ["-ffp-contract=off"]))
         elif re.fullmatch(r"mlp_bf16_dgrad_gen_v\d+\.hip", f):
             out.append((f, NO_IEEE))

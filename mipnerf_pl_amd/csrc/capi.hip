@@ -236,6 +236,10 @@ struct PreTables {
     const int32_t* gemm_bias = nullptr;    // [n_gemm_bias]
     const int32_t* trunk_pack = nullptr;   // [n_trunk_chunks * 512]
     const int32_t* trunk_bias = nullptr;   // [n_trunk_tiles * 32]
+    // round 6: the one-kernel form of the same model (mlp_plan.Plan.build(arch, fused=True)), tables behind the two-kernel form's
+    int n_fused_chunks = 0, n_fused_tiles = 0;
+    const int32_t* fused_pack = nullptr;   // [n_fused_chunks * 512]
+    const int32_t* fused_bias = nullptr;   // [n_fused_tiles * 32]
 };
 bool pre_tables(PreTables& T, int variant, int nparams) {
     if (variant < 0 || variant >= mip::plan::kNumVariants || !mip::kPreTableBlobs[variant]) return false;
@@ -246,6 +250,9 @@ bool pre_tables(PreTables& T, int variant, int nparams) {
     T.gemm_bias = T.gemm_pack + (size_t)h[1] * 512;
     T.trunk_pack = T.gemm_bias + h[3];
     T.trunk_bias = T.trunk_pack + (size_t)h[4] * 512;
+    T.n_fused_chunks = h[10]; T.n_fused_tiles = h[11];
+    T.fused_pack = T.trunk_bias + (size_t)h[6] * 32;
+    T.fused_bias = T.fused_pack + (size_t)h[10] * 512;
     return true;
 }
 
@@ -271,7 +278,10 @@ struct mipnerf_ctx {
     // two-kernel bf16 inference of the variants whose encoding does not fit k_mlp_bf16's wave-private LDS area (gen_pre_gemm.py):
     // k_pre_gemm's weight stream + accumulator images, the trunk kernel's stream + bias table, and scratch for the per-stage entry point
     PreTables pre;
-    int32_t* d_pre_idx[4] = {nullptr, nullptr, nullptr, nullptr};     // index tables: gemm pack, gemm bias, trunk pack, trunk bias
+    int32_t* d_pre_idx[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};     // index tables: gemm pack, gemm bias, trunk pack, trunk bias, one-kernel pack, one-kernel bias
+    void* d_fused_stream = nullptr;  // one-kernel form (round 6): its weight stream and bias table
+    float* d_fused_bias = nullptr;
+    int fused_pre = 1;               // option 6: 1 = mipnerf_forward runs the one-kernel form where generated, 0 = k_pre_gemm + trunk (same bits)
     void* d_pre_gemm_stream = nullptr;
     float* d_pre_gemm_bias = nullptr;
     void* d_pre_trunk_stream = nullptr;
@@ -333,6 +343,11 @@ static size_t pre_frag_bytes(const mipnerf_ctx* c, size_t M) { return ((M + 255)
 // k_pre_gemm + the trunk kernel.  enc: bf16, row-major [M, xyz_dim] (frag = 0) or the fragment layout launch_cast_ipe_360 writes
 hipError_t launch_bf16_pre(mipnerf_ctx* c, const void* enc, int frag, const void* viewenc, float* rgb_sigma, float* raw, int64_t M, int N,
                            void* pre_x, void* pre_acc, const float* dnoise, hipStream_t st) {
+    // round 6: fragment encodings go through ONE kernel where it was generated (layer 0 and the skip layer as k-step-major ops of the trunk
+    // kernel, the encoding streamed through a wave-private LDS ring): no pre_x / pre_acc hand-off through HBM, same bits (option 6 = 0: two kernels)
+    if (frag && c->fused_pre && c->d_fused_stream && mip::kLaunchBf16Fused[c->P->variant])
+        return mip::kLaunchBf16Fused[c->P->variant](c->d_fused_stream, c->d_fused_bias, enc, nullptr, viewenc, rgb_sigma, raw, M, N,
+                                                    c->cfg.density_bias, c->cfg.rgb_padding, c->grid_limit, dnoise, c->cfg.density_noise, st);
     hipError_t er = mip::kLaunchPreGemm[c->P->variant](c->d_pre_gemm_stream, c->d_pre_gemm_bias, enc, frag, pre_x, pre_acc, M, c->grid_limit, st);
     if (er != hipSuccess) return er;
     return mip::kLaunchBf16Pre[c->P->variant](c->d_pre_trunk_stream, c->d_pre_trunk_bias, pre_x, pre_acc, viewenc, rgb_sigma, raw, M, N,
@@ -507,9 +522,11 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
             return fail(MIPNERF_E_INVALID, "mipnerf_create: embedded tables of the two-kernel bf16 form are inconsistent with the compiled plan");
         }
         const PreTables& pt = c->pre;
-        const int32_t* src[4] = {pt.gemm_pack, pt.gemm_bias, pt.trunk_pack, pt.trunk_bias};
-        const size_t cnt[4] = {(size_t)pt.n_gemm_chunks * 512, (size_t)pt.n_gemm_bias, (size_t)pt.n_trunk_chunks * 512, (size_t)pt.n_trunk_tiles * 32};
-        for (int i = 0; i < 4; ++i) {
+        const int32_t* src[6] = {pt.gemm_pack, pt.gemm_bias, pt.trunk_pack, pt.trunk_bias, pt.fused_pack, pt.fused_bias};
+        const size_t cnt[6] = {(size_t)pt.n_gemm_chunks * 512, (size_t)pt.n_gemm_bias, (size_t)pt.n_trunk_chunks * 512, (size_t)pt.n_trunk_tiles * 32,
+                               (size_t)pt.n_fused_chunks * 512, (size_t)pt.n_fused_tiles * 32};
+        for (int i = 0; i < 6; ++i) {
+            if (cnt[i] == 0) continue;
             const std::vector<int32_t> enc_i = encode(std::vector<int32_t>(src[i], src[i] + cnt[i]), c->tab.tensor_off);
             chk(hipMalloc(&c->d_pre_idx[i], cnt[i] * 4));
             if (er == hipSuccess) chk(hipMemcpy(c->d_pre_idx[i], enc_i.data(), cnt[i] * 4, hipMemcpyHostToDevice));
@@ -518,6 +535,10 @@ int mipnerf_create(const mipnerf_config* cfg, mipnerf_ctx** out) {
         chk(hipMalloc(&c->d_pre_gemm_bias, cnt[1] * 4));
         chk(hipMalloc(&c->d_pre_trunk_stream, cnt[2] * 2));
         chk(hipMalloc(&c->d_pre_trunk_bias, cnt[3] * 4));
+        if (cnt[4]) {
+            chk(hipMalloc(&c->d_fused_stream, cnt[4] * 2));
+            chk(hipMalloc(&c->d_fused_bias, cnt[5] * 4));
+        }
         if (er != hipSuccess) {
             mipnerf_destroy(c);
             return fail(MIPNERF_E_HIP, "mipnerf_create (tables of the two-kernel bf16 form): %s", hipGetErrorString(er));
@@ -575,7 +596,8 @@ int mipnerf_destroy(mipnerf_ctx* c) {
     (void)hipFree(c->d_wgtab); (void)hipFree(c->d_jobslots); (void)hipFree(c->d_scratch); (void)hipFree(c->d_extra_wT);
     (void)hipFree(c->d_pack_extraT);
     (void)hipFree(c->d_pack_f32r); (void)hipFree(c->d_aux_idx_f32r); (void)hipFree(c->d_stream_f32r); (void)hipFree(c->d_aux_f32r);
-    for (int i = 0; i < 4; ++i) (void)hipFree(c->d_pre_idx[i]);
+    for (int i = 0; i < 6; ++i) (void)hipFree(c->d_pre_idx[i]);
+    (void)hipFree(c->d_fused_stream); (void)hipFree(c->d_fused_bias);
     (void)hipFree(c->d_pre_gemm_stream); (void)hipFree(c->d_pre_gemm_bias); (void)hipFree(c->d_pre_trunk_stream); (void)hipFree(c->d_pre_trunk_bias);
     (void)hipFree(c->d_pre_scratch);
     if (c->pre_scratch_event) (void)hipEventDestroy(c->pre_scratch_event);
@@ -593,6 +615,7 @@ int mipnerf_set_option(mipnerf_ctx* c, int option, int value) {
         case 3: c->fused_ipe = value ? 1 : 0; return MIPNERF_OK;
         case 4: c->fuse_small = value ? 1 : 0; return MIPNERF_OK;
         case 5: c->f32_resident = value ? 1 : 0; return MIPNERF_OK;
+        case 6: c->fused_pre = value ? 1 : 0; return MIPNERF_OK;
         default: return fail(MIPNERF_E_INVALID, "unknown option %d", option);
     }
 }
@@ -636,6 +659,10 @@ int mipnerf_set_params(mipnerf_ctx* c, const float* const* params_host, void* st
         add(c->d_pre_idx[1], (int64_t)c->pre.n_gemm_bias, c->d_pre_gemm_bias, false);
         add(c->d_pre_idx[2], (int64_t)c->pre.n_trunk_chunks * 512, c->d_pre_trunk_stream, true);
         add(c->d_pre_idx[3], (int64_t)c->pre.n_trunk_tiles * 32, c->d_pre_trunk_bias, false);
+        if (c->d_fused_stream) {
+            add(c->d_pre_idx[4], (int64_t)c->pre.n_fused_chunks * 512, c->d_fused_stream, true);
+            add(c->d_pre_idx[5], (int64_t)c->pre.n_fused_tiles * 32, c->d_fused_bias, false);
+        }
     }
     if (sg_overflow) return fail(MIPNERF_E_INVALID, "set_params: more than %d pack segments", mip::kMaxPackSegments);
     HIP_TRY(mip::launch_pack_multi(sg, pp, S(stream)));

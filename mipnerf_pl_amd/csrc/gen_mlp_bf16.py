@@ -50,6 +50,10 @@ PRE_NT = os.environ.get("MLP_PRE_NT_LOADS", "1") == "1"
 # from LDS instead (stale weights as X, the bias table as accumulator images).  WRONG results (build.py: WRONG_RESULT_KNOBS)
 ABLATE_PRELOADS = os.environ.get("MLP_TRUNK_ABLATE_PRELOADS", "0") == "1"
 NE = 3                # rotating registers for LDS-resident B operands (E0..E2)
+# one-kernel form of a wide encoding (Plan.fused): wave-private LDS ring of encoding k-steps (1 KiB each, global_load_lds from the fragment buffer
+# k_cast_ipe_360 writes) and how many k-steps ahead of its MFMAs a k-step's DMA is issued (its B-operand read happens two k-steps ahead)
+FUSED_RING = int(os.environ.get("MLP_FUSED_RING", "8"))
+FUSED_AHEAD = int(os.environ.get("MLP_FUSED_AHEAD", "7"))
 ENC_WAVE_BYTES = 8192  # wave-private LDS: 6 KiB encoding + 2 KiB view encoding
 
 
@@ -149,9 +153,27 @@ def build_schedule(plan: Plan):
     slot c: MFMA of chunk c with accumulator `acc` and B operand `b`; b is either a literal
     register ('reg', 'X[3]') or ('lds', byte offset in the wave-private area)."""
     a = plan.arch
-    nenc_lds = 0 if plan.pre_gemm else a.xyz_dim // 16
+    nenc_lds = 0 if (plan.pre_gemm or plan.fused) else a.xyz_dim // 16
     panels, slots = [], []
+    ring_seq = 0           # fused plans: running index of the encoding k-steps streamed through the wave-private ring (layer 0: 0.., skip layer: nk..)
     for op in plan.ops:
+        if op.kmajor:
+            # one WIDE panel: all output tiles accumulate at once (accW0..), chunks in [k-step][tile] order; the encoding k-steps come
+            # through the wave-private LDS ring ('ring', sequence index), the activation k-steps from registers as everywhere
+            nt = len(op.tiles)
+            first = len(slots)
+            for ks in range(op.nk):
+                seg, ksl = plan.seg_of(op, ks)
+                if seg.regset == "encg":
+                    b = ("ring", ring_seq)
+                    ring_seq += 1
+                else:
+                    assert seg.regset in ("X", "Y")
+                    b = ("reg", f"{seg.regset}[{seg.reg0 + ksl}]")
+                for t in range(nt):
+                    slots.append(dict(acc=f"accW{t}", b=b, panel=len(panels), ks=ks, first_of_ks=(t == 0)))
+            panels.append(dict(op=op, t0=None, t1=None, tiles=list(range(nt)), wide=True, first=first, n=len(slots) - first, pair=None, spk=nt))
+            continue
         for (t0, t1) in plan.panels(op):
             pair = len(panels) & 1
             first = len(slots)
@@ -205,10 +227,10 @@ def epilogue_pieces(plan, pn):
     op, pair = pn["op"], pn["pair"]
     relu = "true" if op.relu else "false"
     pieces = []
-    for which, t in ((0, pn["t0"]), (1, pn["t1"])):
+    for which, t in ([(t, t) for t in pn["tiles"]] if pn.get("wide") else ((0, pn["t0"]), (1, pn["t1"]))):
         if t is None:
             continue
-        acc = f"acc{pair}{which}"
+        acc = f"accW{t}" if pn.get("wide") else f"acc{pair}{which}"
         if op.out in ("X", "Y"):
             if op.name == "head" and t == len(op.tiles) - 1:
                 pieces.append(f"raw_density = {acc}[0];   // row 0 of the density tile (lanes hi=0)")
@@ -222,6 +244,8 @@ def epilogue_pieces(plan, pn):
 
 def bias_pieces(plan, pn):
     op, pair = pn["op"], pn["pair"]
+    if pn.get("wide"):
+        return [f"BIAS(accW{t}, {op.first_tile + t});" for t in pn["tiles"]]
     if op.pre:      # accumulator images written by k_pre_gemm (gen_pre_gemm.py): 4 KiB per tile and wave, four lane-linear 1-KiB loads
         out = [f"pre_load(acc{pair}0, pre_lane + {pn['t0'] * 4096});"]
         if pn["t1"] is not None:
@@ -480,6 +504,93 @@ DEEP_RING_MACRO = r"""// One wave per SIMD (the 512-wide trunk, gen_mlp_bf16.wav
 """
 
 
+FUSED_MACROS = r"""// ---- one-kernel form of a wide encoding (Plan.fused) ----
+// One k-step of the encoding (1 KiB fragment of this wave tile: 16 bytes per lane) from global memory into the wave-private LDS ring.
+// Wave-private: the wave that issues the DMA is the wave that reads the slot, so its own counted vmcnt orders the read behind the landing
+// (no barrier).  Uniform source base + the 32-bit lane offset (saddr form), like issue_group.
+__device__ __forceinline__ void enc_dma(const char* gsrc, char* ldst, unsigned lane16) {
+    asm volatile("" : "+s"(gsrc));      // opaque: one scalar add per DMA instead of a hoisted 64-bit base per k-step
+    const unsigned lds_addr = (unsigned)(size_t)(__attribute__((address_space(3))) char*)ldst;
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane16), "s"(gsrc), "s"(lds_addr)
+        : "memory");
+}
+#define ENC_DMA(i, base, goff, loff) enc_dma((base) + (goff), encw + (loff), lane16)
+// a wave-uniform pointer the compiler can keep in SGPRs (the tile index is loop-carried: its divergence analysis gives up on it)
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)p), hi_ = __builtin_amdgcn_readfirstlane((unsigned)((size_t)p >> 32));
+    return reinterpret_cast<const char*>(((size_t)hi_ << 32) | lo);
+}
+// Ring-group boundary with a COUNTED vmcnt: K = the vector-memory operations this wave has issued since its DMAs of group g (the encoding
+// DMAs of the k-steps in between), which stay in flight; everything older -- group g included -- has landed when the wait returns.
+#define GROUP_BEGIN_CNT(g, nslot, K)                                                              \
+    do {                                                                                          \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(K) : "memory");          \
+        if ((g) + 1 < kNumGroups) issue_group<DMA>(stream, smem, (g) + 1, (nslot), wave, lane16); \
+        else if (has_next) issue_group<DMA>(stream, smem, 0, (nslot), wave, lane16);              \
+    } while (0)
+"""
+
+
+def count_waits(lines, start, cpw, ngroups):
+    """Fused form: fill in the counted vmcnt of every GROUP_BEGIN_CNT and RING_WAIT of the tile body lines[start:] (program order = text
+    order: the body is straight-line code between sched_barriers, its DMAs are asm volatile).  Model: the wave's vector-memory operations
+    retire in issue order; a wait for operation x with K younger operations issued since is `vmcnt(K)`.  GROUP_BEGIN(0) at the tile start
+    waits for everything (the previous tile's stores, this tile's view encoding, the first encoding k-steps)."""
+    log = []                 # tags of the operations issued since the last full wait, in issue order
+    unknown = False          # a conditionally issued DMA is in the log: no counted wait may follow before the next full wait
+    tok = re.compile(r"GROUP_BEGIN\(0, \d+\)|GROUP_BEGIN_CNT\((\d+), (\d+), @VM@\)|ENC_DMA\((\d+),|RING_WAIT\((\d+)\); ")
+    kmax = 0
+
+    def wait_for(tag):
+        nonlocal log, kmax
+        assert not unknown, "counted wait behind a conditionally issued DMA"
+        if tag not in log:
+            return None                      # issued before the last full wait: landed
+        last = max(i for i, t in enumerate(log) if t == tag)
+        k = len(log) - 1 - last
+        assert k <= 56, k
+        kmax = max(kmax, k)
+        log = log[last + 1:]
+        return k
+    for li in range(start, len(lines)):
+        line = lines[li]
+        out, pos = [], 0
+        for m in tok.finditer(line):
+            out.append(line[pos:m.start()])
+            pos = m.end()
+            t = m.group(0)
+            if t.startswith("GROUP_BEGIN(0"):
+                log, unknown = [], False     # full wait
+                log += [("grp", 1)] * cpw
+                out.append(t)
+            elif t.startswith("GROUP_BEGIN_CNT"):
+                g = int(m.group(1))
+                k = wait_for(("grp", g))
+                assert k is not None, g
+                out.append(f"GROUP_BEGIN_CNT({g}, {m.group(2)}, {k})")
+                if g + 1 < ngroups:
+                    log += [("grp", g + 1)] * cpw
+                else:
+                    unknown = True            # the tile's last boundary issues the NEXT tile's group 0 only when there is one
+            elif t.startswith("ENC_DMA"):
+                log.append(("enc", int(m.group(3))))
+                out.append(t)
+            else:                             # RING_WAIT(i);
+                k = wait_for(("enc", int(m.group(4))))
+                out.append("" if k is None else f'asm volatile("s_waitcnt vmcnt({k})" ::: "memory"); ')
+        out.append(line[pos:])
+        lines[li] = "".join(out)
+    return kmax
+
+
 def _shadow_fits(plan: Plan) -> bool:
     """Three ops behind the last encoding reader with >= 2 x 18 MFMA slots each (gen_kernel places one encoding k-step per op)."""
     last = max(i for i, op in enumerate(plan.ops) if any(sg.regset == "enc" for sg in op.segs))
@@ -496,6 +607,9 @@ def waves_of(arch: Arch) -> int:
 
 def gen_kernel(plan: Plan, variant: int = 0) -> str:
     pre = plan.pre_gemm        # trunk of the two-kernel form (mlp_pre_plan.py): X preloaded, skip-layer accumulators from k_pre_gemm
+    fused = plan.fused         # one-kernel form of the same variants: layer 0 and the skip layer as k-step-major ops over a streamed encoding
+    ENC_WAVE_BYTES = (2 + FUSED_RING) * 1024 if fused else globals()["ENC_WAVE_BYTES"]       # fused: 2 KiB view encoding + the encoding ring
+    assert not fused or (1 < FUSED_AHEAD <= FUSED_RING - 1)
     WAVES = waves_of(plan.arch)                 # (shadow the module defaults: everything below is per kernel)
     wide = max(plan.arch.net_width, plan.arch.net_width_condition) > 256      # one wave per SIMD, 512-register budget
     # chunks a wave DMAs per ring group.  The one-wave-per-SIMD kernels can take 8 (MLP_WIDE_CPW): a group is then 32 of a wave's MFMAs, so the
@@ -513,13 +627,14 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     AHEAD = int(os.environ.get("MLP_WIDE_AHEAD", "2")) if wide else 1         # ring groups in flight (GROUP_BEGIN_DEEP); the 8-wave kernels: 1
     SPARE = wide and os.environ.get("MLP_WIDE_SPARE_SLOT", "1") == "1"           # one more ring slot than groups in flight: no LDS drain at the group boundaries
     SLOTS = (AHEAD + (2 if SPARE else 1)) if wide else globals()["SLOTS"]
-    sfx = f"_pre_v{variant}" if pre else ("" if variant == 0 else f"_v{variant}")
+    sfx = f"_pre_v{variant}" if pre else (f"_fused_v{variant}" if fused else ("" if variant == 0 else f"_v{variant}"))
     nchunks = len(plan.chunks)
     assert nchunks % GROUP == 0, "stream must be a whole number of ring groups"
     ngroups = nchunks // GROUP
     assert ngroups % SLOTS == 0, "tile-to-tile ring phase must be stable"
     a = plan.arch
-    nenc = 0 if pre else a.xyz_dim // 16
+    nenc = 0 if (pre or fused) else a.xyz_dim // 16
+    nk_enc = a.xyz_dim // 16      # (fused: encoding k-steps of one pass over the fragment run of a wave tile)
     assert (nenc + 2) * 1024 <= ENC_WAVE_BYTES
     nbias_bytes = plan.n_tiles * 128
     ring_bytes = SLOTS * GROUP * CHUNK_BYTES
@@ -543,8 +658,9 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     if variant:
         a_ = plan.arch
         e(f"// architecture variant {variant}: depth {a_.net_depth} width {a_.net_width} cond {a_.net_depth_condition}x{a_.net_width_condition} "
-          f"use_viewdirs={int(a_.use_viewdirs)}" + (" -- TRUNK of the two-kernel form (layers 1.., mlp_pre_plan.py)" if pre else ""))
-        e(f"namespace v{variant}{'pre' if pre else ''} {{")
+          f"use_viewdirs={int(a_.use_viewdirs)}" + (" -- TRUNK of the two-kernel form (layers 1.., mlp_pre_plan.py)" if pre else "")
+          + (" -- ONE-kernel form of the wide encoding (Plan.fused)" if fused else ""))
+        e(f"namespace v{variant}{'pre' if pre else ('fused' if fused else '')} {{")
     e("typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;")
     e("typedef __attribute__((ext_vector_type(16))) float f32x16;")
     if pre and ABLATE_PRELOADS:
@@ -574,11 +690,13 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
       .replace("WAIT_INSN", "s_waitcnt lgkmcnt(0)" if ABLATE_WAIT else "s_waitcnt vmcnt(0) lgkmcnt(0)"))
     if wide:
         e(DEEP_RING_MACRO)
+    if fused:
+        e(FUSED_MACROS)
     e("template <bool DMA, bool IPE>")
     e(f"__global__ void __launch_bounds__({WAVES * 64}, {1 if wide else 2})")
     e("k_mlp_bf16(const char* __restrict__ stream, const float* __restrict__ bias_tab,")
-    if pre:
-        e("           const char* __restrict__ pre_x, const char* __restrict__ pre_acc,")
+    if pre or fused:
+        e("           const char* __restrict__ pre_x, const char* __restrict__ pre_acc,       // fused: pre_x = the encoding's fragment buffer, pre_acc unused")
     e("           const __bf16* __restrict__ enc, const __bf16* __restrict__ viewenc, float4* __restrict__ rgb_sigma,")
     e("           float4* __restrict__ raw_out, int64_t M, int num_samples, int ntiles, float density_bias,")
     e("           float rgb_padding, RayIn rin, const float* __restrict__ dnoise, float dnoise_scale) {")
@@ -603,6 +721,12 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         for g in range(AHEAD):
             e(f"        issue_group<DMA>(stream, smem, {g}, {g}, wave, lane16);")
         e("    }")
+    elif fused:
+        e("    if ((int)blockIdx.x < ntiles) {")
+        e("        issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
+        e(f"        const char* encb = uniform_ptr(pre_x + ((int64_t)blockIdx.x * {WAVES} + wave) * {nk_enc * 1024});      // the first tile's first encoding k-steps")
+        e("        PROLOGUE_ENC_DMAS")
+        e("    }")
     else:
         e("    if ((int)blockIdx.x < ntiles) issue_group<DMA>(stream, smem, 0, 0, wave, lane16);")
     if shadow:
@@ -621,7 +745,7 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         e("        IpeNext ipn;")
         e("        float ipe_y = 0.0f, ipe_d = 0.0f;")
         e("        bf16x8 ipe_fs, ipe_fc;")
-    if pre:
+    if pre or fused:
         e("        issue_encodings<DMA, 0, 0>(nullptr, viewenc + ray * 32 + hi * 8, encw, lane16);")
     else:
         e("        if (IPE) {")
@@ -640,6 +764,10 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         for k in range(16):
             e(f"        X[{k}] = PRE_LD(reinterpret_cast<const bf16x8*>(prex_lane + {k * 1024}));")
     e("        f32x16 acc00, acc01, acc10, acc11;")
+    if fused:
+        e("        f32x16 " + ", ".join(f"accW{t}" for t in range(a.net_width // 32)) + ";      // the k-step-major ops: all output tiles of a layer at once")
+        e(f"        const char* encb = uniform_ptr(pre_x + ((int64_t)tile * {WAVES} + wave) * {nk_enc * 1024});                     // this wave tile's fragment run")
+        e(f"        const char* encb_next = uniform_ptr(has_next ? pre_x + ((int64_t)(tile + (int)gridDim.x) * {WAVES} + wave) * {nk_enc * 1024} : encb);")
     e("        float raw_density = 0.0f, raw_r = 0.0f, raw_g = 0.0f, raw_b = 0.0f;")
 
     def lda(c):
@@ -665,7 +793,10 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
             ecount += 1
             spk = panels[sl["panel"]]["spk"]
             at = c - 2 * spk          # two k-steps ahead; the register's previous user is 3 k-steps back
-            stmt = f"{cur_e} = LDB({val});"
+            if kind == "ring":        # k-step `val` of the streamed encoding: its DMA must have landed (counted wait, filled in below)
+                stmt = f"RING_WAIT({val}); {cur_e} = LDB({2048 + (val % FUSED_RING) * 1024});"
+            else:
+                stmt = f"{cur_e} = LDB({val});"
             if at < 0:
                 prologue.append(stmt)
             else:
@@ -674,13 +805,14 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     # sanity: an E load at slot `at` (emitted after that slot's MFMA) must not precede a pending user
     last_use = {}
     for c in range(nreal):
-        if slots[c]["b"][0] == "lds":
+        if slots[c]["b"][0] in ("lds", "ring"):
             last_use[b_expr[c]] = c
         for stmt in side[c]:
-            if stmt[0] == "E" and stmt[2] == " ":
-                reg = stmt[:2]
+            m_e = re.search(r"(?:^|; )(E\d) = LDB", stmt)
+            if m_e:
+                reg = m_e.group(1)
                 # every user of the PREVIOUS value of reg must be <= c
-                prev_users = [u for u in range(c + 1, nreal) if slots[u]["b"][0] == "lds" and b_expr[u] == reg]
+                prev_users = [u for u in range(c + 1, nreal) if slots[u]["b"][0] in ("lds", "ring") and b_expr[u] == reg]
                 first_new = prev_users[0] if prev_users else None
                 assert first_new is None or first_new > c
                 assert last_use.get(reg, -1) <= c
@@ -688,10 +820,20 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     # ---- epilogue of the previous panel / bias of the next panel, spread over this panel ----------
     for pi, pn in enumerate(panels):
         work = []
-        if pi > 0:
-            work += epilogue_pieces(plan, panels[pi - 1])
-        if pi + 1 < len(panels):
-            work += bias_pieces(plan, panels[pi + 1])
+        nxt = panels[pi + 1] if pi + 1 < len(panels) else None
+        if pn.get("wide"):
+            # A wide panel keeps 8 accumulator tiles (128 registers) live: its predecessor's epilogue and its own bias loads run between
+            # the predecessor's last MFMA and its first one (a bubble of ~50 VALU / LDS instructions per wide op, two per tile), and the
+            # bias loads of the panel behind it wait for its last MFMA (the input set is dead from there on)
+            if pi > 0:
+                side[pn["first"] - 1] += epilogue_pieces(plan, panels[pi - 1]) + bias_pieces(plan, pn)
+            if nxt is not None:
+                side[pn["first"] + pn["n"] - 1] += bias_pieces(plan, nxt)
+        else:
+            if pi > 0:
+                work += epilogue_pieces(plan, panels[pi - 1])
+            if nxt is not None and not nxt.get("wide"):
+                work += bias_pieces(plan, nxt)
         n = pn["n"]
         for wi, stmt in enumerate(work):
             at = min(2 + wi, n - 1)     # start two slots in: the previous panel's last MFMAs have drained
@@ -704,6 +846,28 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
                     at = min(at, readers[0] - pn["first"] - 1)
             side[pn["first"] + at].append(stmt)       # at == -1: right behind the last MFMA of the producing panel
     _check_hazards(plan, panels, slots, b_expr, side)
+
+    # ---- fused form: DMA of every encoding k-step into the wave-private ring, FUSED_AHEAD k-steps ahead of its MFMAs ------------------
+    # ring sequence i = 0 .. nring - 1 over the tile (layer 0, then the skip layer); slot i % FUSED_RING; source = fragment i % nk_enc of
+    # the wave tile.  DMA(i) goes behind the first MFMA of sequence i - FUSED_AHEAD (by then sequence i - FUSED_RING has been consumed);
+    # the first FUSED_AHEAD of a tile are issued by the PREVIOUS tile right behind its last ring k-step (kernel prologue for the first tile).
+    enc_prologue = []
+    if fused:
+        first_slot = {}
+        for c, sl in enumerate(slots):
+            if sl["b"][0] == "ring" and sl["first_of_ks"]:
+                first_slot[sl["b"][1]] = c
+        nring = len(first_slot)
+        assert nring % nk_enc == 0 and nring >= FUSED_RING
+        for i in range(nring):
+            stmt = f"ENC_DMA({i}, encb, {(i % nk_enc) * 1024}, {2048 + (i % FUSED_RING) * 1024});"
+            if i < FUSED_AHEAD:
+                enc_prologue.append(stmt)
+            else:
+                side[first_slot[i - FUSED_AHEAD]].append(stmt)
+        last_ring = max(c for c, sl in enumerate(slots) if sl["b"][0] == "ring")
+        for i in range(FUSED_AHEAD):      # the next tile's first k-steps (a harmless re-read of this tile's on the last tile)
+            side[last_ring].append(f"ENC_DMA({nring + i}, encb_next, {i * 1024}, {2048 + (i % FUSED_RING) * 1024});")
 
     # ---- the next tile's integrated positional encoding, in pieces, behind the last reader of this tile's encoding ----
     # One k-step (8 feature pairs + its LDS store) per op, in the FIRST HALF of that op's slots: there most of the op's output
@@ -741,7 +905,10 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
             if SPARE and g != 0:
                 return f"GROUP_BEGIN_DEEP_NODRAIN({g}, {CPW * (AHEAD - 1)});{note}"
             return f"GROUP_BEGIN_DEEP({g}, {0 if g == 0 else CPW * (AHEAD - 1)});{note}"
+        if fused and g != 0:
+            return f"GROUP_BEGIN_CNT({g}, {(g + 1) % SLOTS}, @VM@);{note}"      # counted vmcnt, filled in by count_waits below
         return f"GROUP_BEGIN({g}, {(g + 1) % SLOTS});{note}"
+    body_start = len(lines)
     e(f"        {group_begin(0)}")
     for c in range(PREFETCH):
         e(f"        {lda(c)}")
@@ -771,6 +938,13 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         e(f"        {group_begin(g, pad_note)}")
     for stmt in epilogue_pieces(plan, panels[-1]):
         e(f"        {stmt}")
+    if fused:
+        kmax = count_waits(lines, body_start, CPW, ngroups)      # fill in the counted waits of the tile body
+        text = "\n".join(lines)
+        assert "@VM@" not in text and "RING_WAIT" not in text
+        for i, ln in enumerate(lines):
+            if "PROLOGUE_ENC_DMAS" in ln:
+                lines[i] = "\n".join("        " + st for st in enc_prologue)
     e("        if (hi == 0 && s < M) {")
     e("            // mip_nerf.py:232-233: raw_density += density_noise * randn (randomized training only), BEFORE the activation")
     e("            const float noisy_density = dnoise ? raw_density + dnoise_scale * dnoise[s] : raw_density;")
@@ -779,18 +953,19 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
     e("            if (raw_out) raw_out[s] = make_float4(raw_r, raw_g, raw_b, raw_density);")
     e("        }")
     e("    }")
-    if wide:
+    if wide or fused:
         e('    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the refill runs around the stream: no LDS-DMA may land after the workgroup has released its LDS')
     e("}")
     e("")
     if variant:
-        e(f"}}  // namespace v{variant}{'pre' if pre else ''}")
-        e(f"using namespace v{variant}{'pre' if pre else ''};")
+        e(f"}}  // namespace v{variant}{'pre' if pre else ('fused' if fused else '')}")
+        e(f"using namespace v{variant}{'pre' if pre else ('fused' if fused else '')};")
     else:
         e("int mlp_bf16_lds_bytes() { return kLdsBytes; }")
     e("")
-    if pre:
+    if pre or fused:
         e("// pre_x / pre_acc: the two outputs of launch_pre_gemm for the same M (16 KiB + 32 KiB per wave tile of 32 samples)")
+        e("// (one-kernel form: pre_x = the encoding's fragment buffer -- whole 256-sample tiles, as k_cast_ipe_360 writes it --, pre_acc = nullptr)")
         e(f"hipError_t launch_mlp_bf16{sfx}(const void* stream_w, const float* bias_tab, const void* pre_x, const void* pre_acc, const void* viewenc,")
         e("                           float* rgb_sigma, float* raw_out, int64_t M, int num_samples, float density_bias,")
         e("                           float rgb_padding, int grid_limit, const float* dnoise, float dnoise_scale, hipStream_t st) {")

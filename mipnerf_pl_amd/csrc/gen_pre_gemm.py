@@ -539,10 +539,14 @@ def variants_header(vis, n):
         L.append(f"hipError_t launch_pre_gemm_v{vi}(const void*, const float*, const void*, int, void*, void*, int64_t, int, hipStream_t);")
         L.append(f"hipError_t launch_mlp_bf16_pre_v{vi}(const void*, const float*, const void*, const void*, const void*, float*, float*, int64_t, int, float,")
         L.append("                                   float, int, const float*, float, hipStream_t);")
+        L.append(f"hipError_t launch_mlp_bf16_fused_v{vi}(const void*, const float*, const void*, const void*, const void*, float*, float*, int64_t, int, float,")
+        L.append("                                     float, int, const float*, float, hipStream_t);")
         L.append(f'extern "C" const unsigned char mip_pre_tables_v{vi}[];')
     f = lambda fmt: ", ".join(fmt.format(vi) if vi in vis else "nullptr" for vi in range(n))
     L.append(f"static const LaunchPreGemmFn kLaunchPreGemm[{n}] = {{{f('launch_pre_gemm_v{}')}}};")
     L.append(f"static const LaunchBf16PreFn kLaunchBf16Pre[{n}] = {{{f('launch_mlp_bf16_pre_v{}')}}};")
+    L.append("// one-kernel form (round 6): same launcher shape as the trunk's; pre_x = the encoding's fragment buffer, pre_acc = nullptr")
+    L.append(f"static const LaunchBf16PreFn kLaunchBf16Fused[{n}] = {{{f('launch_mlp_bf16_fused_v{}')}}};")
     L.append(f"static const unsigned char* const kPreTableBlobs[{n}] = {{{f('mip_pre_tables_v{}')}}};")
     L.append("}  // namespace mip")
     return "\n".join(L) + "\n"
@@ -558,6 +562,10 @@ def main():
             f.write(gen_gemm_once(p, vi) if once else gen_gemm(p, vi))
         with open(os.path.join(outdir, f"mlp_bf16_pre_gen_v{vi}.hip"), "w") as f:
             f.write(gb.gen_kernel(p.trunk, vi))
+        # round 6: the ONE-kernel form of the same model (Plan.build(arch, fused=True)): layer 0 and the skip layer as k-step-major ops of the trunk
+        # kernel, their encoding streamed through a wave-private LDS ring; its pack / bias tables ride behind the two-kernel form's in the blob
+        with open(os.path.join(outdir, f"mlp_bf16_fused_gen_v{vi}.hip"), "w") as f:
+            f.write(gb.gen_kernel(p.fused, vi))
         with open(os.path.join(outdir, f"_gen_pre_tables_v{vi}.bin"), "wb") as f:
             f.write(p.blob())
         print(f"variant {vi}: pre-GEMM {p.n_real_chunks} chunks ({p.nk} k-steps x {p.ntiles} tiles x 2 passes), trunk {p.trunk.n_real_chunks} "

@@ -209,7 +209,7 @@ struct ParamPtrs {
 };
 // table entry: -1 => 0, else (tensor << 20) | element offset
 hipError_t launch_pack(const int32_t* table, int64_t n, const ParamPtrs& ptrs, void* out, bool bf16, hipStream_t st);
-constexpr int kMaxPackSegments = 12;
+constexpr int kMaxPackSegments = 16;
 struct PackSegments {              // several (table -> stream) packs as one launch
     int n;
     int64_t start[kMaxPackSegments + 1];

@@ -49,7 +49,7 @@ PARAM_ORDER_DOC = "layers.{0..D-1}.0.{weight,bias}, density_layer, extra_layer, 
 @dataclass
 class Seg:
     """A run of k-steps of a layer input taken from one register set."""
-    regset: str        # 'enc' | 'view' | 'X' | 'Y'
+    regset: str        # 'enc' | 'view' | 'X' | 'Y' | 'encg' (one-kernel form of wide encodings: streamed from global memory through a wave-private LDS ring)
     kind: int          # NATURAL | DLAYOUT
     nk: int            # k-steps (16 features each)
     col0: int          # first column of the torch weight this segment multiplies
@@ -76,6 +76,7 @@ class Op:
     out: str           # register set written: 'X' | 'Y' | 'head' | 'rgb'
     first_tile: int = 0   # global tile index of tiles[0] (bias table row)
     pre: bool = False     # accumulators start from pre-activations computed by the pre-GEMM kernel (mlp_pre_plan.py), not from the bias
+    kmajor: bool = False  # all output tiles of the op accumulate at once, chunks in [k-step][tile] order (Plan.fused: the ops that read the wide encoding)
 
     @property
     def nk(self):
@@ -137,16 +138,19 @@ class Plan:
     n_tiles: int = 0
     n_real_chunks: int = 0
     pre_gemm: bool = False     # trunk of the two-kernel bf16 form (mlp_pre_plan.py): no encoding segments, layer 0 done elsewhere
+    fused: bool = False        # ONE-kernel form of a wide encoding (round 6): layer 0 and the skip layer are k-step-major ops with all 8 output
+                               # tiles live, their encoding k-steps streamed global -> wave-private LDS ring -> B operand
 
     # ---- construction -----------------------------------------------------------------
     @staticmethod
-    def build(arch: Arch = None, pre_gemm: bool = False) -> "Plan":
+    def build(arch: Arch = None, pre_gemm: bool = False, fused: bool = False) -> "Plan":
         """pre_gemm: the TRUNK of the two-kernel bf16 form used for encodings too wide for the wave-private LDS area (mlp_pre_plan.py):
         layer 0 and the encoding part of the skip layer are a separate k-step-major GEMM kernel; this plan starts at layer 1 with the
         register set X preloaded from memory (bf16(relu(layer 0))) and the skip layer's accumulators initialised from the GEMM's fp32
         partial sums (Op.pre) instead of the bias."""
         a = arch or Arch()
-        wmax = 256 if pre_gemm else 512      # (above 256 the bf16 kernel runs one wave per SIMD: gen_mlp_bf16.waves_of)
+        assert not (pre_gemm and fused)
+        wmax = 256 if (pre_gemm or fused) else 512      # (above 256 the bf16 kernel runs one wave per SIMD: gen_mlp_bf16.waves_of)
         if a.net_width % TILE or a.net_width_condition % TILE or a.net_width > wmax or a.net_width_condition > wmax:
             raise NotImplementedError("MFMA kernels need widths that are multiples of 32 and <= 512 (<= 256 for the two-kernel trunk form)")
         if a.xyz_dim % KSTEP or a.view_dim > 32 or a.num_rgb > 4 or a.num_density != 1:
@@ -156,7 +160,8 @@ class Plan:
         if not a.use_viewdirs and a.net_width_condition != a.net_width:
             raise NotImplementedError("use_viewdirs=False feeds the trunk output (net_width) to color_layer "
                                       "(net_width_condition inputs): the reference fails unless the two widths are equal")
-        p = Plan(a, pre_gemm=pre_gemm)
+        p = Plan(a, pre_gemm=pre_gemm, fused=fused)
+        encset = "encg" if fused else "enc"
         names = [n for n, _ in a.param_shapes()]
         pid = {n: i for i, n in enumerate(names)}
         W, E = a.net_width, a.xyz_dim
@@ -168,18 +173,22 @@ class Plan:
                 if pre_gemm:                       # X = bf16(relu(layer 0)) arrives from the pre-GEMM kernel
                     cur, other = "X", "Y"
                     continue
-                segs.append(Seg("enc", NATURAL, E // KSTEP, 0, E))
+                segs.append(Seg(encset, NATURAL, E // KSTEP, 0, E))
                 ld = E
             else:
                 segs.append(Seg(cur, DLAYOUT, W // KSTEP, 0, W))
                 ld = W
                 if is_skip:
-                    if not pre_gemm:
+                    if fused:
+                        # encoding part FIRST: the order of the two-kernel form (k_pre_gemm's partial sums, then the trunk's 16 k-steps on
+                        # top), so both forms add the same products in the same order and agree bit for bit
+                        segs.insert(0, Seg(encset, NATURAL, E // KSTEP, W, E))
+                    elif not pre_gemm:
                         segs.append(Seg("enc", NATURAL, E // KSTEP, W, E))
                     ld = W + E
             tiles = [TileSrc(pid[f"layers.{i}.0.weight"], pid[f"layers.{i}.0.bias"], t * TILE, TILE, ld)
                      for t in range(W // TILE)]
-            p.ops.append(Op(f"layer{i}", segs, tiles, True, other, pre=pre_gemm and is_skip))
+            p.ops.append(Op(f"layer{i}", segs, tiles, True, other, pre=pre_gemm and is_skip, kmajor=fused and (i == 0 or is_skip)))
             cur, other = other, ("Y" if other == "X" else "X")
         # head: bottleneck (no activation) + density row as an extra tile; without view directions only the density row
         # (extra_layer and view_layers stay unused parameters, mip_nerf.py:99-110)
@@ -210,6 +219,11 @@ class Plan:
         for oi, op in enumerate(p.ops):
             op.first_tile = gt
             gt += len(op.tiles)
+            if op.kmajor:                          # [k-step][tile]: every k-step's B operand feeds all tiles of the op back to back
+                for ks in range(op.nk):
+                    for t in range(len(op.tiles)):
+                        p.chunks.append((oi, t, ks))
+                continue
             for (t0, t1) in p.panels(op):
                 if CHAIN:
                     for t in (t0, t1):
@@ -389,7 +403,7 @@ def emulate_wave(plan: Plan, flat_params: np.ndarray, enc: np.ndarray, view: np.
     if plan.pre_gemm:
         regs["X"] = pre_x
     else:
-        regs["enc"] = natural(enc, plan.arch.xyz_dim // 16)
+        regs["encg" if plan.fused else "enc"] = natural(enc, plan.arch.xyz_dim // 16)
     regs["view"] = natural(view, 2)
     ci = 0
     result = {}
@@ -398,11 +412,11 @@ def emulate_wave(plan: Plan, flat_params: np.ndarray, enc: np.ndarray, view: np.
         acc = np.zeros((nt, 64, 16), np.float32)
         for ti in range(nt):
             acc[ti] = pre_acc[ti] if op.pre else bias[op.first_tile + ti][lanes_hi]      # accumulator initialised with bias
-        for (t0, t1) in plan.panels(op):
+        for tiles_of_panel in ([tuple(range(nt))] if op.kmajor else [((t0,) if t1 is None else (t0, t1)) for (t0, t1) in plan.panels(op)]):
             for ks in range(op.nk):
                 seg, ksl = plan.seg_of(op, ks)
                 b = regs[seg.regset][seg.reg0 + ksl]               # [64, 8]
-                for t in ((t0,) if t1 is None else (t0, t1)):
+                for t in tiles_of_panel:
                     assert plan.chunks[ci] == (plan.ops.index(op), t, ks)
                     a = stream[ci]
                     ci += 1

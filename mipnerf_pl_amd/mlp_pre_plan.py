@@ -51,6 +51,7 @@ def supported(a: Arch) -> bool:
 class PrePlan:
     arch: Arch
     trunk: Plan = None
+    fused: Plan = None                                      # the one-kernel form of the same model (round 6)
     skip_layer: int = 0
     nk: int = 0                                             # encoding k-steps
     chunks: List[Tuple[int, int, int]] = field(default_factory=list)      # (pass = matrix, ks, tile); pass -1: zero padding
@@ -61,7 +62,7 @@ class PrePlan:
     def build(arch: Arch, split: bool = None) -> "PrePlan":
         if not supported(arch):
             raise NotImplementedError("the pre-GEMM form is generated for fp32-only variants with a wide encoding, a 256-wide trunk and one skip layer")
-        p = PrePlan(arch, trunk=Plan.build(arch, pre_gemm=True), split=SPLIT if split is None else bool(split))
+        p = PrePlan(arch, trunk=Plan.build(arch, pre_gemm=True), fused=Plan.build(arch, fused=True), split=SPLIT if split is None else bool(split))
         p.skip_layer = [i for i in range(arch.net_depth) if (i - 1) % arch.skip_index == 0 and i > 1][0]
         p.nk = arch.xyz_dim // KSTEP
         nt = arch.net_width // TILE
@@ -115,14 +116,16 @@ class PrePlan:
         return tab
 
     def blob(self) -> bytes:
-        """header (16 int32) + gemm pack table + gemm bias table + trunk pack table + trunk bias table (flat parameter indices, -1 = zero)"""
+        """header (16 int32) + gemm pack table + gemm bias table + trunk pack table + trunk bias table + (round 6) the one-kernel form's pack
+        and bias tables (flat parameter indices, -1 = zero); h[10] / h[11] = chunks / tiles of the one-kernel form"""
         gp, gb = self.pack_table().ravel(), self.bias_table().ravel()
         tp, tb = self.trunk.pack_table().ravel(), self.trunk.bias_table().ravel()
+        fp, fb = self.fused.pack_table().ravel(), self.fused.bias_table().ravel()
         _, total = self.trunk.param_offsets()
         h = np.zeros(16, np.int32)
-        h[:10] = [MAGIC, len(self.chunks), self.n_real_chunks, gb.size, len(self.trunk.chunks), self.trunk.n_real_chunks, self.trunk.n_tiles,
-                  total, self.nk, self.ntiles]
-        return b"".join(x.astype(np.int32).tobytes() for x in (h, gp, gb, tp, tb))
+        h[:12] = [MAGIC, len(self.chunks), self.n_real_chunks, gb.size, len(self.trunk.chunks), self.trunk.n_real_chunks, self.trunk.n_tiles,
+                  total, self.nk, self.ntiles, len(self.fused.chunks), self.fused.n_tiles]
+        return b"".join(x.astype(np.int32).tobytes() for x in (h, gp, gb, tp, tb, fp, fb))
 
 
 def emulate_pre_gemm(p: PrePlan, flat_params: np.ndarray, enc: np.ndarray, round_bf16: bool = False):

@@ -371,6 +371,41 @@ def test_forward_on_a_trained_unbounded_field_vs_the_360_oracle(G, name, precisi
     assert abs(errs["psnr_vs_scene_pixels"] - errs["oracle_psnr_vs_scene_pixels"]) < (0.1 if precision == "bf16" else 1e-2)
 
 
+@pytest.mark.parametrize("name", ["full360_1000x96", "full360_8192x256"])
+def test_one_kernel_form_equals_the_two_kernel_form_bit_for_bit(G, name):
+    """Round 6: the bf16 forward of the unbounded model as ONE MLP kernel per level (layer 0 and the skip layer as k-step-major
+    ops of the trunk kernel, the 672-wide encoding streamed through a wave-private LDS ring; option 6 = 1, the default) against k_pre_gemm +
+    trunk kernel (option 6 = 0): the same products added in the same order, so EVERY output of both levels is bit-identical -- on the trained
+    field at BASELINE configs[3]'s size and the ragged 1000 x 96 case (partial tiles), with 1 / 5 / 256 persistent workgroups."""
+    g = G.load_golden(name)
+    params = _field360(G)
+    rays = G.to_dev(syn.Rays(*[g["rays_" + k] for k in syn.Rays._fields]))
+    model = _model(params, int(g["num_samples"]), "bf16", density_bias=float(g["density_bias"]))
+    ctx = model.mlp.native(torch.device(DEV))
+    outs = {}
+    try:
+        for form in (1, 0):
+            ctx.set_option(6, form)
+            with torch.no_grad():
+                outs[form] = model(rays, False, True)
+        for grid in (1, 5):
+            ctx.set_option(6, 1)
+            ctx.set_option(1, grid)
+            with torch.no_grad():
+                outs[("grid", grid)] = model(rays, False, True) if name == "full360_1000x96" else None
+    finally:
+        ctx.set_option(6, 1)
+        ctx.set_option(1, 256)
+    for lvl in range(2):
+        for a, b in zip(outs[1][lvl], outs[0][lvl]):
+            assert torch.equal(a, b), (name, lvl)
+        for grid in (1, 5):
+            if outs[("grid", grid)] is not None:
+                for a, b in zip(outs[1][lvl], outs[("grid", grid)][lvl]):
+                    assert torch.equal(a, b), (name, lvl, grid)
+    assert bool(torch.isfinite(outs[1][1][0]).all())
+
+
 # measured on MI355X (profiles/r05_parity.jsonl), 1000 x 96 / 8192 x 256:
 #   fp32  l0 rgb 3.0e-6 / 6.3e-6, l0 acc 3.2e-6 / 6.3e-6, l1 rgb 2.2e-6 / 4.6e-6, l1 acc 3.1e-6 / 4.6e-6, distance / far 1.5e-6 / 1.9e-6, 126 / 117 dB
 #   bf16  l0 rgb 2.1e-3 / 3.7e-3, l0 acc 3.1e-3 / 4.0e-3, l1 rgb 2.9e-3 / 3.0e-3, l1 acc 3.6e-3 / 3.2e-3, empty rays rgb 2.4e-4 / 4.8e-4 and

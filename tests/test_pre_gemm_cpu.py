@@ -103,7 +103,9 @@ def test_streams_and_blob(vi):
     blob = np.frombuffer(p.blob(), np.int32)
     assert blob[0] == MAGIC and blob[1] == blob[2] == 672 and blob[4] == 1152 and blob[5] == 1120 and blob[6] == p.trunk.n_tiles == 70
     assert blob[7] == p.trunk.param_offsets()[1] and blob[8] == 42 and blob[9] == 8
-    assert blob.size == 16 + 672 * 512 + blob[3] + 1152 * 512 + 70 * 32
+    # round 6: the one-kernel form's tables ride behind (1792 chunks: 2 x 336 k-major + the trunk's 1120, no padding; 78 tiles)
+    assert blob[10] == len(p.fused.chunks) == p.fused.n_real_chunks == 1792 and blob[11] == p.fused.n_tiles == 78
+    assert blob.size == 16 + 672 * 512 + blob[3] + 1152 * 512 + 70 * 32 + 1792 * 512 + 78 * 32
 
 
 @pytest.mark.parametrize("split", [True, False])
@@ -217,3 +219,70 @@ def test_compiled_gemm_kernel_keeps_the_counted_waits_honest(vi, tmp_path):
         assert loads[3:23] == [per_gap] * 20 and loads[2] in (per_gap - 1, per_gap) and dma[2:24] == [4] * 22 and loads[1] == depth - 1 and dma[1] == 8
         waits = re.findall(r"s_waitcnt vmcnt\((\d+)\) lgkmcnt\(0\)[^\n]*\n[^\n]*s_barrier", body)      # the wait in front of every ring barrier
         assert len(waits) == 22 and set(waits) == {str(4 + 2 * per_gap - gp.VM_MARGIN)}
+
+
+@pytest.mark.parametrize("vi", VIS)
+def test_one_kernel_form_plan_and_generated_kernel(vi):
+    """Round 6, the ONE-kernel form (Plan.build(arch, fused=True)): layer 0 and the skip layer are k-step-major ops (chunks [k-step][tile], all 8
+    accumulator tiles live), the skip layer adds the encoding part FIRST -- the order of k_pre_gemm + trunk --, so the numpy emulation of the plan
+    gives the two-kernel emulation's bits (fp32 and bf16 rounding); against the oracle MLP to fp32 round-off.  From the generated source: every
+    encoding k-step is DMA'd into the wave-private ring exactly once per pass, FUSED_AHEAD k-steps ahead of its first MFMA and never into a slot
+    whose previous k-step is still to be read; every ring read sits behind a wait that leaves at most the DMAs issued after its own in flight; the
+    ring-group boundaries wait with counted vmcnt too (a full wait would drain the prefetched encoding every 4 k-steps)."""
+    from mipnerf_pl_amd.mlp_plan import emulate_wave
+    a = gb.VARIANTS[vi]
+    p = PrePlan.build(a)
+    pf = p.fused
+    assert [op.kmajor for op in pf.ops[:6]] == [True, False, False, False, False, True]
+    assert [(s_.regset, s_.nk) for s_ in pf.ops[5].segs] == [("encg", 42), ("X", 16)] and pf.ops[0].segs[0].regset == "encg"
+    params = orc.make_params(seed=21, density_gain=10.0, xyz_dim=a.xyz_dim)
+    flat = np.concatenate([params[n].ravel() for n, _ in a.param_shapes()])
+    rng = np.random.default_rng(3)
+    enc = rng.uniform(-1, 1, (32, a.xyz_dim)).astype(np.float32)
+    v27 = rng.uniform(-1, 1, (32, 27)).astype(np.float32)
+    view = np.zeros((32, 32), np.float32)
+    view[:, :27] = v27
+    for rb in (False, True):
+        r1, d1 = emulate_wave(pf, flat, enc, view, rb)
+        r2, d2 = emulate_pre_wave(p, flat, enc, view, rb)
+        assert np.array_equal(r1, r2) and np.array_equal(d1, d2)
+    rr, dd = orc.mlp_forward(params, enc[:, None, :], v27)
+    r1, d1 = emulate_wave(pf, flat, enc, view, False)
+    np.testing.assert_allclose(r1, rr[:, 0], atol=5e-6)
+    np.testing.assert_allclose(d1, dd[:, 0, 0], atol=2e-5)
+    # ---- the generated kernel text ----
+    src = gb.gen_kernel(pf, vi)
+    body = src[src.index("for (int tile = blockIdx.x;"):src.index("if (hi == 0 && s < M)")]
+    R, D = gb.FUSED_RING, gb.FUSED_AHEAD
+    assert len(re.findall(r"\n\s+MFMA\(", body)) == 1792 and "@VM@" not in src and "RING_WAIT" not in src
+    events = []                                   # program order: ("dma", seq) | ("read", ring slot byte offset) | ("mfma", b operand)
+    for ln in body.splitlines():
+        for m in re.finditer(r"ENC_DMA\((\d+), (\w+), (\d+), (\d+)\)|(E\d) = LDB\((\d+)\)|MFMA\((\w+), A\d, ([\w\[\]]+)\)", ln):
+            if m.group(1):
+                events.append(("dma", int(m.group(1)), m.group(2), int(m.group(3)), int(m.group(4))))
+            elif m.group(5):
+                events.append(("read", m.group(5), int(m.group(6))))
+            else:
+                events.append(("mfma", m.group(7), m.group(8)))
+    dmas = [e_ for e_ in events if e_[0] == "dma"]
+    assert [d[1] for d in dmas] == list(range(D, 84 + D))                      # 0 .. D-1: issued by the previous tile (or the kernel prologue)
+    for _, i, base, goff, loff in dmas:
+        assert goff == (i % 42) * 1024 and loff == 2048 + (i % 84 % R) * 1024 and base == ("encb" if i < 84 else "encb_next")
+    pro = src[:src.index("for (int tile = blockIdx.x;")]
+    assert [int(x) for x in re.findall(r"ENC_DMA\((\d+), encb,", pro)] == list(range(D))
+    # ring discipline: walking the events, slot contents and who still has to read them
+    ring_reads = [e_ for e_ in events if e_[0] == "read" and e_[2] >= 2048]
+    assert len(ring_reads) == 84 and [(r[2] - 2048) // 1024 for r in ring_reads] == [i % R for i in range(84)]
+    pos = {("dma", d[1]): k for k, d in enumerate(events) if d[0] == "dma"}
+    reads_at = [k for k, e_ in enumerate(events) if e_[0] == "read" and e_[2] >= 2048]
+    for i in range(D, 84):
+        assert pos[("dma", i)] < reads_at[i]                                   # landed before read is the wait's business; issued before, in any case
+        if i >= R:
+            assert reads_at[i - R] < pos[("dma", i)]                           # the slot's previous k-step has been read (and consumed: its MFMAs follow the read by two k-steps)
+            first_mfma_after_read = next(k for k in range(reads_at[i - R], len(events)) if events[k][0] == "mfma" and events[k][2] == events[reads_at[i - R]][1])
+            assert first_mfma_after_read < pos[("dma", i)]
+    # counted waits: group boundaries never wait for everything inside a tile, ring reads wait with small counts
+    ks_ = [int(x) for x in re.findall(r"GROUP_BEGIN_CNT\(\d+, \d+, (\d+)\)", body)]
+    assert len(ks_) == 55 and max(ks_) <= D + 1 and body.count("GROUP_BEGIN(0, 1);") == 1
+    waits = [int(x) for x in re.findall(r's_waitcnt vmcnt\((\d+)\)" ::: "memory"\); E\d = LDB', body)]
+    assert waits and max(waits) <= D + 4 and min(waits) >= D - 4
