@@ -848,7 +848,7 @@ def run_fp32_c4(args, e):
             mse = float(torch.mean((bout[-1][0] - uout[-1][0]) ** 2))
             unb["bf16"] = {"ms_per_step": round(bdt / bsteps * 1e3, 4), "value": round(B * N * 2 * e.world * bsteps / bdt, 1), "steps": bsteps,
                            "mlp_ms_per_level": round(blaunch, 4), "achieved": round(btf, 2), "peak": PEAK_TFLOPS["bf16"],
-                           "frac": round(btf / PEAK_TFLOPS["bf16"], 4), "kernels": "k_pre_gemm + k_mlp_bf16 (trunk), timed together per level",
+                           "frac": round(btf / PEAK_TFLOPS["bf16"], 4), "kernels": "the one-kernel form (round 6): layer 0 and the skip layer as k-step-major ops of the MLP kernel, timed per level",
                            "psnr_vs_fp32_frame_db": round(float(-10 * math.log10(max(mse, 1e-20))), 2),
                            "finite": bool(torch.isfinite(bout[-1][0]).all()), "traffic": unbounded_bf16_traffic(M)}
         except Exception as ex:  # noqa: BLE001

@@ -1,5 +1,6 @@
 """forward of the unbounded-scene model at BASELINE configs[3] shape (8192 rays x (256 + 256) samples), for rocprofv3 --kernel-trace --stats.
-usage: prof_unbounded.py [fp32|bf16] [iterations]; prints the wall time per forward (torch events)"""
+usage: prof_unbounded.py [fp32|bf16] [iterations] [bf16 form: 1 = one MLP kernel per level (default), 0 = k_pre_gemm + trunk]; prints the wall time
+per forward (torch events)"""
 import os
 import sys
 
@@ -18,6 +19,8 @@ um = MipNerf(num_samples=N, precision=prec, unbounded=True)
 um.load_state_dict({"mlp." + k: torch.from_numpy(v.copy()) for k, v in syn.make_params(seed=0, density_gain=40.0, xyz_dim=672).items()})
 um = um.cuda()
 R = Rays(*[torch.from_numpy(a).cuda() for a in rays_np])
+if len(sys.argv) > 3 and prec == "bf16":
+    um.mlp.native(torch.device("cuda:0")).set_option(6, int(sys.argv[3]))
 with torch.no_grad():
     um(R, False, True)
     torch.cuda.synchronize()
