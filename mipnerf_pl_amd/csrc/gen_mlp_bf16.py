@@ -574,7 +574,9 @@ def count_waits(lines, start, cpw, ngroups):
             elif t.startswith("GROUP_BEGIN_CNT"):
                 g = int(m.group(1))
                 k = wait_for(("grp", g))
-                assert k is not None, g
+                if k is None:                 # an earlier, stricter wait (a ring read behind a younger encoding DMA) has retired this group's DMAs already:
+                    k = len(log)              # nothing to wait for -- whatever is in flight may stay in flight
+                    assert k <= 56
                 out.append(f"GROUP_BEGIN_CNT({g}, {m.group(2)}, {k})")
                 if g + 1 < ngroups:
                     log += [("grp", g + 1)] * cpw
@@ -671,7 +673,9 @@ def gen_kernel(plan: Plan, variant: int = 0) -> str:
         e("#define PRE_LD(ptr) pre_fake(ptr)")
     elif pre and PRE_NT:
         e("#define PRE_LD(ptr) __builtin_nontemporal_load(ptr)")
-    if wide:
+    # (fused: 29 instead of 136 SGPRs spilled to VGPR lanes and -0.3 % per forward in three alternating pairs, profiles/r06g_fused360_ab.txt;
+    #  the ring geometry -- 8 slots / 7 ahead, 8 / 5, 6 / 5 -- is worth nothing: 6.60-6.61 ms all)
+    if wide or (fused and os.environ.get("MLP_FUSED_OPAQUE", "1") == "1"):
         e("#define MIP_OPAQUE_STREAM_BASE 1")
     e(f"constexpr int kRingBytes = {ring_bytes};")
     e(f"constexpr int kBiasBytes = {nbias_bytes};")

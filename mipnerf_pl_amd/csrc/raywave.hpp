@@ -22,6 +22,12 @@ namespace mip {
 #ifndef MIP_WAVE_DPP
 #define MIP_WAVE_DPP 1
 #endif
+// wave_shr:1 (0x138) and row_bcast:15 / :31 (0x142 / 0x143) exist on the GCN / CDNA family only: a device pass for any other
+// architecture falls back to the shuffle forms instead of failing to assemble (this tree builds gfx950 only; the guard costs nothing)
+#if MIP_WAVE_DPP && defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#undef MIP_WAVE_DPP
+#define MIP_WAVE_DPP 0
+#endif
 
 #if MIP_WAVE_DPP
 // lane i <- lane (i - n) within its row of 16 (row_shr:n), lanes without a source get `ident`
