@@ -286,3 +286,75 @@ def test_one_kernel_form_plan_and_generated_kernel(vi):
     assert len(ks_) == 55 and max(ks_) <= D + 1 and body.count("GROUP_BEGIN(0, 1);") == 1
     waits = [int(x) for x in re.findall(r's_waitcnt vmcnt\((\d+)\)" ::: "memory"\); E\d = LDB', body)]
     assert waits and max(waits) <= D + 4 and min(waits) >= D - 4
+
+
+@pytest.mark.parametrize("vi", VIS)
+def test_one_kernel_form_counted_waits_replayed(vi):
+    """An INDEPENDENT replay of the generated one-kernel form's vector-memory traffic (not gen_mlp_bf16.count_waits' own bookkeeping): walk the
+    tile body in program order with the hardware's rule -- a wave's vector-memory operations retire in issue order, `s_waitcnt vmcnt(K)` returns
+    when at most K are outstanding -- and require that (i) when a ring-group boundary's wait returns, this wave's four DMAs of that group have
+    retired (the barrier behind it then makes that true for all eight waves), (ii) every read of an encoding ring slot happens after the DMA of
+    the k-step it expects has retired, and that DMA is the LAST one issued into the slot, (iii) no DMA overwrites a slot whose k-step has not been
+    read yet.  Two tiles back to back, so the hand-over of the next tile's first k-steps is replayed too."""
+    p = PrePlan.build(gb.VARIANTS[vi])
+    src = gb.gen_kernel(p.fused, vi)
+    body = src[src.index("for (int tile = blockIdx.x;"):src.index("if (hi == 0 && s < M)")]
+    pro = src[:src.index("for (int tile = blockIdx.x;")]
+    R, D, NG = gb.FUSED_RING, gb.FUSED_AHEAD, len(p.fused.chunks) // 32
+    tok = re.compile(r"GROUP_BEGIN\(0, \d+\)|GROUP_BEGIN_CNT\((\d+), \d+, (\d+)\)|ENC_DMA\((\d+), (\w+),|s_waitcnt vmcnt\((\d+)\)\" ::: \"memory\"\); |(E\d) = LDB\((\d+)\)")
+    outstanding = []                       # issue order; entries ("grp", g, tile) | ("enc", seq, tile)
+    slot_holds = {}                        # ring slot -> (tile, seq) of the last DMA issued into it
+    retired = set()
+    unread = {}                            # ring slot -> (tile, seq) landed or in flight and not read yet
+    nreads = 0
+
+    def wait(k):
+        while len(outstanding) > k:
+            retired.add(outstanding.pop(0))
+
+    def issue(tag, slot=None):
+        outstanding.append(tag)
+        if slot is not None:
+            assert slot not in unread, ("DMA into a ring slot whose k-step was not read", tag, unread[slot])
+            slot_holds[slot] = tag
+            unread[slot] = tag
+    # kernel prologue: group 0 + the first tile's first D encoding k-steps
+    for _ in range(4):
+        issue(("grp", 0, 0))
+    for i in (int(x) for x in re.findall(r"ENC_DMA\((\d+), encb,", pro)):
+        issue(("enc", i, 0), i % R)
+    for tile in range(2):
+        nread_tile = 0
+        for m in tok.finditer(body):
+            t = m.group(0)
+            if t.startswith("GROUP_BEGIN(0"):
+                wait(0)
+                for _ in range(4):
+                    issue(("grp", 1, tile))
+            elif t.startswith("GROUP_BEGIN_CNT"):
+                g, k = int(m.group(1)), int(m.group(2))
+                wait(k)
+                assert not any(o[0] == "grp" and o[1] == g and o[2] == tile for o in outstanding), ("group not landed at its boundary", g, k)
+                if g + 1 < NG:
+                    for _ in range(4):
+                        issue(("grp", g + 1, tile))
+                else:
+                    for _ in range(4):
+                        issue(("grp", 0, tile + 1))          # has_next
+            elif t.startswith("ENC_DMA"):
+                i, base = int(m.group(3)), m.group(4)
+                tag = ("enc", i % 84, tile + (1 if base == "encb_next" else 0))
+                assert (base == "encb_next") == (i >= 84)
+                issue(tag, (i % 84) % R)
+            elif t.startswith("s_waitcnt"):
+                wait(int(m.group(5)))
+            elif int(m.group(7)) >= 2048:                     # a read of the encoding ring: the nread_tile-th k-step of this tile
+                slot = (int(m.group(7)) - 2048) // 1024
+                want = ("enc", nread_tile, tile)
+                assert slot == nread_tile % R and slot_holds.get(slot) == want, (slot, want, slot_holds.get(slot))
+                assert want in retired, ("ring slot read before its DMA has retired", want, list(outstanding)[:4])
+                del unread[slot]
+                nread_tile += 1
+        assert nread_tile == 84
+        nreads += nread_tile
+    assert nreads == 168
