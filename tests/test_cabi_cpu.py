@@ -357,6 +357,48 @@ def test_one_wave_per_simd_kernel_ring_is_consistent():
     assert 's_waitcnt vmcnt(0)' in tail[:tail.index("\n}\n")]
 
 
+def test_one_wave_per_simd_kernel_ring_replayed():
+    """ADVICE r05 (high) was a counted wait that leaned on DMAs which are not in flight on a workgroup's last tile.  An independent replay of the
+    512-wide kernel's ring (the rule of the hardware: a wave's vector-memory operations retire in issue order, `vmcnt(K)` leaves K outstanding),
+    two tiles back to back with the refill running around the stream: at every group boundary the wave's four DMAs of that group have retired
+    when the wait returns, every A-fragment read comes from the slot its group was DMA'd into LAST, and no refill overwrites a slot before all 16
+    chunks of the group it held have been read."""
+    src = open(os.path.join(REPO, "mipnerf_pl_amd", "csrc", "mlp_bf16_gen_v6.hip")).read()
+    ahead = int(re.search(r"constexpr int kAhead = (\d+);", src).group(1))
+    slots = int(re.search(r"constexpr int kSlots = (\d+);", src).group(1))
+    ngroups = int(re.search(r"constexpr int kNumGroups = (\d+);", src).group(1))
+    pro = src[:src.index("for (int tile = blockIdx.x;")]
+    body = src[src.index("for (int tile = blockIdx.x;"):]
+    body = body[:body.index("if (hi == 0 && s < M)")]
+    outstanding, holds, reads_done = [], {}, {}
+
+    def issue(group_id, slot):
+        prev = holds.get(slot)
+        assert prev is None or reads_done.get(prev, 0) == 16, ("refill over unread chunks", group_id, prev, reads_done.get(prev, 0))
+        holds[slot] = group_id
+        outstanding.extend([group_id] * 4)
+    for g, sl in re.findall(r"issue_group<DMA>\(stream, smem, (\d+), (\d+), wave, lane16\);", pro)[-ahead:]:
+        issue((0, int(g)), int(sl))
+    tok = re.compile(r"GROUP_BEGIN_DEEP(?:_NODRAIN)?\((\d+), (\d+)\);|A\d+ = LDA\((\d+)\);")
+    for tile in range(2):
+        chunk = 0
+        for m in tok.finditer(body):
+            if m.group(3) is None:
+                g, k = int(m.group(1)), int(m.group(2))
+                while len(outstanding) > k:
+                    outstanding.pop(0)
+                assert (tile, g) not in outstanding, ("group not landed at its boundary", tile, g, k)
+                nxt = g + ahead
+                issue((tile + nxt // ngroups, nxt % ngroups), nxt % slots)          # around the stream, unconditionally
+            else:
+                slot = int(m.group(3)) // (16 * 1024)
+                gid = (tile, chunk // 16)
+                assert holds.get(slot) == gid and gid not in outstanding, ("A fragment read from a slot that does not hold its group", gid, holds.get(slot))
+                reads_done[gid] = reads_done.get(gid, 0) + 1
+                chunk += 1
+        assert chunk == ngroups * 16
+
+
 def test_sample_count_limit_is_one_number_everywhere():
     """num_samples <= 1024 = 64 lanes x 16 samples: the header, the ctypes layer, the LDS row constants and the samples-per-lane dispatch of
     every per-ray kernel (buckets 1, 2, 4, 8, 16) say the same."""
