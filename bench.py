@@ -1087,10 +1087,13 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
-    if os.environ.get("MIPNERF_BENCH_WATCHDOG_SECONDS"):
-        # a rank stuck in a collective says WHERE: every thread's Python stack on stderr after N seconds, then exit
+    # a rank stuck in a collective says WHERE: every thread's Python stack on stderr after N seconds, then exit.  On by default for
+    # multi-rank runs (1800 s: a healthy --gpus 8 run takes a few minutes), so that a hang in somebody else's unattended SCALE run leaves
+    # a diagnosis instead of a timeout; MIPNERF_BENCH_WATCHDOG_SECONDS=0 turns it off, any other value sets it (also for one rank)
+    wd = os.environ.get("MIPNERF_BENCH_WATCHDOG_SECONDS", "1800" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "0")
+    if float(wd) > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["MIPNERF_BENCH_WATCHDOG_SECONDS"]), exit=True)
+        faulthandler.dump_traceback_later(float(wd), exit=True)
     e = setup(args)
     PREHEAT["seconds"] = max(0.0, args.preheat_seconds)
     import torch.distributed as dist
