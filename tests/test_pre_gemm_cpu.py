@@ -288,14 +288,19 @@ def test_one_kernel_form_plan_and_generated_kernel(vi):
     assert waits and max(waits) <= D + 4 and min(waits) >= D - 4
 
 
+@pytest.mark.parametrize("ring,ahead", [(8, 7), (8, 5), (6, 5), (4, 3)])
 @pytest.mark.parametrize("vi", VIS)
-def test_one_kernel_form_counted_waits_replayed(vi):
+def test_one_kernel_form_counted_waits_replayed(vi, ring, ahead, monkeypatch):
     """An INDEPENDENT replay of the generated one-kernel form's vector-memory traffic (not gen_mlp_bf16.count_waits' own bookkeeping): walk the
     tile body in program order with the hardware's rule -- a wave's vector-memory operations retire in issue order, `s_waitcnt vmcnt(K)` returns
     when at most K are outstanding -- and require that (i) when a ring-group boundary's wait returns, this wave's four DMAs of that group have
     retired (the barrier behind it then makes that true for all eight waves), (ii) every read of an encoding ring slot happens after the DMA of
     the k-step it expects has retired, and that DMA is the LAST one issued into the slot, (iii) no DMA overwrites a slot whose k-step has not been
     read yet.  Two tiles back to back, so the hand-over of the next tile's first k-steps is replayed too."""
+    # (the shipped geometry is 8 slots / 7 ahead; the others exercise the generator's other paths -- e.g. a group boundary whose DMAs an earlier,
+    #  stricter ring wait has already retired -- with the same replay)
+    monkeypatch.setattr(gb, "FUSED_RING", ring)
+    monkeypatch.setattr(gb, "FUSED_AHEAD", ahead)
     p = PrePlan.build(gb.VARIANTS[vi])
     src = gb.gen_kernel(p.fused, vi)
     body = src[src.index("for (int tile = blockIdx.x;"):src.index("if (hi == 0 && s < M)")]
